@@ -1,0 +1,145 @@
+"""Host-side callers of the plane-sweep forward.
+
+Mirrors, by name and argument meaning, the three functions of the reference that sit
+directly either side of ``MultiViewStereoNet.forward``:
+
+* ``build_image_pyramid``      <- utils/image_utils.py:111-128
+* ``multi_view_unpack_batch``  <- multi_view_stereonet/multi_view_stereonet_utils.py:541-641
+* ``multi_view_forward``       <- multi_view_stereonet/multi_view_stereonet_utils.py:643-662
+
+Nothing here is compute-heavy; it is tensor plumbing on whatever device it is handed
+(PyTorch-ROCm on the GPU box, CPU in the oracle tests).
+"""
+import time
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as F
+
+
+def build_image_pyramid(image: torch.Tensor, num_levels: int) -> List[torch.Tensor]:
+    """Ceil-halving area pyramid: level l has ((h+1)//2, (w+1)//2) of level l-1.
+
+    ``interpolate(mode="area")`` is an adaptive average pool, i.e. an exact 2x2 mean for
+    even sizes and overlapping windows for odd ones (utils/image_utils.py:118-126).
+    """
+    if image.dim() != 4:
+        raise AssertionError("image must be (batch, channels, rows, cols)")
+    levels = [image]
+    while len(levels) < num_levels:
+        prev = levels[-1]
+        size = ((prev.shape[2] + 1) // 2, (prev.shape[3] + 1) // 2)
+        levels.append(F.adaptive_avg_pool2d(prev, size))
+    return levels
+
+
+def build_intrinsics_pyramid(K: torch.Tensor, image_pyr: List[torch.Tensor]) -> List[torch.Tensor]:
+    """Per-level intrinsics with the half-pixel-aware principal point.
+
+    A resize by s maps pixel centre x to s*(x+0.5)-0.5, hence cx' = s*(cx+0.5)-0.5 and
+    fx' = s*fx, with s taken from the actual level sizes as python floats
+    (multi_view_stereonet_utils.py:575-581).
+    """
+    rows0, cols0 = image_pyr[0].shape[-2], image_pyr[0].shape[-1]
+    out = [K]
+    for lvl in range(1, len(image_pyr)):
+        sx = float(image_pyr[lvl].shape[-1]) / cols0
+        sy = float(image_pyr[lvl].shape[-2]) / rows0
+        Kl = K.clone()
+        Kl[:, 0, 0] *= sx
+        Kl[:, 1, 1] *= sy
+        Kl[:, 0, 2] = sx * (Kl[:, 0, 2] + 0.5) - 0.5
+        Kl[:, 1, 2] = sy * (Kl[:, 1, 2] + 0.5) - 0.5
+        out.append(Kl)
+    return out
+
+
+def multi_view_unpack_batch(batch: Dict[str, object], device, num_levels: int) -> Dict[str, object]:
+    """DataLoader batch -> forward() inputs.
+
+    Image pyramids for the reference view and every source view, the K pyramid, the
+    source poses and their inverses with ALL translations divided by the baseline to the
+    FIRST source (multi_view_stereonet_utils.py:597-604), and that baseline.  When the batch
+    carries ground-truth depth it is expressed in the same baseline units and inverted
+    where positive (:615-637).
+    """
+    left = batch["left_image"].to(device)
+    rights = [r.to(device) for r in batch["right_image"]]
+
+    left_pyr = build_image_pyramid(left, num_levels)
+    K = batch["K"].to(device).squeeze(1)
+    K_pyr = build_intrinsics_pyramid(K, left_pyr)
+
+    T_r_in_l, T_l_in_r, right_pyrs = [], [], []
+    for idx, pose in enumerate(batch["T_right_in_left"]):
+        T = pose.to(device).squeeze(1).clone()
+        T_r_in_l.append(T)
+        T_l_in_r.append(torch.linalg.inv(T))
+        right_pyrs.append(build_image_pyramid(rights[idx], num_levels))
+
+    baseline = T_r_in_l[0][:, :3, 3].pow(2).sum(1).sqrt()
+    if not bool((baseline > 0).all()):
+        raise AssertionError("baseline to the first source view must be positive")
+    for T, Tinv in zip(T_r_in_l, T_l_in_r):
+        T[:, :3, 3] /= baseline[:, None]
+        Tinv[:, :3, 3] /= baseline[:, None]
+
+    inputs = {"left_filename": batch.get("left_filename"),
+              "right_filename": batch.get("right_filename"),
+              "T_right_in_left": T_r_in_l,
+              "T_left_in_right": T_l_in_r,
+              "K_pyr": K_pyr,
+              "left_image_pyr": left_pyr,
+              "right_image_pyr": right_pyrs,
+              "baseline": baseline}
+
+    if "left_depthmap_true" in batch:
+        scale = baseline.view(-1, 1, 1, 1)
+        depth = batch["left_depthmap_true"].to(device) / scale
+        inputs["left_depthmap_true"] = depth
+        inputs["left_idepthmap_true"] = torch.where(depth > 0, 1.0 / depth, depth)
+        rd = [d.to(device) / scale for d in batch["right_depthmap_true"]]
+        inputs["right_depthmap_true"] = rd
+        inputs["right_idepthmap_true"] = [torch.where(d > 0, 1.0 / d, d) for d in rd]
+
+    if inputs["left_image_pyr"][0].dtype != torch.float32:
+        raise AssertionError("images must be float32")
+    return inputs
+
+
+def _tick(device_is_gpu: bool):
+    if device_is_gpu:
+        torch.cuda.synchronize()
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        return a, b
+    return time.time(), None
+
+
+def _tock(device_is_gpu: bool, a, b) -> float:
+    if device_is_gpu:
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b)
+    return (time.time() - a) * 1000.0
+
+
+def multi_view_forward(stereo_network, inputs: Dict[str, object], params: Dict[str, object]):
+    """Time and run the network exactly as the reference's wrapper does.
+
+    Timer semantics follow utils/pytorch_utils.py:31-48 (device events bracketed by
+    synchronize on a GPU, wall clock on CPU).  ``cost_volume_filter`` / ``refiners``
+    default to on when the yaml lacks them (the DeMoN params.yaml does).
+    """
+    on_gpu = inputs["left_image_pyr"][0].is_cuda
+    a, b = _tick(on_gpu)
+    out = stereo_network(inputs["left_image_pyr"], inputs["K_pyr"], inputs["T_right_in_left"],
+                         inputs["right_image_pyr"], int(params["num_idepth_samples"]),
+                         bool(params.get("cost_volume_filter", True)),
+                         list(params.get("refiners", [True] * 5)))
+    ms = _tock(on_gpu, a, b)
+    return {"left_idepthmap_pyr": out["left_idepthmap_pyr"],
+            "left_idepthmap_raw_pyr": out["left_idepthmap_raw_pyr"],
+            "left_idepthmap_mask_pyr": out["left_idepthmap_mask_pyr"],
+            "stereo_time_ms": ms}

@@ -1,0 +1,300 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE.
+
+Build-container only: imports the eager reference from /root/reference (with a stub
+``torchvision``, which the hot path imports but never uses), loads the extracted pretrained
+tensors, runs seeded synthetic inputs (multi_view_stereonet_amd.synthetic) through it and
+records inputs, named intermediates and outputs as .npz files.  The fixtures are data; the
+reference itself never travels to the GPU box.
+
+    python tests/golden/make_golden.py
+
+Fixtures:
+  g1_gta_128x64_d16_s1.npz      config 1 with pretrained GTA weights, every intermediate
+  g1_init_128x64_d16_s1.npz     config 1 with default-statistics random weights (weights.default_init_weights(0))
+  g1b_gta_96x80_d8_s2_b2.npz    batch 2, two sources, per-element poses, odd-ish pyramid sizes
+  g2_gta_512x256_d64_s2.npz     headline config: outputs only (inputs regenerated from the seed)
+  g2s_gta_512x256_d64_s2.npz    same on the smooth synthetic scene
+  g3_demon_640x480_d96_s1.npz   config 4 shape with DeMoN weights: outputs only
+  g4_units.npz                  single-op pins on tiny tensors
+  g6_flags_128x64.npz           do_cost_volume_filter=False / refiners off variants
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
+sys.path.insert(0, "/root/reference")
+
+from multi_view_stereonet.multi_view_stereonet import (  # noqa: E402  (reference)
+    MultiViewStereoNet, FeatureRefiner, CostVolumeFilter, IDepthmapRefiner, MaskUpsampler,
+    extract_idepthmap, create_idepth_samples, create_plane_sweep_homographies, PlaneSweepWarper)
+import multi_view_stereonet.multi_view_stereonet as ref_mod  # noqa: E402
+from multi_view_stereonet import multi_view_stereonet_utils as ref_snu  # noqa: E402
+from stereo import image_predictor as ref_ip  # noqa: E402
+from utils import image_utils as ref_iu  # noqa: E402
+
+from multi_view_stereonet_amd import synthetic  # noqa: E402
+from multi_view_stereonet_amd.weights import load_weights, default_init_weights  # noqa: E402
+from multi_view_stereonet_amd import multi_view_stereonet_utils as my_snu  # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def ref_net(weights=None, seed=0):
+    """Reference eager module with either extracted pretrained tensors or the build's seeded
+    default-statistics init (regenerable from the seed, so never stored in a fixture)."""
+    net = MultiViewStereoNet().eval()
+    sd = load_weights(weights) if weights is not None else default_init_weights(seed)
+    net.load_state_dict(sd, strict=True)
+    return net
+
+
+def run_reference(net, batch, D, do_filter=True, refiners=(True,) * 5, capture=True):
+    """Unpack with the REFERENCE's unpacker, run forward, optionally hook intermediates."""
+    import copy
+    b = copy.deepcopy(batch)
+    inputs = ref_snu.multi_view_unpack_batch(b, torch.device("cpu"), net.num_levels)
+    rec = {"samples": [], "H": [], "rfe_out": [], "vf_in": [], "vf_out": [], "fe_out": [], "warp": []}
+    hooks = []
+    if capture:
+        orig_samples = ref_mod.create_idepth_samples
+        orig_H = ref_mod.create_plane_sweep_homographies
+
+        def samples_spy(*a, **k):
+            r = orig_samples(*a, **k)
+            rec["samples"].append(r.clone())
+            return r
+
+        def H_spy(*a, **k):
+            r = orig_H(*a, **k)
+            rec["H"].append(r.clone())
+            return r
+
+        ref_mod.create_idepth_samples = samples_spy
+        ref_mod.create_plane_sweep_homographies = H_spy
+        def on_rfe(m, i, o):
+            rec["rfe_out"].append((o[0].clone(), o[1].clone()))
+
+        def on_vf(m, i, o):
+            rec["vf_in"].append(i[0].clone())
+            rec["vf_out"].append(o.clone())
+
+        def on_fe(m, i, o):
+            rec["fe_out"].append([t.clone() for t in o])
+
+        def on_warp(m, i, o):
+            if len(rec["warp"]) < 4:
+                rec["warp"].append((o[0].clone(), o[1].clone()))
+
+        hooks.append(net.right_feature_extractor.register_forward_hook(on_rfe))
+        hooks.append(net.volume_filter4.register_forward_hook(on_vf))
+        hooks.append(net.left_feature_extractor.register_forward_hook(on_fe))
+        hooks.append(net.right_feature_extractor.warper.register_forward_hook(on_warp))
+    try:
+        out = net(inputs["left_image_pyr"], inputs["K_pyr"], inputs["T_right_in_left"],
+                  inputs["right_image_pyr"], D, do_filter, list(refiners))
+    finally:
+        for h in hooks:
+            h.remove()
+        if capture:
+            ref_mod.create_idepth_samples = orig_samples
+            ref_mod.create_plane_sweep_homographies = orig_H
+    return inputs, out, rec
+
+
+def pack_outputs(d, out):
+    for lvl in range(5):
+        d[f"idepth_{lvl}"] = npy(out["left_idepthmap_pyr"][lvl])
+        d[f"raw_{lvl}"] = npy(out["left_idepthmap_raw_pyr"][lvl])
+    return d
+
+
+def check_unpack(batch, inputs, levels=5):
+    """The build's unpacker must reproduce the reference's inputs bit-for-bit (row a14)."""
+    mine = my_snu.multi_view_unpack_batch(batch, torch.device("cpu"), levels)
+    for a, b in zip(mine["K_pyr"], inputs["K_pyr"]):
+        assert torch.equal(a, b)
+    for a, b in zip(mine["left_image_pyr"], inputs["left_image_pyr"]):
+        assert torch.equal(a, b)
+    for a, b in zip(mine["T_right_in_left"], inputs["T_right_in_left"]):
+        assert torch.equal(a, b)
+    assert torch.equal(mine["baseline"], inputs["baseline"])
+
+
+def full_capture(name, weights, rows, cols, D, S, B=1, seed=1, jitter=0.0, init_seed=0, store_weights=False):
+    net = ref_net(weights, init_seed)
+    batch = synthetic.make_batch(rows, cols, S, batch=B, seed=seed, pose_jitter=jitter)
+    inputs, out, rec = run_reference(net, batch, D)
+    check_unpack(batch, inputs)
+    d = {"meta": np.array([rows, cols, D, S, B, seed], dtype=np.int64), "jitter": np.float32(jitter)}
+    d["left_image"] = npy(batch["left_image"])
+    d["K"] = npy(batch["K"])
+    for s in range(S):
+        d[f"right_image_{s}"] = npy(batch["right_image"][s])
+        d[f"T_{s}"] = npy(batch["T_right_in_left"][s])
+        d[f"T_unpacked_{s}"] = npy(inputs["T_right_in_left"][s])
+        d[f"idepth_samples_{s}"] = npy(rec["samples"][s])
+        d[f"H_lvl0_plane0_{s}"] = npy(rec["H"][2 * s])
+        d[f"H_{s}"] = npy(rec["H"][2 * s + 1])
+        d[f"feature_volume_{s}"] = npy(rec["rfe_out"][s][0])
+        d[f"mask_volume_{s}"] = npy(rec["rfe_out"][s][1])
+        d[f"cost_volume_{s}"] = npy(rec["vf_in"][s])
+        d[f"filtered_cost_{s}"] = npy(rec["vf_out"][s])
+        d[f"plane0_features_{s}"] = npy(rec["fe_out"][1 + s][-1])
+    # warper calls of source 0: [0] full-res plane 0, [1] L4 image volume, [2..] incremental
+    d["warped_fullres_0"] = npy(rec["warp"][0][0])
+    d["image_volume_0"] = npy(rec["warp"][1][0])
+    d["image_volume_mask_0"] = npy(rec["warp"][1][1])
+    d["baseline"] = npy(inputs["baseline"])
+    for lvl in range(5):
+        d[f"K_pyr_{lvl}"] = npy(inputs["K_pyr"][lvl])
+        d[f"left_feat_{lvl}"] = npy(rec["fe_out"][0][lvl]) if lvl > 0 else np.zeros(1, np.float32)
+        d[f"mask_{lvl}"] = np.packbits(npy(out["left_idepthmap_mask_pyr"][lvl]))
+        d[f"mask_shape_{lvl}"] = np.array(out["left_idepthmap_mask_pyr"][lvl].shape, dtype=np.int64)
+    d["left_image_lvl4"] = npy(inputs["left_image_pyr"][4])
+    pack_outputs(d, out)
+    if store_weights:
+        for k, v in net.state_dict().items():
+            if not k.startswith("right_feature_extractor.feature_extractor."):
+                d["w:" + k] = npy(v)
+    np.savez_compressed(os.path.join(HERE, name), **d)
+    print(name, "ok", sum(v.nbytes for v in d.values()) // 1024, "KiB raw")
+
+
+def outputs_only(name, weights, rows, cols, D, S, seed, smooth=False):
+    net = ref_net(weights)
+    batch = synthetic.make_batch(rows, cols, S, batch=1, seed=seed, smooth=smooth)
+    inputs, out, rec = run_reference(net, batch, D)
+    check_unpack(batch, inputs)
+    d = {"meta": np.array([rows, cols, D, S, 1, seed], dtype=np.int64), "smooth": np.int64(smooth)}
+    for s in range(S):
+        d[f"idepth_samples_{s}"] = npy(rec["samples"][s])
+        d[f"H_{s}"] = npy(rec["H"][2 * s + 1])
+        d[f"filtered_cost_{s}"] = npy(rec["vf_out"][s]).astype(np.float32)
+        d[f"mask_volume_count_{s}"] = np.int64(rec["rfe_out"][s][1].sum().item())
+        fv = rec["rfe_out"][s][0]
+        d[f"feature_volume_last_plane_{s}"] = npy(fv[:, :, -1])
+    for lvl in range(5):
+        d[f"mask_count_{lvl}"] = np.int64(out["left_idepthmap_mask_pyr"][lvl].sum().item())
+    d["mask_4"] = np.packbits(npy(out["left_idepthmap_mask_pyr"][4]))
+    d["idepth_0"] = npy(out["left_idepthmap_pyr"][0])
+    d["idepth_4"] = npy(out["left_idepthmap_pyr"][4])
+    d["raw_4"] = npy(out["left_idepthmap_raw_pyr"][4])
+    d["raw_0"] = npy(out["left_idepthmap_raw_pyr"][0]).astype(np.float16)  # coarse pin only
+    np.savez_compressed(os.path.join(HERE, name), **d)
+    print(name, "ok", sum(v.nbytes for v in d.values()) // 1024, "KiB raw")
+
+
+def flags_capture(name):
+    net = ref_net("gta_sfm_150epochs")
+    batch = synthetic.make_batch(64, 128, 2, batch=1, seed=5)
+    d = {"meta": np.array([64, 128, 16, 2, 1, 5], dtype=np.int64)}
+    variants = {"nofilter": (False, (True,) * 5),
+                "norefine4": (True, (True, True, True, True, False)),
+                "norefine_all": (True, (False,) * 5),
+                "norefine_0_2": (True, (False, True, False, True, True))}
+    for key, (flt, refs) in variants.items():
+        _, out, _ = run_reference(net, batch, 16, flt, refs, capture=False)
+        for lvl in (0, 4):
+            d[f"{key}:idepth_{lvl}"] = npy(out["left_idepthmap_pyr"][lvl])
+            d[f"{key}:raw_{lvl}"] = npy(out["left_idepthmap_raw_pyr"][lvl])
+    np.savez_compressed(os.path.join(HERE, name), **d)
+    print(name, "ok")
+
+
+def unit_pins(name):
+    g = torch.Generator().manual_seed(11)
+    d = {}
+    sd = load_weights("gta_sfm_150epochs")
+    # --- HomographyImagePredictor on special homographies ---------------------------------
+    img = torch.rand(4, 5, 6, 9, generator=g) * 2 - 1
+    Hs = torch.eye(3).repeat(4, 1, 1)
+    Hs[1, 0, 2] = 0.5                                   # half-pixel shift in x
+    Hs[2] = torch.tensor([[1.0, 0.0, 5.0], [0.0, 1.0, -2.0], [0.0, 0.0, 1.0]])   # half the image OOB
+    Hs[3] = torch.tensor([[1.0, 0.1, 0.3], [-0.05, 1.1, 0.2], [0.01, 0.002, -1.0]])  # z < 0
+    pred, mask = ref_ip.HomographyImagePredictor()(Hs, img)
+    d.update(hip_image=npy(img), hip_H=npy(Hs), hip_pred=npy(pred), hip_mask=npy(mask))
+    # --- PlaneSweepWarper: (B,C,h,w) x (B,n,3,3) -> volume + mask, with zeroing ----------
+    img2 = torch.rand(2, 3, 7, 10, generator=g)
+    H2 = torch.eye(3).repeat(2, 3, 1, 1) + 0.05 * (torch.rand(2, 3, 3, 3, generator=g) - 0.5)
+    H2[..., 2, :2] *= 0.05
+    vol, vmask = PlaneSweepWarper()(img2, H2)
+    d.update(psw_image=npy(img2), psw_H=npy(H2), psw_volume=npy(vol), psw_mask=npy(vmask))
+    # --- get_fronto_parallel_homography / create_plane_sweep_homographies ----------------
+    batch = synthetic.make_batch(48, 80, 2, batch=2, seed=3, pose_jitter=0.3)
+    inputs = ref_snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
+    T = inputs["T_right_in_left"][1]
+    K4 = inputs["K_pyr"][4]
+    samples = create_idepth_samples(T.clone(), K4, 3, 5, 7)
+    Hfam = create_plane_sweep_homographies(T, K4, samples, [3, 5])
+    d.update(fph_T=npy(T), fph_K=npy(K4), fph_samples=npy(samples), fph_H=npy(Hfam))
+    disp = 6.0 * torch.ones(2, 1, 3, 5)
+    d["d2i_idepth"] = npy(ref_ip.disparity_to_idepth(K4, T, disp))
+    # --- FeatureRefiner one step ---------------------------------------------------------
+    fr = FeatureRefiner(32).eval()
+    fr.load_state_dict({k.split("refiner.", 1)[1]: v for k, v in sd.items()
+                        if k.startswith("right_feature_extractor.refiner.")})
+    fimg = torch.rand(2, 3, 6, 8, generator=g) * 2 - 1
+    ffeat = torch.randn(2, 32, 6, 8, generator=g)
+    d.update(fr_image=npy(fimg), fr_feat=npy(ffeat), fr_out=npy(fr(fimg, ffeat)))
+    # --- CostVolumeFilter on a small volume ----------------------------------------------
+    cvf = CostVolumeFilter(32).eval()
+    cvf.load_state_dict({k.split("volume_filter4.", 1)[1]: v for k, v in sd.items()
+                         if k.startswith("volume_filter4.")})
+    vol_in = torch.rand(2, 32, 8, 4, 8, generator=g)
+    vout = cvf(vol_in)
+    d.update(cvf_in=npy(vol_in), cvf_out=npy(vout))
+    # --- extract_idepthmap ---------------------------------------------------------------
+    idv = torch.linspace(0, 1.5, 8).view(1, 8, 1, 1).repeat(2, 1, 4, 8)
+    d.update(sm_idepth=npy(idv[:, :, 0, 0]), sm_out=npy(extract_idepthmap(vout, idv)))
+    # --- IDepthmapRefiner level 1 (36 ch) and level 0 (4 ch) ----------------------------
+    for lvl, ch in ((1, 35), (0, 3)):
+        r = IDepthmapRefiner(ch, 1.0).eval()
+        r.load_state_dict({k.split(f"refiner{lvl}.", 1)[1]: v for k, v in sd.items()
+                           if k.startswith(f"refiner{lvl}.")})
+        guide = torch.randn(2, ch, 20, 24, generator=g)
+        prior = torch.rand(2, 1, 20, 24, generator=g) * 30.0
+        d[f"idr{lvl}_guide"] = npy(guide)
+        d[f"idr{lvl}_prior"] = npy(prior)
+        d[f"idr{lvl}_out"] = npy(r(guide, prior))
+    # --- MaskUpsampler / bilinear upsample on odd sizes ---------------------------------
+    m = torch.rand(2, 5, 8, 15, generator=g) > 0.5
+    d.update(mu_in=npy(m), mu_out=npy(MaskUpsampler()(m, [15, 30])))
+    x = torch.rand(2, 1, 8, 15, generator=g)
+    d.update(up_in=npy(x), up_out=npy(torch.nn.functional.interpolate(x, size=[15, 30], mode="bilinear",
+                                                                     align_corners=False)))
+    # --- build_image_pyramid on odd sizes ------------------------------------------------
+    im = torch.rand(1, 3, 30, 45, generator=g)
+    pyr = ref_iu.build_image_pyramid(im, 4)
+    d["pyr_in"] = npy(im)
+    for i, p in enumerate(pyr):
+        d[f"pyr_{i}"] = npy(p)
+    np.savez_compressed(os.path.join(HERE, name), **d)
+    print(name, "ok")
+
+
+def main():
+    torch.set_num_threads(8)
+    full_capture("g1_gta_128x64_d16_s1.npz", "gta_sfm_150epochs", 64, 128, 16, 1, seed=1)
+    full_capture("g1_init_128x64_d16_s1.npz", None, 64, 128, 16, 1, seed=1, init_seed=0, store_weights=False)
+    full_capture("g1b_gta_96x80_d8_s2_b2.npz", "gta_sfm_150epochs", 80, 96, 8, 2, B=2, seed=2, jitter=0.3)
+    outputs_only("g2_gta_512x256_d64_s2.npz", "gta_sfm_150epochs", 256, 512, 64, 2, seed=7)
+    outputs_only("g2s_gta_512x256_d64_s2.npz", "gta_sfm_150epochs", 256, 512, 64, 2, seed=7, smooth=True)
+    outputs_only("g3_demon_640x480_d96_s1.npz", "demon_45epochs", 480, 640, 96, 1, seed=9)
+    flags_capture("g6_flags_128x64.npz")
+    unit_pins("g4_units.npz")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,161 @@
+"""Pin the CPU oracle (oracle/mvsn_oracle.py) against fixtures generated from the reference.
+
+The reference has no tests of its own; these fixtures are the reference's
+eager PyTorch-CPU outputs recorded by tests/golden/make_golden.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, t, unpack_mask, batch_from_meta, rel_err
+from multi_view_stereonet_amd import multi_view_stereonet_utils as snu
+from multi_view_stereonet_amd.weights import load_weights, default_init_weights
+from oracle import mvsn_oracle as oracle
+
+torch.set_grad_enabled(False)
+
+
+def _run(fix, weights, smooth=False, capture=None):
+    batch, D = batch_from_meta(fix["meta"], fix.get("jitter", 0.0), smooth)
+    inp = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
+    out = oracle.forward(weights, inp["left_image_pyr"], inp["K_pyr"], inp["T_right_in_left"],
+                         inp["right_image_pyr"], D, True, [True] * 5, capture=capture)
+    return batch, inp, out
+
+
+@pytest.mark.parametrize("name,wname", [("g1_gta_128x64_d16_s1.npz", "gta_sfm_150epochs"),
+                                        ("g1_init_128x64_d16_s1.npz", None),
+                                        ("g1b_gta_96x80_d8_s2_b2.npz", "gta_sfm_150epochs")])
+def test_full_capture(name, wname):
+    fix = load_golden(name)
+    w = load_weights(wname) if wname else default_init_weights(0)
+    cap = {}
+    batch, inp, out = _run(fix, w, capture=cap)
+    S = int(fix["meta"][3])
+    # the regenerated inputs are the recorded ones
+    assert torch.equal(batch["left_image"], t(fix["left_image"]))
+    for lvl in range(5):
+        assert torch.equal(inp["K_pyr"][lvl], t(fix[f"K_pyr_{lvl}"]))
+    assert torch.equal(inp["left_image_pyr"][4], t(fix["left_image_lvl4"]))
+    for s in range(S):
+        c = cap["sources"][s]
+        assert torch.allclose(c["idepth_samples"], t(fix[f"idepth_samples_{s}"]), rtol=1e-5, atol=1e-7)
+        assert torch.allclose(c["H"], t(fix[f"H_{s}"]), rtol=1e-4, atol=1e-5)
+        assert torch.allclose(c["H_lvl0_plane0"], t(fix[f"H_lvl0_plane0_{s}"]), rtol=1e-4, atol=1e-5)
+        assert torch.allclose(c["plane0_features"], t(fix[f"plane0_features_{s}"]), rtol=1e-4, atol=1e-5)
+        m_ref = t(fix[f"mask_volume_{s}"])
+        assert int((c["mask_volume"] != m_ref).sum()) == 0
+        for key in ("feature_volume", "cost_volume", "filtered_cost"):
+            mean_rel, max_rel = rel_err(c[key], fix[f"{key}_{s}"])
+            assert mean_rel < 1e-4 and max_rel < 1e-3, (key, mean_rel, max_rel)
+    assert torch.allclose(cap["sources"][0]["image_volume"], t(fix["image_volume_0"]), rtol=1e-4, atol=1e-5)
+    for lvl in range(1, 5):
+        assert torch.allclose(cap["left_features"][lvl], t(fix[f"left_feat_{lvl}"]), rtol=1e-4, atol=1e-5)
+    for lvl in range(5):
+        for kind, key in (("idepth", "left_idepthmap_pyr"), ("raw", "left_idepthmap_raw_pyr")):
+            mean_rel, max_rel = rel_err(out[key][lvl], fix[f"{kind}_{lvl}"])
+            assert mean_rel < 1e-4 and max_rel < 1e-3, (kind, lvl, mean_rel, max_rel)
+        assert np.array_equal(out["left_idepthmap_mask_pyr"][lvl].numpy(), unpack_mask(fix, lvl))
+
+
+@pytest.mark.parametrize("name,wname,smooth", [("g2_gta_512x256_d64_s2.npz", "gta_sfm_150epochs", False),
+                                               ("g2s_gta_512x256_d64_s2.npz", "gta_sfm_150epochs", True),
+                                               ("g3_demon_640x480_d96_s1.npz", "demon_45epochs", False)])
+def test_headline_outputs(name, wname, smooth):
+    fix = load_golden(name)
+    cap = {}
+    _, _, out = _run(fix, load_weights(wname), smooth=smooth, capture=cap)
+    S = int(fix["meta"][3])
+    for s in range(S):
+        c = cap["sources"][s]
+        assert torch.allclose(c["idepth_samples"], t(fix[f"idepth_samples_{s}"]), rtol=1e-5, atol=1e-7)
+        # a handful of voxels sit within an ulp of the |n|>1 predicate; count, don't hide
+        assert abs(int(c["mask_volume"].sum()) - int(fix[f"mask_volume_count_{s}"])) <= 2
+        mean_rel, max_rel = rel_err(c["feature_volume"][:, :, -1], fix[f"feature_volume_last_plane_{s}"])
+        assert mean_rel < 2e-4, ("last plane", mean_rel, max_rel)
+        mean_rel, max_rel = rel_err(c["filtered_cost"], fix[f"filtered_cost_{s}"])
+        assert mean_rel < 2e-4, ("filtered", mean_rel, max_rel)
+    for lvl, key in ((0, "idepth_0"), (4, "idepth_4")):
+        mean_rel, max_rel = rel_err(out["left_idepthmap_pyr"][lvl], fix[key])
+        assert mean_rel < 1e-4 and max_rel < 1e-3, (key, mean_rel, max_rel)
+    mean_rel, max_rel = rel_err(out["left_idepthmap_raw_pyr"][4], fix["raw_4"])
+    assert mean_rel < 1e-4 and max_rel < 1e-3
+    for lvl in range(5):
+        assert abs(int(out["left_idepthmap_mask_pyr"][lvl].sum()) - int(fix[f"mask_count_{lvl}"])) <= 2 * 4 ** (4 - lvl)
+
+
+def test_flag_variants():
+    fix = load_golden("g6_flags_128x64.npz")
+    batch, D = batch_from_meta(fix["meta"])
+    inp = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
+    w = load_weights("gta_sfm_150epochs")
+    variants = {"nofilter": (False, [True] * 5),
+                "norefine4": (True, [True, True, True, True, False]),
+                "norefine_all": (True, [False] * 5),
+                "norefine_0_2": (True, [False, True, False, True, True])}
+    for key, (flt, refs) in variants.items():
+        out = oracle.forward(w, inp["left_image_pyr"], inp["K_pyr"], inp["T_right_in_left"],
+                             inp["right_image_pyr"], D, flt, refs)
+        for lvl in (0, 4):
+            for kind, okey in (("idepth", "left_idepthmap_pyr"), ("raw", "left_idepthmap_raw_pyr")):
+                mean_rel, max_rel = rel_err(out[okey][lvl], fix[f"{key}:{kind}_{lvl}"])
+                assert mean_rel < 1e-4 and max_rel < 1e-3, (key, kind, lvl, mean_rel, max_rel)
+
+
+def test_unit_pins():
+    fix = load_golden("g4_units.npz")
+    w = load_weights("gta_sfm_150epochs")
+    # homography warp on special homographies (identity, half-pixel shift, half OOB, z<0)
+    img, H = t(fix["hip_image"]), t(fix["hip_H"])
+    vol, mask = oracle.homography_warp(img, H[:, None])
+    ref_mask = t(fix["hip_mask"])[:, 0]
+    assert torch.equal(mask[:, 0], ref_mask)
+    ref = t(fix["hip_pred"]) * (~ref_mask).float()[:, None]
+    assert torch.allclose(vol[:, :, 0], ref, rtol=1e-5, atol=1e-6)
+    # identity homography is the identity map up to the normalise/un-normalise round trip
+    assert torch.allclose(vol[0, :, 0], img[0], atol=2e-6)
+    # plane-sweep warper with several planes per image
+    vol, mask = oracle.homography_warp(t(fix["psw_image"]), t(fix["psw_H"]))
+    assert torch.equal(mask, t(fix["psw_mask"])[:, 0])
+    assert torch.allclose(vol, t(fix["psw_volume"]), rtol=1e-5, atol=1e-6)
+    # idepth samples, homography family, disparity -> idepth
+    T, K = t(fix["fph_T"]), t(fix["fph_K"])
+    samples = oracle.idepth_samples(T, K, 3, 5, 7)
+    assert torch.allclose(samples, t(fix["fph_samples"]), rtol=1e-5, atol=1e-7)
+    assert torch.allclose(oracle.plane_sweep_homographies(T, K, samples), t(fix["fph_H"]), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(oracle.disparity_to_idepth(K, T, 6.0, 3, 5).view(2, 1, 3, 5), t(fix["d2i_idepth"]),
+                          rtol=1e-4, atol=1e-6)
+    # feature refiner, cost-volume filter, soft argmin, idepth refiners
+    out = oracle.feature_refiner(w, "right_feature_extractor.refiner", t(fix["fr_image"]), t(fix["fr_feat"]))
+    assert torch.allclose(out, t(fix["fr_out"]), rtol=1e-4, atol=1e-5)
+    vout = oracle.cost_volume_filter(w, "volume_filter4", t(fix["cvf_in"]))
+    assert torch.allclose(vout, t(fix["cvf_out"]), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(oracle.soft_argmin(vout, t(fix["sm_idepth"])), t(fix["sm_out"]), rtol=1e-5, atol=1e-6)
+    for lvl in (1, 0):
+        out = oracle.idepth_refiner(w, f"refiner{lvl}", t(fix[f"idr{lvl}_guide"]), t(fix[f"idr{lvl}_prior"]))
+        assert torch.allclose(out, t(fix[f"idr{lvl}_out"]), rtol=1e-4, atol=1e-4)
+    # upsamplers and the area pyramid on odd sizes
+    assert torch.equal(oracle.upsample_mask(t(fix["mu_in"]), (15, 30)), t(fix["mu_out"]))
+    assert torch.allclose(oracle.upsample(t(fix["up_in"]), (15, 30)), t(fix["up_out"]), rtol=1e-6, atol=1e-7)
+    pyr = snu.build_image_pyramid(t(fix["pyr_in"]), 4)
+    for i, p in enumerate(pyr):
+        assert torch.equal(p, t(fix[f"pyr_{i}"]))
+
+
+def test_analytic_known_answers():
+    """G5: no reference needed."""
+    img = torch.rand(2, 3, 9, 13)
+    vol, mask = oracle.homography_warp(img, torch.eye(3).repeat(2, 1, 1, 1))
+    assert torch.allclose(vol[:, :, 0], img, atol=2e-6) and not mask.any()
+    # pure translation at idepth 0 -> H = I
+    T = torch.eye(4).repeat(2, 1, 1)
+    T[:, 0, 3] = 1.0
+    K = torch.eye(4).repeat(2, 1, 1)
+    K[:, 0, 0] = K[:, 1, 1] = 25.0
+    K[:, 0, 2], K[:, 1, 2] = 6.0, 4.0
+    H = oracle.plane_sweep_homographies(T, K, torch.zeros(2, 1))
+    assert torch.allclose(H[:, 0], torch.eye(3).repeat(2, 1, 1), atol=1e-6)
+    # constant cost -> soft argmin is the mean of the samples
+    samples = torch.linspace(0, 1.7, 9)[None]
+    out = oracle.soft_argmin(torch.full((1, 9, 2, 2), 3.0), samples)
+    assert torch.allclose(out, samples.mean().expand_as(out), atol=1e-6)
