@@ -1,0 +1,172 @@
+/*
+ * mvsn_hip.h -- C ABI of libmvsn_hip.so, the MI355X (gfx950) plane-sweep hot path of
+ * MultiViewStereoNet.
+ *
+ * The reference (robustrobotics/multi_view_stereonet) has no native layer: its "kernels" are
+ * stock ATen ops called from multi_view_stereonet/multi_view_stereonet.py.  Each entry point
+ * below replaces one group of those call sites (cited as file:line into the reference).  A
+ * maintainer binds them with ctypes (INTEGRATION.md shows the stub) from inside
+ * MultiViewStereoNet.forward().
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into HBM; tensors are dense fp32, row-major in the
+ *     index order written next to them (NCHW / NCDHW as in the reference); masks are uint8
+ *     (0/1), bit-compatible with torch.bool storage;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); every call only
+ *     enqueues work on that stream and never synchronises the device;
+ *   - return value: 0 on success, a positive hipError_t, or a negative MVSN_E_* code;
+ *     mvsn_last_error() returns a thread-local message for the last non-zero return;
+ *   - a "chain" is one (reference image, source view) pair; chains are indexed
+ *     n = source * B + image, so n % B is the reference-image index;
+ *   - P = rows*cols of the coarsest (1/16) pyramid level, D = number of idepth hypotheses.
+ */
+#ifndef MVSN_HIP_H
+#define MVSN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVSN_ABI_VERSION 1
+
+#define MVSN_E_BADARG (-1)      /* null pointer, non-positive size, unsupported channel count */
+#define MVSN_E_TOOLARGE (-2)    /* shape exceeds what the kernel's LDS/global plan supports */
+#define MVSN_E_WORKSPACE (-3)   /* workspace pointer null or smaller than the *_workspace_bytes() answer */
+
+typedef void *mvsn_stream_t;
+
+int mvsn_abi_version(void);
+const char *mvsn_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Plane-sweep set-up: per chain, the baseline-normalised pose, the D idepth samples, the
+ * fronto-parallel homographies at the coarsest level, the incremental homographies
+ * H_inc[d] = H[d-1]^-1 H[d] (H_inc[0] = I) and the full-resolution homography of plane 0.
+ * Replaces create_idepth_samples (multi_view_stereonet.py:131-165 -> stereo/image_predictor.py:120-209),
+ * create_plane_sweep_homographies (:167-194 -> image_predictor.py:400-461), the per-source
+ * baseline renormalisation (:566-571) and the per-step torch.inverse/matmul (:281-282).
+ *   T_right_in_left (N,4,4)  K_lvl0 (N,4,4)  K_lvl4 (N,4,4)
+ *   idepth_samples (N,D)  H_lvl4 (N,D,3,3)  H_inc (N,D,3,3)  H_lvl0_plane0 (N,3,3)  baseline (N)
+ * ------------------------------------------------------------------------------------------- */
+int mvsn_plane_sweep_setup(const float *T_right_in_left, const float *K_lvl0, const float *K_lvl4,
+                           int n_chains, int rows4, int cols4, int num_idepth_samples,
+                           float *idepth_samples, float *H_lvl4, float *H_inc, float *H_lvl0_plane0,
+                           float *baseline, mvsn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Homography warp with bilinear, clamp-to-edge sampling and out-of-image zeroing.
+ * Replaces PlaneSweepWarper.forward (multi_view_stereonet.py:205-235) ->
+ * HomographyImagePredictor.forward (stereo/image_predictor.py:470-523, grid_sample bilinear /
+ * border / align_corners=False).  mask = |nx|>1 or |ny|>1 on the normalised coordinate.
+ *   image (B,C,rows,cols)  H (B,n,3,3)  ->  volume (B,C,n,rows,cols)  mask (B,n,rows,cols) u8
+ * ------------------------------------------------------------------------------------------- */
+int mvsn_homography_warp(const float *image, const float *H, int batch, int channels, int n_planes,
+                         int rows, int cols, float *volume, uint8_t *mask, mvsn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The fused incremental chain: for every chain, one persistent workgroup keeps the source-view
+ * feature map resident on-chip and walks d = 1..D-1: warp the previous plane's features by
+ * H_inc[d], warp the coarse source image by H[d], run the FeatureRefiner (conv 35->32, GN,
+ * LReLU, residual block, conv 32->32, +features) on fp32 MFMA, and emit the cost-volume slice
+ * (not mask) * |left - right| and the mask slice.  Replaces
+ * IncrementalFastGeometryAwareFeatureNetwork.forward :270-300 (everything after the plane-0
+ * extractor), FeatureRefiner.forward :424-440 and the cost-volume build :553,:587-592.
+ *   src_image_lvl4 (N,3,rows,cols)   H_lvl4, H_inc (N,D,3,3)   plane0_features (N,32,rows,cols)
+ *   left_features (B,32,rows,cols)   refiner_packed: mvsn_feature_refiner_packed_floats() floats
+ *   cost_volume (N,32,D,rows,cols)   mask_volume (N,D,rows,cols) u8
+ *   feature_volume: optional (N,32,D,rows,cols) masked source features, or NULL
+ *   workspace: mvsn_incremental_cost_volume_workspace_bytes() bytes (may be 0 -> NULL allowed)
+ * ------------------------------------------------------------------------------------------- */
+size_t mvsn_feature_refiner_packed_floats(void);
+/* Pack the ten FeatureRefiner tensors (state_dict order: conv0.{weight,bias}, bn0.{weight,bias},
+ * res0.conv1.{weight,bias}, res0.bn1.{weight,bias}, conv_final.{weight,bias}) into the MFMA
+ * fragment order the chain kernel streams. */
+int mvsn_pack_feature_refiner(const float *conv0_w, const float *conv0_b, const float *bn0_w,
+                              const float *bn0_b, const float *res0_w, const float *res0_b,
+                              const float *res0_bn_w, const float *res0_bn_b, const float *final_w,
+                              const float *final_b, float *packed, mvsn_stream_t stream);
+size_t mvsn_incremental_cost_volume_workspace_bytes(int n_chains, int rows, int cols);
+int mvsn_incremental_cost_volume(const float *src_image_lvl4, const float *H_lvl4, const float *H_inc,
+                                 const float *plane0_features, const float *left_features,
+                                 const float *refiner_packed, int n_chains, int batch,
+                                 int num_idepth_samples, int rows, int cols, float *cost_volume,
+                                 uint8_t *mask_volume, float *feature_volume, void *workspace,
+                                 size_t workspace_bytes, mvsn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Direct convolution on fp32 MFMA (implicit GEMM, weights = A, activations = B), 2-D or 3-D,
+ * C_out in {1..32}, 'same' padding = dilation*(k/2), stride 1 or 2 (2-D only), with
+ *   - an optional input transform fused into the tile load:
+ *         x = LeakyReLU_0.2(GroupNorm_4(in))            (in_stats != NULL)
+ *   - bias add, and per-workgroup GroupNorm partials of the OUTPUT (out_partials != NULL) that
+ *     mvsn_groupnorm_finalize turns into (mean, rstd) per (sample, group).
+ * Replaces every conv2d/conv3d + GroupNorm + LeakyReLU call site of FeatureNetwork (:109-129),
+ * CostVolumeFilter (:341-353) and IDepthmapRefiner (:468-484).
+ *   in (N,C_in,[D,]H,W)  weight_packed: mvsn_conv_packed_floats() floats  bias (C_out) or NULL
+ *   in_stats (N,4,2) mean,rstd   in_gamma,in_beta (C_in)   out (N,C_out,[D,]Ho,Wo)
+ *   out_partials (N, tiles, 4, 3) {count, mean, M2}
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  int n;         /* samples */
+  int c_in;      /* input channels (any >= 1) */
+  int c_out;     /* 1..32 */
+  int depth;     /* 1 for 2-D */
+  int rows, cols;/* input spatial size */
+  int kd, kh, kw;/* kernel extent; kd = 1 for 2-D */
+  int stride;    /* 1 or 2 (rows/cols only) */
+  int dilation;  /* rows/cols only */
+} mvsn_conv_desc;
+
+size_t mvsn_conv_packed_floats(const mvsn_conv_desc *desc);
+int mvsn_conv_pack_weights(const mvsn_conv_desc *desc, const float *weight, float *packed,
+                           mvsn_stream_t stream);
+int mvsn_conv_num_tiles(const mvsn_conv_desc *desc);
+int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, const float *weight_packed,
+                      const float *bias, const float *in_stats, const float *in_gamma,
+                      const float *in_beta, float *out, float *out_partials, mvsn_stream_t stream);
+/* partials (N,tiles,4,3) -> stats (N,4,2) = {mean, rstd}, eps 1e-5, biased variance */
+int mvsn_groupnorm_finalize(const float *partials, int n, int tiles, float *stats, mvsn_stream_t stream);
+/* out = [residual +] LeakyReLU_0.2(GroupNorm(x)) on (N,32,spatial); residual may be NULL; out may alias x */
+int mvsn_groupnorm_lrelu_apply(const float *x, const float *stats, const float *gamma, const float *beta,
+                               const float *residual, int n, long spatial, float *out, mvsn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Soft-argmin over the hypothesis axis: out = sum_d softmax(-cost)_d * idepth_d.
+ * Replaces extract_idepthmap (multi_view_stereonet.py:486-492).
+ *   cost (N,D,P)  idepth_samples (N,D)  ->  idepth (N,P)
+ * ------------------------------------------------------------------------------------------- */
+int mvsn_soft_argmin(const float *cost, const float *idepth_samples, int n, int num_idepth_samples,
+                     int pixels, float *idepth, mvsn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Bilinear resize, align_corners=False, to an arbitrary target size (Upsampler :372-380), and
+ * the boolean-mask variant float -> bilinear -> (> 0.5) (MaskUpsampler :389-396).
+ *   in (N,C,h,w) -> out (N,C,H,W)
+ * ------------------------------------------------------------------------------------------- */
+int mvsn_upsample_bilinear(const float *in, int n, int channels, int rows_in, int cols_in, int rows_out,
+                           int cols_out, float *out, mvsn_stream_t stream);
+int mvsn_upsample_mask(const uint8_t *in, int n, int channels, int rows_in, int cols_in, int rows_out,
+                       int cols_out, uint8_t *out, mvsn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-source fusion (multi_view_stereonet.py:615-627): per chain divide by its baseline, mean
+ * over the S sources; mask = mean(mask) > 0.5.
+ *   raw, refined (S*B,P)  baseline (S*B)  mask (S*B,D,P) u8
+ *   -> raw_out, refined_out (B,P)  mask_out (B,D,P) u8
+ * `refined_aliases_raw` != 0 reproduces the reference's double division when refiner 4 is off.
+ * ------------------------------------------------------------------------------------------- */
+int mvsn_fuse_sources(const float *raw, const float *refined, const float *baseline, const uint8_t *mask,
+                      int n_sources, int batch, int num_idepth_samples, int pixels, int refined_aliases_raw,
+                      float *raw_out, float *refined_out, uint8_t *mask_out, mvsn_stream_t stream);
+
+/* Device self-test of the MFMA fragment mapping the conv kernels rely on (A = 16x4, B = 4x16
+ * fp32, asymmetric operands); returns 0 when the on-device result matches the scalar product. */
+int mvsn_selftest_mfma(mvsn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVSN_HIP_H */

@@ -1,0 +1,91 @@
+"""ctypes binding of libmvsn_hip.so (include/mvsn_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, the caller gets a
+RuntimeError.  Tensors are handed over as raw device pointers plus sizes, and every call is
+enqueued on torch's current HIP stream.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_int, c_long, c_size_t, c_void_p, POINTER, Structure
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmvsn_hip.so")
+_lib = None
+
+
+class ConvDesc(Structure):
+    """mvsn_conv_desc"""
+    _fields_ = [("n", c_int), ("c_in", c_int), ("c_out", c_int), ("depth", c_int), ("rows", c_int),
+                ("cols", c_int), ("kd", c_int), ("kh", c_int), ("kw", c_int), ("stride", c_int),
+                ("dilation", c_int)]
+
+
+# name -> (restype, argtypes); mirrors include/mvsn_hip.h one to one
+SIGNATURES = {
+    "mvsn_abi_version": (c_int, []),
+    "mvsn_last_error": (c_char_p, []),
+    "mvsn_plane_sweep_setup": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 5 + [c_void_p]),
+    "mvsn_homography_warp": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p] * 2 + [c_void_p]),
+    "mvsn_feature_refiner_packed_floats": (c_size_t, []),
+    "mvsn_pack_feature_refiner": (c_int, [c_void_p] * 11 + [c_void_p]),
+    "mvsn_incremental_cost_volume_workspace_bytes": (c_size_t, [c_int] * 3),
+    "mvsn_incremental_cost_volume": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 4 + [c_size_t, c_void_p]),
+    "mvsn_conv_packed_floats": (c_size_t, [POINTER(ConvDesc)]),
+    "mvsn_conv_pack_weights": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p]),
+    "mvsn_conv_num_tiles": (c_int, [POINTER(ConvDesc)]),
+    "mvsn_conv_forward": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 8 + [c_void_p]),
+    "mvsn_groupnorm_finalize": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "mvsn_groupnorm_lrelu_apply": (c_int, [c_void_p] * 5 + [c_int, c_long, c_void_p, c_void_p]),
+    "mvsn_soft_argmin": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p, c_void_p]),
+    "mvsn_upsample_bilinear": (c_int, [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
+    "mvsn_upsample_mask": (c_int, [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
+    "mvsn_fuse_sources": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p] * 3 + [c_void_p]),
+    "mvsn_selftest_mfma": (c_int, [c_void_p]),
+}
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load (once) and type the library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"{_LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -m multi_view_stereonet_amd.build` or __graft_entry__.build()). "
+            "There is no CPU fallback for the plane-sweep path.")
+    lib = ctypes.CDLL(_LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the binary disagree
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mvsn_abi_version() != 1:
+        raise RuntimeError("libmvsn_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libmvsn_hip.so takes device (HBM) pointers; got a CPU tensor")
+    if not t.is_contiguous():
+        raise RuntimeError("libmvsn_hip.so takes dense tensors")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().mvsn_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

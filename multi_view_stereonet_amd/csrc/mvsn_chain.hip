@@ -1,0 +1,540 @@
+// The fused incremental chain (see include/mvsn_hip.h: mvsn_incremental_cost_volume).
+//
+// One 1024-thread workgroup (16 waves, 4 per SIMD) owns one (reference image, source view)
+// chain for all D-1 sequential steps.  Per step: homography gather of the previous plane's
+// features out of LDS, three 3x3 convolutions as implicit GEMMs on v_mfma_f32_16x16x4_f32
+// (A = weights 16 couts x 4 cins, B = activations 4 cins x 16 pixels), two GroupNorm(4)
+// reductions, and the cost-volume slice written straight to HBM.  Nothing but the cost / mask
+// slices (and the optional feature volume) leaves the CU between steps.
+//
+// LDS plan (floats), P = rows*cols, RS = cols+1, G = RS+1, CS = rows*RS+G rounded to 16 mod 32:
+//   wbuf   [10368]      weight fragments of the conv that runs next, [tap][cin/4][cout/16][lane]
+//   sparams[224]        biases and GroupNorm affine
+//   red    [4][16][4]   cross-wave reduction scratch (one slab per reduction of a step)
+//   maskb  [P]          out-of-image flag of the current plane
+//   act    G + 36*CS    activation planes.  Each channel is rows x RS with one zero column
+//                       closing every row (it doubles as the left halo of the next row) and G
+//                       zeros between channels (top/bottom halo), so every 3x3 tap of every
+//                       pixel is a plain offset read with no bounds test.  CS = 16 (mod 32)
+//                       makes the 16-pixel x 4-channel B-fragment read conflict-free.
+//                       ch 0..2 image plane d, ch 3..34 features, ch 35 zero (K padding).
+// When that exceeds 160 KiB the activation planes move to a per-chain global workspace
+// (L2-resident); the code path is otherwise identical.
+#include "mvsn_common.h"
+
+namespace mvsn {
+
+constexpr int CH_THREADS = 1024;
+constexpr int CH_WAVES = 16;
+constexpr int W0_FLOATS = 9 * 9 * 2 * 64;  // conv0: 35 -> 36 input channels = 9 k-steps per tap
+constexpr int W1_FLOATS = 9 * 8 * 2 * 64;
+constexpr int SP_FLOATS = 7 * 32;
+constexpr int PACKED_FLOATS = W0_FLOATS + 2 * W1_FLOATS + SP_FLOATS;
+constexpr int RED_FLOATS = 4 * CH_WAVES * 4;
+constexpr float GN_EPS = 1e-5f;
+
+struct ChainArgs {
+  const float *src;      // (N,3,P)
+  const float *H;        // (N,D,9)
+  const float *Hinc;     // (N,D,9)
+  const float *f0;       // (N,32,P)
+  const float *fl;       // (B,32,P)
+  const float *packed;   // PACKED_FLOATS
+  float *cost;           // (N,32,D,P)
+  uint8_t *mask;         // (N,D,P)
+  float *fvol;           // (N,32,D,P) or null
+  float *workspace;      // global activation planes or null
+  int B, D, rows, cols, CS;
+};
+
+// ---------------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_refiner_kernel(const float *c0w, const float *c0b, const float *g0w, const float *g0b,
+                                    const float *c1w, const float *c1b, const float *g1w, const float *g1b,
+                                    const float *c2w, const float *c2b, float *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= PACKED_FLOATS) return;
+  if (i < W0_FLOATS + 2 * W1_FLOATS) {
+    int conv, rel, cin_total, nc;
+    const float *w;
+    if (i < W0_FLOATS) {
+      conv = 0, rel = i, cin_total = 35, nc = 9, w = c0w;
+    } else if (i < W0_FLOATS + W1_FLOATS) {
+      conv = 1, rel = i - W0_FLOATS, cin_total = 32, nc = 8, w = c1w;
+    } else {
+      conv = 2, rel = i - W0_FLOATS - W1_FLOATS, cin_total = 32, nc = 8, w = c2w;
+    }
+    (void)conv;
+    const int lane = rel & 63;
+    const int t = (rel >> 6) & 1;
+    const int c4 = (rel >> 7) % nc;
+    const int tap = (rel >> 7) / nc;
+    const int cout = t * 16 + (lane & 15);
+    const int cin = c4 * 4 + (lane >> 4);
+    out[i] = cin < cin_total ? w[((size_t)cout * cin_total + cin) * 9 + tap] : 0.0f;
+  } else {
+    const int r = i - (W0_FLOATS + 2 * W1_FLOATS);
+    const int which = r / 32, c = r % 32;
+    const float *srcs[7] = {c0b, g0w, g0b, c1b, g1w, g1b, c2b};
+    out[i] = srcs[which][c];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pieces of the step
+// ---------------------------------------------------------------------------------------------
+template <int TP, int NC>
+__device__ __forceinline__ void conv3x3_mfma(const float *__restrict__ act, const float *__restrict__ wbuf, int CS,
+                                             int RS, const int (&qb)[TP], int lane, floatx4 (&acc)[TP][2]) {
+#pragma unroll
+  for (int j = 0; j < TP; ++j) {
+    acc[j][0] = floatx4{0.f, 0.f, 0.f, 0.f};
+    acc[j][1] = floatx4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float *abase = act + (lane >> 4) * CS;
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    const int off = (tap / 3 - 1) * RS + (tap % 3 - 1);
+    const float *wt = wbuf + tap * NC * 128 + lane;
+    const float *ab = abase + off;
+#pragma unroll
+    for (int c4 = 0; c4 < NC; ++c4) {
+      const float w0 = wt[c4 * 128];
+      const float w1 = wt[c4 * 128 + 64];
+#pragma unroll
+      for (int j = 0; j < TP; ++j) {
+        const float b = ab[c4 * 4 * CS + qb[j]];
+        acc[j][0] = mfma16x16x4(w0, b, acc[j][0]);
+        acc[j][1] = mfma16x16x4(w1, b, acc[j][1]);
+      }
+    }
+  }
+}
+
+// Sum `v[t]` (t = 0,1: the two cout tiles) over the whole workgroup, per GroupNorm group.
+// Lanes 0..31 of a wave hold channels of group 2t, lanes 32..63 of group 2t+1.
+__device__ __forceinline__ void block_group_sum(float (&v)[2], float *red_slab, int lane, int wave) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float s = v[t];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);
+    s += __shfl_xor(s, 16, 64);
+    v[t] = s;
+  }
+  if ((lane & 31) == 0) {
+    const int hi = lane >> 5;
+    red_slab[wave * 4 + 0 + hi] = v[0];
+    red_slab[wave * 4 + 2 + hi] = v[1];
+  }
+  __syncthreads();
+  const int hi = lane >> 5;
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int w = 0; w < CH_WAVES; ++w) {
+    s0 += red_slab[w * 4 + 0 + hi];
+    s1 += red_slab[w * 4 + 2 + hi];
+  }
+  v[0] = s0;
+  v[1] = s1;
+}
+
+// acc(+bias) -> LeakyReLU(GroupNorm(.)) in place.
+template <int TP>
+__device__ __forceinline__ void groupnorm_lrelu(floatx4 (&acc)[TP][2], const bool (&valid)[TP],
+                                                const float *__restrict__ bias, const float *__restrict__ gamma,
+                                                const float *__restrict__ beta, float *red_a, float *red_b,
+                                                float inv_count, int lane, int wave) {
+  const int cbase = (lane >> 4) * 4;
+  float s[2] = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < TP; ++j)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[j][t][r] += bias[t * 16 + cbase + r];
+        if (valid[j]) s[t] += acc[j][t][r];
+      }
+  block_group_sum(s, red_a, lane, wave);
+  const float mean[2] = {s[0] * inv_count, s[1] * inv_count};
+  float q[2] = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < TP; ++j)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float dv = acc[j][t][r] - mean[t];
+        if (valid[j]) q[t] += dv * dv;
+      }
+  block_group_sum(q, red_b, lane, wave);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float rstd = 1.0f / sqrtf(q[t] * inv_count + GN_EPS);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = t * 16 + cbase + r;
+      const float sc = rstd * gamma[c];
+      const float sh = beta[c] - mean[t] * sc;
+#pragma unroll
+      for (int j = 0; j < TP; ++j) acc[j][t][r] = lrelu02(acc[j][t][r] * sc + sh);
+    }
+  }
+}
+
+template <int WFLOATS>
+__device__ __forceinline__ void load_weights_to_regs(const float *__restrict__ g, floatx4 (&wreg)[3], int tid) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int idx = (tid + k * CH_THREADS) * 4;
+    if (idx < WFLOATS) wreg[k] = *reinterpret_cast<const floatx4 *>(g + idx);
+  }
+}
+template <int WFLOATS>
+__device__ __forceinline__ void store_weights_to_lds(float *wbuf, const floatx4 (&wreg)[3], int tid) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int idx = (tid + k * CH_THREADS) * 4;
+    if (idx < WFLOATS) *reinterpret_cast<floatx4 *>(wbuf + idx) = wreg[k];
+  }
+}
+
+template <int TP, bool LDS_ACT>
+__global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.x;
+  const int rows = a.rows, cols = a.cols, P = rows * cols, RS = cols + 1, G = RS + 1, CS = a.CS, D = a.D;
+  constexpr int IMG_IT = (TP * 256 + CH_THREADS - 1) / CH_THREADS;
+
+  float *wbuf = smem;
+  float *sparams = wbuf + W0_FLOATS;
+  float *red = sparams + SP_FLOATS;
+  float *maskb = red + RED_FLOATS;
+  const int Ppad = (P + 3) & ~3;
+  float *act;
+  const int act_floats = G + 36 * CS;
+  if constexpr (LDS_ACT) {
+    act = maskb + Ppad + G;
+  } else {
+    act = a.workspace + (size_t)n * act_floats + G;
+  }
+
+  // ---- one-time set-up ---------------------------------------------------------------------
+  for (int i = tid; i < act_floats; i += CH_THREADS) act[i - G] = 0.0f;
+  for (int i = tid; i < SP_FLOATS; i += CH_THREADS) sparams[i] = a.packed[W0_FLOATS + 2 * W1_FLOATS + i];
+  const float *bias0 = sparams, *gn0w = sparams + 32, *gn0b = sparams + 64, *bias1 = sparams + 96,
+              *gn1w = sparams + 128, *gn1b = sparams + 160, *bias2 = sparams + 192;
+
+  int pb[TP], qb[TP];
+  bool valid[TP];
+#pragma unroll
+  for (int j = 0; j < TP; ++j) {
+    const int p = (wave * TP + j) * 16 + (lane & 15);
+    valid[j] = p < P;
+    pb[j] = valid[j] ? p : 0;
+    qb[j] = (pb[j] / cols) * RS + (pb[j] % cols);
+  }
+  const int cbase = (lane >> 4) * 4;  // this lane's channels: t*16 + cbase + r
+  __syncthreads();
+
+  const float *f0 = a.f0 + (size_t)n * 32 * P;
+  const float *flp = a.fl + (size_t)(n % a.B) * 32 * P;
+#pragma unroll
+  for (int j = 0; j < TP; ++j)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = t * 16 + cbase + r;
+        if (valid[j]) act[(3 + c) * CS + qb[j]] = f0[(size_t)c * P + pb[j]];
+      }
+
+  const float *Hn = a.H + (size_t)n * D * 9;
+  const float *Hin = a.Hinc + (size_t)n * D * 9;
+  const float *src = a.src + (size_t)n * 3 * P;
+  uint8_t *maskg = a.mask + (size_t)n * D * P;
+  float *costg = a.cost + (size_t)n * 32 * D * P;
+  float *fvolg = a.fvol ? a.fvol + (size_t)n * 32 * D * P : nullptr;
+
+  // ---- plane 0: mask and cost from the extractor's features ---------------------------------
+  {
+    float Hl[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Hl[i] = Hn[i];
+    for (int p = tid; p < P; p += CH_THREADS) {
+      WarpCoord c = warp_coord(Hl, (float)(p % cols), (float)(p / cols), (float)rows, (float)cols);
+      maskb[p] = c.outside ? 1.0f : 0.0f;
+      maskg[p] = c.outside ? 1 : 0;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < TP; ++j) {
+    if (!valid[j]) continue;
+    const bool out = maskb[pb[j]] != 0.0f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = t * 16 + cbase + r;
+        const float f = act[(3 + c) * CS + qb[j]];
+        costg[((size_t)c * D) * P + pb[j]] = out ? 0.0f : fabsf(flp[(size_t)c * P + pb[j]] - f);
+        if (fvolg) fvolg[((size_t)c * D) * P + pb[j]] = out ? 0.0f : f;
+      }
+  }
+  const float inv_count = 1.0f / (8.0f * (float)P);
+
+  // ---- the recurrence ------------------------------------------------------------------------
+  for (int d = 1; d < D; ++d) {
+    floatx4 wreg[3];
+    load_weights_to_regs<W0_FLOATS>(a.packed, wreg, tid);
+
+    // A1: image plane d and its mask (global gathers; the 6 KB source image stays in L1/L2)
+    float img[IMG_IT][3];
+    float mk[IMG_IT];
+    {
+      float Hl[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Hl[i] = Hn[d * 9 + i];
+#pragma unroll
+      for (int it = 0; it < IMG_IT; ++it) {
+        const int p = tid + it * CH_THREADS;
+        if (p < P) {
+          WarpCoord c = warp_coord(Hl, (float)(p % cols), (float)(p / cols), (float)rows, (float)cols);
+          Bilinear b = bilinear_taps(c.ix, c.iy, rows, cols);
+          const float keep = c.outside ? 0.0f : 1.0f;
+          mk[it] = c.outside ? 1.0f : 0.0f;
+          const int o00 = b.y0 * cols + b.x0, o01 = b.y0 * cols + b.x1, o10 = b.y1 * cols + b.x0,
+                    o11 = b.y1 * cols + b.x1;
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) {
+            const float *ic = src + (size_t)ch * P;
+            img[it][ch] = keep * (ic[o00] * b.w00 + ic[o01] * b.w01 + ic[o10] * b.w10 + ic[o11] * b.w11);
+          }
+        }
+      }
+    }
+
+    // A2: previous plane's features moved by the incremental homography (gather from LDS)
+    floatx4 fp[TP][2];
+    {
+      float Hl[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Hl[i] = Hin[d * 9 + i];
+#pragma unroll
+      for (int j = 0; j < TP; ++j) {
+        WarpCoord c = warp_coord(Hl, (float)(pb[j] % cols), (float)(pb[j] / cols), (float)rows, (float)cols);
+        Bilinear b = bilinear_taps(c.ix, c.iy, rows, cols);
+        const float keep = c.outside ? 0.0f : 1.0f;
+        const int o00 = b.y0 * RS + b.x0, o01 = b.y0 * RS + b.x1, o10 = b.y1 * RS + b.x0, o11 = b.y1 * RS + b.x1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float *fc = act + (3 + t * 16 + cbase + r) * CS;
+            fp[j][t][r] = keep * (fc[o00] * b.w00 + fc[o01] * b.w01 + fc[o10] * b.w10 + fc[o11] * b.w11);
+          }
+      }
+    }
+    __syncthreads();  // B1: every gather of plane d-1 is done
+
+    // A3: lay out the refiner input [image(3) | moved features(32)]
+#pragma unroll
+    for (int j = 0; j < TP; ++j)
+      if (valid[j]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) act[(3 + t * 16 + cbase + r) * CS + qb[j]] = fp[j][t][r];
+      }
+#pragma unroll
+    for (int it = 0; it < IMG_IT; ++it) {
+      const int p = tid + it * CH_THREADS;
+      if (p < P) {
+        const int q = (p / cols) * RS + (p % cols);
+        act[0 * CS + q] = img[it][0];
+        act[1 * CS + q] = img[it][1];
+        act[2 * CS + q] = img[it][2];
+        maskb[p] = mk[it];
+        maskg[(size_t)d * P + p] = mk[it] != 0.0f ? 1 : 0;
+      }
+    }
+    store_weights_to_lds<W0_FLOATS>(wbuf, wreg, tid);
+    __syncthreads();  // B2
+
+    floatx4 acc[TP][2];
+    conv3x3_mfma<TP, 9>(act, wbuf, CS, RS, qb, lane, acc);
+    __syncthreads();  // B3: act and wbuf free
+
+    load_weights_to_regs<W1_FLOATS>(a.packed + W0_FLOATS, wreg, tid);
+    groupnorm_lrelu<TP>(acc, valid, bias0, gn0w, gn0b, red, red + 64, inv_count, lane, wave);
+#pragma unroll
+    for (int j = 0; j < TP; ++j)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (valid[j]) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) act[(t * 16 + cbase + r) * CS + qb[j]] = acc[j][t][r];
+        }
+      }
+    store_weights_to_lds<W1_FLOATS>(wbuf, wreg, tid);
+    __syncthreads();  // B6
+
+    conv3x3_mfma<TP, 8>(act, wbuf, CS, RS, qb, lane, acc);
+    __syncthreads();  // B7
+
+    load_weights_to_regs<W1_FLOATS>(a.packed + W0_FLOATS + W1_FLOATS, wreg, tid);
+    groupnorm_lrelu<TP>(acc, valid, bias1, gn1w, gn1b, red + 128, red + 192, inv_count, lane, wave);
+#pragma unroll
+    for (int j = 0; j < TP; ++j)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (valid[j]) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) act[(t * 16 + cbase + r) * CS + qb[j]] += acc[j][t][r];  // x2 = x1 + ...
+        }
+      }
+    store_weights_to_lds<W1_FLOATS>(wbuf, wreg, tid);
+    __syncthreads();  // B10
+
+    conv3x3_mfma<TP, 8>(act, wbuf, CS, RS, qb, lane, acc);
+    __syncthreads();  // B11
+
+    // epilogue: new features, cost slice, next step's gather source
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+      if (!valid[j]) continue;
+      const bool out = maskb[pb[j]] != 0.0f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = t * 16 + cbase + r;
+          const float f = fp[j][t][r] + (acc[j][t][r] + bias2[c]);
+          act[(3 + c) * CS + qb[j]] = f;
+          costg[((size_t)c * D + d) * P + pb[j]] = out ? 0.0f : fabsf(flp[(size_t)c * P + pb[j]] - f);
+          if (fvolg) fvolg[((size_t)c * D + d) * P + pb[j]] = out ? 0.0f : f;
+        }
+    }
+    __syncthreads();  // B12
+  }
+}
+
+static size_t chain_lds_bytes(int P, int act_floats, bool lds_act) {
+  const int Ppad = (P + 3) & ~3;
+  size_t f = (size_t)W0_FLOATS + SP_FLOATS + RED_FLOATS + Ppad;
+  if (lds_act) f += act_floats;
+  return f * sizeof(float);
+}
+
+static int chain_cs(int rows, int cols) {
+  const int RS = cols + 1, G = RS + 1;
+  int cs = rows * RS + G;
+  while ((cs & 31) != 16) ++cs;
+  return cs;
+}
+
+}  // namespace mvsn
+
+extern "C" size_t mvsn_feature_refiner_packed_floats(void) { return mvsn::PACKED_FLOATS; }
+
+extern "C" int mvsn_pack_feature_refiner(const float *conv0_w, const float *conv0_b, const float *bn0_w,
+                                         const float *bn0_b, const float *res0_w, const float *res0_b,
+                                         const float *res0_bn_w, const float *res0_bn_b, const float *final_w,
+                                         const float *final_b, float *packed, mvsn_stream_t stream) {
+  MVSN_REQUIRE(conv0_w && conv0_b && bn0_w && bn0_b && res0_w && res0_b && res0_bn_w && res0_bn_b && final_w &&
+                   final_b && packed,
+               MVSN_E_BADARG, "mvsn_pack_feature_refiner: null pointer");
+  hipLaunchKernelGGL(mvsn::pack_refiner_kernel, dim3((mvsn::PACKED_FLOATS + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, conv0_w, conv0_b, bn0_w, bn0_b, res0_w, res0_b, res0_bn_w, res0_bn_b,
+                     final_w, final_b, packed);
+  return mvsn::check_launch("mvsn_pack_feature_refiner");
+}
+
+extern "C" size_t mvsn_incremental_cost_volume_workspace_bytes(int n_chains, int rows, int cols) {
+  if (n_chains <= 0 || rows <= 0 || cols <= 0) return 0;
+  const int CS = mvsn::chain_cs(rows, cols);
+  const int act_floats = (cols + 2) + 36 * CS;
+  if (mvsn::chain_lds_bytes(rows * cols, act_floats, true) <= 160 * 1024) return 0;
+  return (size_t)n_chains * act_floats * sizeof(float);
+}
+
+extern "C" int mvsn_incremental_cost_volume(const float *src_image_lvl4, const float *H_lvl4, const float *H_inc,
+                                            const float *plane0_features, const float *left_features,
+                                            const float *refiner_packed, int n_chains, int batch,
+                                            int num_idepth_samples, int rows, int cols, float *cost_volume,
+                                            uint8_t *mask_volume, float *feature_volume, void *workspace,
+                                            size_t workspace_bytes, mvsn_stream_t stream) {
+  using namespace mvsn;
+  MVSN_REQUIRE(src_image_lvl4 && H_lvl4 && H_inc && plane0_features && left_features && refiner_packed &&
+                   cost_volume && mask_volume,
+               MVSN_E_BADARG, "mvsn_incremental_cost_volume: null pointer");
+  MVSN_REQUIRE(n_chains > 0 && batch > 0 && num_idepth_samples >= 1 && rows > 0 && cols > 0, MVSN_E_BADARG,
+               "mvsn_incremental_cost_volume: bad sizes");
+  const int P = rows * cols;
+  const int tiles = (P + 15) / 16;
+  const int TP = (tiles + CH_WAVES - 1) / CH_WAVES;
+  MVSN_REQUIRE(TP <= 5, MVSN_E_TOOLARGE,
+               "mvsn_incremental_cost_volume: %dx%d coarse grid (%d px) exceeds the 1280 px plan", rows, cols, P);
+  ChainArgs a;
+  a.src = src_image_lvl4;
+  a.H = H_lvl4;
+  a.Hinc = H_inc;
+  a.f0 = plane0_features;
+  a.fl = left_features;
+  a.packed = refiner_packed;
+  a.cost = cost_volume;
+  a.mask = mask_volume;
+  a.fvol = feature_volume;
+  a.B = batch;
+  a.D = num_idepth_samples;
+  a.rows = rows;
+  a.cols = cols;
+  a.CS = chain_cs(rows, cols);
+  const int act_floats = (cols + 2) + 36 * a.CS;
+  const bool lds_act = chain_lds_bytes(P, act_floats, true) <= 160 * 1024;
+  const size_t need = lds_act ? 0 : (size_t)n_chains * act_floats * sizeof(float);
+  MVSN_REQUIRE(lds_act || (workspace && workspace_bytes >= need), MVSN_E_WORKSPACE,
+               "mvsn_incremental_cost_volume: workspace of %zu bytes required", need);
+  a.workspace = lds_act ? nullptr : (float *)workspace;
+  const size_t lds = chain_lds_bytes(P, act_floats, lds_act);
+
+#define MVSN_CHAIN_LAUNCH(TPV, LDSV)                                                                           \
+  do {                                                                                                         \
+    auto kern = chain_kernel<TPV, LDSV>;                                                                       \
+    static size_t opted = 0;                                                                                   \
+    if (lds > opted) {                                                                                         \
+      hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) {                                                                                   \
+        set_error("mvsn_incremental_cost_volume: LDS opt-in of %zu bytes failed: %s", lds, hipGetErrorString(e)); \
+        return (int)e;                                                                                         \
+      }                                                                                                        \
+      opted = lds;                                                                                             \
+    }                                                                                                          \
+    hipLaunchKernelGGL(kern, dim3(n_chains), dim3(CH_THREADS), lds, (hipStream_t)stream, a);                   \
+  } while (0)
+
+  MVSN_REQUIRE(!lds_act || TP <= 3, MVSN_E_TOOLARGE, "mvsn_incremental_cost_volume: internal plan error");
+  if (lds_act) {
+    switch (TP) {
+      case 1: MVSN_CHAIN_LAUNCH(1, true); break;
+      case 2: MVSN_CHAIN_LAUNCH(2, true); break;
+      default: MVSN_CHAIN_LAUNCH(3, true); break;
+    }
+  } else {
+    switch (TP) {
+      case 1: MVSN_CHAIN_LAUNCH(1, false); break;
+      case 2: MVSN_CHAIN_LAUNCH(2, false); break;
+      case 3: MVSN_CHAIN_LAUNCH(3, false); break;
+      case 4: MVSN_CHAIN_LAUNCH(4, false); break;
+      default: MVSN_CHAIN_LAUNCH(5, false); break;
+    }
+  }
+#undef MVSN_CHAIN_LAUNCH
+  return check_launch("mvsn_incremental_cost_volume");
+}

@@ -1,0 +1,92 @@
+// Shared helpers for libmvsn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mvsn_hip.h"
+
+namespace mvsn {
+
+void set_error(const char *fmt, ...);
+
+inline int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+#define MVSN_REQUIRE(cond, code, ...)   \
+  do {                                  \
+    if (!(cond)) {                      \
+      ::mvsn::set_error(__VA_ARGS__);   \
+      return (code);                    \
+    }                                   \
+  } while (0)
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// D(16x16) += A(16x4) * B(4x16), exact fp32.  Lane l supplies A[l&15][l>>4] and B[l>>4][l&15];
+// it receives D[(l>>4)*4 + r][l&15] in element r.
+__device__ __forceinline__ floatx4 mfma16x16x4(float a, float b, floatx4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float lrelu02(float v) { return v > 0.0f ? v : 0.2f * v; }
+
+// Source-pixel coordinate of a homography warp, evaluated with the same fp32 expression order
+// as the reference (stereo/image_predictor.py:493-516) followed by grid_sample's
+// un-normalisation, so that the |n|>1 predicate flips on the same pixels.
+struct WarpCoord {
+  float ix, iy;  // un-normalised, NOT yet clamped
+  bool outside;
+};
+
+__device__ __forceinline__ WarpCoord warp_coord(const float *H, float x, float y, float rows, float cols) {
+  float u0 = H[0] * x + H[1] * y + H[2];
+  float u1 = H[3] * x + H[4] * y + H[5];
+  float u2 = H[6] * x + H[7] * y + H[8];
+  float px = u0 / u2;
+  float py = u1 / u2;
+  float nx = ((px + 0.5f) * 2.0f) / cols - 1.0f;
+  float ny = ((py + 0.5f) * 2.0f) / rows - 1.0f;
+  WarpCoord c;
+  c.outside = (fabsf(nx) > 1.0f) || (fabsf(ny) > 1.0f);
+  c.ix = ((nx + 1.0f) * cols - 1.0f) * 0.5f;
+  c.iy = ((ny + 1.0f) * rows - 1.0f) * 0.5f;
+  return c;
+}
+
+// Clamp-to-edge bilinear footprint: integer top-left tap, the +1 taps clamped (their weight is
+// exactly zero whenever the clamp acts), and the four weights.
+struct Bilinear {
+  int x0, y0, x1, y1;
+  float w00, w01, w10, w11;
+};
+
+__device__ __forceinline__ Bilinear bilinear_taps(float ix, float iy, int rows, int cols) {
+  // NaN coordinates (u2 == 0) propagate through the weights exactly as in grid_sample; fminf/fmaxf
+  // would swallow them, so clamp with comparisons.
+  ix = ix < 0.0f ? 0.0f : (ix > (float)(cols - 1) ? (float)(cols - 1) : ix);
+  iy = iy < 0.0f ? 0.0f : (iy > (float)(rows - 1) ? (float)(rows - 1) : iy);
+  float fx0 = floorf(ix), fy0 = floorf(iy);
+  float fx = ix - fx0, fy = iy - fy0;
+  Bilinear b;
+  b.x0 = (int)fx0;
+  b.y0 = (int)fy0;
+  if (!(b.x0 >= 0 && b.x0 < cols)) b.x0 = 0;  // only reachable through NaN
+  if (!(b.y0 >= 0 && b.y0 < rows)) b.y0 = 0;
+  b.x1 = b.x0 + 1 < cols ? b.x0 + 1 : cols - 1;
+  b.y1 = b.y0 + 1 < rows ? b.y0 + 1 : rows - 1;
+  b.w00 = (1.0f - fx) * (1.0f - fy);
+  b.w01 = fx * (1.0f - fy);
+  b.w10 = (1.0f - fx) * fy;
+  b.w11 = fx * fy;
+  return b;
+}
+
+}  // namespace mvsn

@@ -1,0 +1,492 @@
+// Direct 2-D / 3-D convolution on fp32 MFMA for the feature extractor, the cost-volume
+// regulariser and the idepth refiners (see include/mvsn_hip.h: mvsn_conv_forward).
+//
+// Implicit GEMM with A = weights (16 couts x 4 cins per v_mfma_f32_16x16x4_f32) and
+// B = activations (4 cins x 16 consecutive output columns).  A 256-thread workgroup owns an
+// output tile of TZ x TY x 32 positions and all (<= 32) output channels; the input is walked in
+// chunks of 8 channels: the haloed chunk tile and that chunk's weight fragments are staged in
+// LDS, then every tap is a plain offset read.  The previous layer's GroupNorm + LeakyReLU can be
+// applied while the tile is staged, and the epilogue emits per-tile GroupNorm partials
+// (count, mean, M2) so normalisation never needs its own pass over the volume.
+//
+// LDS tile: [8 ch][HZ][HY][XS], channel stride CST = 16 (mod 32) -> the 16-column x 4-channel
+// fragment read is bank-conflict-free at stride 1.
+#include "mvsn_common.h"
+
+namespace mvsn {
+
+constexpr int CV_THREADS = 256;
+constexpr int CV_WAVES = 4;
+constexpr int CV_TX = 32;   // output columns per tile
+constexpr int CV_CK = 8;    // input channels per staged chunk
+constexpr float CV_EPS = 1e-5f;
+
+struct ConvGeom {
+  int n, cin, cout, D, H, W, Do, Ho, Wo;
+  int kd, kh, kw, stride, dil, pd, ph, pw;
+  int TZ, TY;           // output tile (TX = 32)
+  int HZ, HY, HX, XS;   // staged extent and padded row stride
+  int CST;              // channel stride in LDS (floats)
+  int ntz, nty, ntx, tiles;
+  int ntaps, nchunks;
+  int wfloats_chunk;    // ntaps * 2 ksteps * 2 cout-tiles * 64
+  size_t lds_bytes;
+};
+
+static bool make_geom(const mvsn_conv_desc *d, ConvGeom *g) {
+  if (!d || d->n <= 0 || d->c_in <= 0 || d->c_out <= 0 || d->c_out > 32 || d->depth <= 0 || d->rows <= 0 ||
+      d->cols <= 0)
+    return false;
+  if (d->kd <= 0 || d->kh <= 0 || d->kw <= 0 || !(d->kd & 1) || !(d->kh & 1) || !(d->kw & 1)) return false;
+  if (d->stride != 1 && d->stride != 2) return false;
+  if (d->dilation < 1) return false;
+  if (d->depth > 1 && d->stride != 1) return false;
+  g->n = d->n, g->cin = d->c_in, g->cout = d->c_out, g->D = d->depth, g->H = d->rows, g->W = d->cols;
+  g->kd = d->kd, g->kh = d->kh, g->kw = d->kw, g->stride = d->stride, g->dil = d->dilation;
+  g->pd = d->kd / 2, g->ph = d->dilation * (d->kh / 2), g->pw = d->dilation * (d->kw / 2);
+  g->Do = d->depth;
+  g->Ho = (d->rows - 1) / d->stride + 1;
+  g->Wo = (d->cols - 1) / d->stride + 1;
+  const bool is3d = d->depth > 1 || d->kd > 1;
+  g->TZ = is3d ? 2 : 1;
+  g->TY = 8;
+  g->HZ = g->TZ + d->kd - 1;
+  g->HY = (g->TY - 1) * d->stride + d->dilation * (d->kh - 1) + 1;
+  g->HX = (CV_TX - 1) * d->stride + d->dilation * (d->kw - 1) + 1;
+  g->XS = g->HX;
+  int cst = g->HZ * g->HY * g->XS;
+  while ((cst & 31) != 16) ++cst;
+  g->CST = cst;
+  g->ntz = (g->Do + g->TZ - 1) / g->TZ;
+  g->nty = (g->Ho + g->TY - 1) / g->TY;
+  g->ntx = (g->Wo + CV_TX - 1) / CV_TX;
+  g->tiles = g->ntz * g->nty * g->ntx;
+  g->ntaps = d->kd * d->kh * d->kw;
+  g->nchunks = (d->c_in + CV_CK - 1) / CV_CK;
+  g->wfloats_chunk = g->ntaps * 2 * 2 * 64;
+  g->lds_bytes = ((size_t)CV_CK * g->CST + g->wfloats_chunk + 64 /*in scale/shift*/ + 64 /*red*/) * sizeof(float);
+  return g->lds_bytes <= 160 * 1024;
+}
+
+// packed weights: [chunk][tap][kstep 2][cout-tile 2][lane 64]; lane = k*16 + i holds
+// W[cout = t*16 + i][cin = chunk*8 + ks*4 + k][tap], zero outside (c_in, c_out).
+__global__ void conv_pack_kernel(const float *__restrict__ w, int cin, int cout, int ntaps, int nchunks,
+                                 float *__restrict__ out) {
+  const int total = nchunks * ntaps * 256;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int lane = i & 63, t = (i >> 6) & 1, ks = (i >> 7) & 1;
+  const int tap = (i >> 8) % ntaps, chunk = (i >> 8) / ntaps;
+  const int co = t * 16 + (lane & 15);
+  const int ci = chunk * CV_CK + ks * 4 + (lane >> 4);
+  out[i] = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * ntaps + tap] : 0.0f;
+}
+
+template <int NPT>  // pixel tiles (16 columns each) per wave: TZ*TY*2/4
+__global__ __launch_bounds__(CV_THREADS) void conv_mfma_kernel(ConvGeom g, const float *__restrict__ in,
+                                                               const float *__restrict__ wpk,
+                                                               const float *__restrict__ bias,
+                                                               const float *__restrict__ in_stats,
+                                                               const float *__restrict__ in_gamma,
+                                                               const float *__restrict__ in_beta,
+                                                               float *__restrict__ out,
+                                                               float *__restrict__ out_partials) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *tile = smem;                               // CV_CK * CST
+  float *wl = tile + (size_t)CV_CK * g.CST;         // wfloats_chunk
+  float *scsh = wl + g.wfloats_chunk;               // 32 scale + 32 shift of the input transform
+  float *red = scsh + 64;                           // 4 waves x 4 groups x (sum | M2)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.y;
+  int tix = blockIdx.x;
+  const int txi = tix % g.ntx;
+  tix /= g.ntx;
+  const int tyi = tix % g.nty;
+  const int tzi = tix / g.nty;
+  const int z0 = tzi * g.TZ, y0 = tyi * g.TY, x0 = txi * CV_TX;  // output-space origin
+  const int gz0 = z0 - g.pd, gy0 = y0 * g.stride - g.ph, gx0 = x0 * g.stride - g.pw;  // input-space origin
+  const size_t in_plane = (size_t)g.H * g.W, in_chan = (size_t)g.D * in_plane;
+  const float *inn = in + (size_t)n * g.cin * in_chan;
+
+  // this lane's output positions
+  int lpos[NPT];      // offset of (z, y, x) in the staged tile (tap (0,0,0))
+  int oz[NPT], oy[NPT], ox[NPT];
+  bool valid[NPT];
+#pragma unroll
+  for (int j = 0; j < NPT; ++j) {
+    const int pt = wave * NPT + j;
+    const int xt = pt & 1, yy = (pt >> 1) % g.TY, zz = (pt >> 1) / g.TY;
+    const int xx = xt * 16 + (lane & 15);
+    oz[j] = z0 + zz, oy[j] = y0 + yy, ox[j] = x0 + xx;
+    valid[j] = oz[j] < g.Do && oy[j] < g.Ho && ox[j] < g.Wo;
+    lpos[j] = (zz * g.HY + yy * g.stride) * g.XS + xx * g.stride;
+  }
+
+  floatx4 acc[NPT][2];
+#pragma unroll
+  for (int j = 0; j < NPT; ++j) acc[j][0] = acc[j][1] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  const bool xform = in_stats != nullptr;
+  const int rows_per_ch = g.HZ * g.HY;
+  const int kbase = (lane >> 4) * g.CST;
+
+  for (int chunk = 0; chunk < g.nchunks; ++chunk) {
+    const int c0 = chunk * CV_CK;
+    const int cc = min(CV_CK, g.cin - c0);
+    __syncthreads();  // previous chunk fully consumed
+    if (xform && tid < cc) {
+      const int c = c0 + tid;
+      const int grp = c >> 3;
+      const float mean = in_stats[((size_t)n * 4 + grp) * 2 + 0];
+      const float rstd = in_stats[((size_t)n * 4 + grp) * 2 + 1];
+      const float sc = rstd * in_gamma[c];
+      scsh[tid] = sc;
+      scsh[32 + tid] = in_beta[c] - mean * sc;
+    }
+    // weights of this chunk
+    {
+      const float *wsrc = wpk + (size_t)chunk * g.wfloats_chunk;
+      for (int i = tid * 4; i < g.wfloats_chunk; i += CV_THREADS * 4)
+        *reinterpret_cast<floatx4 *>(wl + i) = *reinterpret_cast<const floatx4 *>(wsrc + i);
+    }
+    if (xform) __syncthreads();
+    // haloed input rows: one wave per (channel, z, y) row, lanes along x
+    const int total_rows = CV_CK * rows_per_ch;
+    for (int r = wave; r < total_rows; r += CV_WAVES) {
+      const int c = r / rows_per_ch;
+      const int rem = r - c * rows_per_ch;
+      const int z = rem / g.HY, y = rem - z * g.HY;
+      const int gz = gz0 + z, gy = gy0 + y;
+      const bool row_ok = c < cc && gz >= 0 && gz < g.D && gy >= 0 && gy < g.H;
+      float *dst = tile + (size_t)c * g.CST + (z * g.HY + y) * g.XS;
+      const float *srow = inn + (size_t)(c0 + c) * in_chan + (size_t)(row_ok ? gz : 0) * in_plane +
+                          (size_t)(row_ok ? gy : 0) * g.W;
+      float sc = 1.0f, sh = 0.0f;
+      if (xform && c < cc) {
+        sc = scsh[c];
+        sh = scsh[32 + c];
+      }
+      for (int x = lane; x < g.HX; x += 64) {
+        const int gx = gx0 + x;
+        float v = 0.0f;
+        if (row_ok && gx >= 0 && gx < g.W) {
+          v = srow[gx];
+          if (xform) v = lrelu02(v * sc + sh);
+        }
+        dst[x] = v;
+      }
+    }
+    __syncthreads();
+
+    const int nks = (cc + 3) >> 2;  // 1 or 2 k-steps carry data in this chunk
+    int tap = 0;
+    for (int tz = 0; tz < g.kd; ++tz)
+      for (int ty = 0; ty < g.kh; ++ty)
+        for (int tx = 0; tx < g.kw; ++tx, ++tap) {
+          const int toff = (tz * g.HY + ty * g.dil) * g.XS + tx * g.dil;
+          const float *wt = wl + tap * 256 + lane;
+          for (int ks = 0; ks < nks; ++ks) {
+            const float w0 = wt[ks * 128];
+            const float w1 = wt[ks * 128 + 64];
+            const float *bp = tile + ks * 4 * g.CST + kbase + toff;
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) {
+              const float b = bp[lpos[j]];
+              acc[j][0] = mfma16x16x4(w0, b, acc[j][0]);
+              acc[j][1] = mfma16x16x4(w1, b, acc[j][1]);
+            }
+          }
+        }
+  }
+
+  // ---- epilogue: bias, store, GroupNorm partials ---------------------------------------------
+  const int cbase = (lane >> 4) * 4;
+  const size_t out_plane = (size_t)g.Ho * g.Wo, out_chan = (size_t)g.Do * out_plane;
+  float *outn = out + (size_t)n * g.cout * out_chan;
+  float s[2] = {0.f, 0.f};
+  int cnt = 0;
+#pragma unroll
+  for (int j = 0; j < NPT; ++j) {
+    const size_t pos = (size_t)oz[j] * out_plane + (size_t)oy[j] * g.Wo + ox[j];
+    if (valid[j]) cnt += 1;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = t * 16 + cbase + r;
+        if (c < g.cout) {
+          const float v = acc[j][t][r] + (bias ? bias[c] : 0.0f);
+          acc[j][t][r] = v;
+          if (valid[j]) {
+            outn[(size_t)c * out_chan + pos] = v;
+            s[t] += v;
+          }
+        }
+      }
+  }
+  if (out_partials == nullptr) return;  // uniform across the grid
+
+  // group of channel t*16 + cbase + r is 2t + (lane >> 5): reduce over the 32 lanes of a half-wave
+  auto half_wave_sum = [&](float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    return v;
+  };
+  const int hi = lane >> 5;
+  // valid positions in this tile (same for every group): count over lanes 0..15 of each wave
+  int cnt_tile;
+  {
+    float c = (lane < 16) ? (float)cnt : 0.0f;
+    c = half_wave_sum(c);
+    __syncthreads();  // red is free (first use in this kernel)
+    if (lane == 0) red[wave] = c;
+    __syncthreads();
+    cnt_tile = (int)(red[0] + red[1] + red[2] + red[3]);
+    __syncthreads();
+  }
+  const float npos = (float)cnt_tile * 8.0f;  // elements per group in this tile
+  float m[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) s[t] = half_wave_sum(s[t]);
+  if ((lane & 31) == 0) {
+    red[wave * 4 + 0 + hi] = s[0];
+    red[wave * 4 + 2 + hi] = s[1];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float tot = 0.f;
+    for (int w = 0; w < CV_WAVES; ++w) tot += red[w * 4 + t * 2 + hi];
+    m[t] = cnt_tile > 0 ? tot / npos : 0.0f;
+  }
+  __syncthreads();
+  float q[2] = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < NPT; ++j)
+    if (valid[j]) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float dv = acc[j][t][r] - m[t];
+          q[t] += dv * dv;
+        }
+    }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) q[t] = half_wave_sum(q[t]);
+  if ((lane & 31) == 0) {
+    red[wave * 4 + 0 + hi] = q[0];
+    red[wave * 4 + 2 + hi] = q[1];
+  }
+  __syncthreads();
+  if (wave == 0 && (lane & 31) == 0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float tot = 0.f;
+      for (int w = 0; w < CV_WAVES; ++w) tot += red[w * 4 + t * 2 + hi];
+      float *p = out_partials + (((size_t)n * g.tiles + blockIdx.x) * 4 + (t * 2 + hi)) * 3;
+      p[0] = npos;
+      p[1] = m[t];
+      p[2] = tot;
+    }
+  }
+}
+
+// Chan et al. combination of per-tile (count, mean, M2) in double; one workgroup per (n, group).
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restrict__ partials, int tiles,
+                                                          float *__restrict__ stats) {
+  const int n = blockIdx.x >> 2, grp = blockIdx.x & 3;
+  const int tid = threadIdx.x;
+  __shared__ double s_a[256], s_b[256];
+  const float *p = partials + ((size_t)n * tiles * 4 + grp) * 3;
+  double cnt = 0.0, sum = 0.0;
+  for (int t = tid; t < tiles; t += 256) {
+    const float *e = p + (size_t)t * 12;
+    cnt += (double)e[0];
+    sum += (double)e[0] * (double)e[1];
+  }
+  s_a[tid] = cnt, s_b[tid] = sum;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) s_a[tid] += s_a[tid + s], s_b[tid] += s_b[tid + s];
+    __syncthreads();
+  }
+  const double N = s_a[0];
+  const double mean = s_b[0] / N;
+  __syncthreads();
+  double m2 = 0.0;
+  for (int t = tid; t < tiles; t += 256) {
+    const float *e = p + (size_t)t * 12;
+    const double dm = (double)e[1] - mean;
+    m2 += (double)e[2] + (double)e[0] * dm * dm;
+  }
+  s_a[tid] = m2;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) s_a[tid] += s_a[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double var = s_a[0] / N;
+    stats[((size_t)n * 4 + grp) * 2 + 0] = (float)mean;
+    stats[((size_t)n * 4 + grp) * 2 + 1] = (float)(1.0 / sqrt(var + (double)CV_EPS));
+  }
+}
+
+// out = [residual +] LeakyReLU(GroupNorm(x)), (N,32,spatial), float4 per thread.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, const float *__restrict__ stats,
+                                                       const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta,
+                                                       const float *__restrict__ residual, long spatial,
+                                                       float *__restrict__ out) {
+  const int plane = blockIdx.y;  // n*32 + c
+  const int n = plane >> 5, c = plane & 31;
+  const float mean = stats[((size_t)n * 4 + (c >> 3)) * 2 + 0];
+  const float rstd = stats[((size_t)n * 4 + (c >> 3)) * 2 + 1];
+  const float sc = rstd * gamma[c];
+  const float sh = beta[c] - mean * sc;
+  const float *xp = x + (size_t)plane * spatial;
+  const float *rp = residual ? residual + (size_t)plane * spatial : nullptr;
+  float *op = out + (size_t)plane * spatial;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  const bool vec_ok = (spatial & 3) == 0;
+  if (vec_ok) {
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < spatial; i += stride) {
+      floatx4 v = *reinterpret_cast<const floatx4 *>(xp + i);
+      floatx4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = lrelu02(v[k] * sc + sh);
+      if (rp) {
+        floatx4 rv = *reinterpret_cast<const floatx4 *>(rp + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] += rv[k];
+      }
+      *reinterpret_cast<floatx4 *>(op + i) = o;
+    }
+  } else {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < spatial; i += (long)gridDim.x * blockDim.x) {
+      float o = lrelu02(xp[i] * sc + sh);
+      if (rp) o += rp[i];
+      op[i] = o;
+    }
+  }
+}
+
+// ---- MFMA fragment self-test ---------------------------------------------------------------
+__global__ void mfma_selftest_kernel(int *bad) {
+  const int lane = threadIdx.x;
+  // A[i][k] = 1 + i + 17k (asymmetric), B[k][j] = 3 + 5k - 2j
+  const float a = 1.0f + (float)(lane & 15) + 17.0f * (float)(lane >> 4);
+  const float b = 3.0f + 5.0f * (float)(lane >> 4) - 2.0f * (float)(lane & 15);
+  floatx4 c = {0.f, 0.f, 0.f, 0.f};
+  c = mfma16x16x4(a, b, c);
+  int wrong = 0;
+  for (int r = 0; r < 4; ++r) {
+    const int i = (lane >> 4) * 4 + r, j = lane & 15;
+    float ref = 0.f;
+    for (int k = 0; k < 4; ++k) ref += (1.0f + i + 17.0f * k) * (3.0f + 5.0f * k - 2.0f * j);
+    if (fabsf(ref - c[r]) > 1e-3f) wrong++;
+  }
+  if (wrong) atomicAdd(bad, wrong);
+}
+
+}  // namespace mvsn
+
+extern "C" size_t mvsn_conv_packed_floats(const mvsn_conv_desc *desc) {
+  mvsn::ConvGeom g;
+  if (!mvsn::make_geom(desc, &g)) return 0;
+  return (size_t)g.nchunks * g.wfloats_chunk;
+}
+
+extern "C" int mvsn_conv_num_tiles(const mvsn_conv_desc *desc) {
+  mvsn::ConvGeom g;
+  if (!mvsn::make_geom(desc, &g)) return 0;
+  return g.tiles;
+}
+
+extern "C" int mvsn_conv_pack_weights(const mvsn_conv_desc *desc, const float *weight, float *packed,
+                                      mvsn_stream_t stream) {
+  mvsn::ConvGeom g;
+  MVSN_REQUIRE(mvsn::make_geom(desc, &g), MVSN_E_BADARG, "mvsn_conv_pack_weights: unsupported descriptor");
+  MVSN_REQUIRE(weight && packed, MVSN_E_BADARG, "mvsn_conv_pack_weights: null pointer");
+  const int total = g.nchunks * g.ntaps * 256;
+  hipLaunchKernelGGL(mvsn::conv_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, weight,
+                     g.cin, g.cout, g.ntaps, g.nchunks, packed);
+  return mvsn::check_launch("mvsn_conv_pack_weights");
+}
+
+extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, const float *weight_packed,
+                                 const float *bias, const float *in_stats, const float *in_gamma,
+                                 const float *in_beta, float *out, float *out_partials, mvsn_stream_t stream) {
+  using namespace mvsn;
+  ConvGeom g;
+  MVSN_REQUIRE(make_geom(desc, &g), MVSN_E_BADARG, "mvsn_conv_forward: unsupported descriptor");
+  MVSN_REQUIRE(in && weight_packed && out, MVSN_E_BADARG, "mvsn_conv_forward: null pointer");
+  MVSN_REQUIRE(!in_stats || (in_gamma && in_beta), MVSN_E_BADARG, "mvsn_conv_forward: input transform needs gamma/beta");
+  MVSN_REQUIRE(!in_stats || g.cin == 32, MVSN_E_BADARG, "mvsn_conv_forward: input transform needs 32 channels");
+  MVSN_REQUIRE(!out_partials || g.cout == 32, MVSN_E_BADARG, "mvsn_conv_forward: partials need 32 output channels");
+  MVSN_REQUIRE(g.n <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_forward: batch too large for one launch");
+  dim3 grid(g.tiles, g.n);
+#define MVSN_CONV_LAUNCH(NPTV)                                                                                   \
+  do {                                                                                                           \
+    auto kern = conv_mfma_kernel<NPTV>;                                                                          \
+    static size_t opted = 0;                                                                                     \
+    if (g.lds_bytes > opted) {                                                                                   \
+      hipError_t e =                                                                                             \
+          hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes); \
+      if (e != hipSuccess) {                                                                                     \
+        set_error("mvsn_conv_forward: LDS opt-in of %zu bytes failed: %s", g.lds_bytes, hipGetErrorString(e));   \
+        return (int)e;                                                                                           \
+      }                                                                                                          \
+      opted = g.lds_bytes;                                                                                       \
+    }                                                                                                            \
+    hipLaunchKernelGGL(kern, grid, dim3(CV_THREADS), g.lds_bytes, (hipStream_t)stream, g, in, weight_packed, bias, \
+                       in_stats, in_gamma, in_beta, out, out_partials);                                          \
+  } while (0)
+  if (g.TZ == 2)
+    MVSN_CONV_LAUNCH(8);
+  else
+    MVSN_CONV_LAUNCH(4);
+#undef MVSN_CONV_LAUNCH
+  return check_launch("mvsn_conv_forward");
+}
+
+extern "C" int mvsn_groupnorm_finalize(const float *partials, int n, int tiles, float *stats, mvsn_stream_t stream) {
+  MVSN_REQUIRE(partials && stats && n > 0 && tiles > 0, MVSN_E_BADARG, "mvsn_groupnorm_finalize: bad argument");
+  hipLaunchKernelGGL(mvsn::gn_finalize_kernel, dim3(n * 4), dim3(256), 0, (hipStream_t)stream, partials, tiles, stats);
+  return mvsn::check_launch("mvsn_groupnorm_finalize");
+}
+
+extern "C" int mvsn_groupnorm_lrelu_apply(const float *x, const float *stats, const float *gamma, const float *beta,
+                                          const float *residual, int n, long spatial, float *out,
+                                          mvsn_stream_t stream) {
+  MVSN_REQUIRE(x && stats && gamma && beta && out && n > 0 && spatial > 0, MVSN_E_BADARG,
+               "mvsn_groupnorm_lrelu_apply: bad argument");
+  MVSN_REQUIRE((long)n * 32 <= 65535, MVSN_E_TOOLARGE, "mvsn_groupnorm_lrelu_apply: batch too large for one launch");
+  long per = (spatial + 1023) / 1024;
+  int gx = (int)(per < 1 ? 1 : (per > 64 ? 64 : per));
+  hipLaunchKernelGGL(mvsn::gn_apply_kernel, dim3(gx, n * 32), dim3(256), 0, (hipStream_t)stream, x, stats, gamma,
+                     beta, residual, spatial, out);
+  return mvsn::check_launch("mvsn_groupnorm_lrelu_apply");
+}
+
+extern "C" int mvsn_selftest_mfma(mvsn_stream_t stream) {
+  int *dbad = nullptr;
+  hipError_t e = hipMalloc(&dbad, sizeof(int));
+  if (e != hipSuccess) return (int)e;
+  (void)hipMemsetAsync(dbad, 0, sizeof(int), (hipStream_t)stream);
+  hipLaunchKernelGGL(mvsn::mfma_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dbad);
+  int bad = -1;
+  (void)hipMemcpyAsync(&bad, dbad, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
+  (void)hipStreamSynchronize((hipStream_t)stream);
+  (void)hipFree(dbad);
+  if (bad != 0) {
+    mvsn::set_error("mvsn_selftest_mfma: %d fragment elements differ from the scalar product", bad);
+    return MVSN_E_BADARG - 100;
+  }
+  return 0;
+}

@@ -1,0 +1,365 @@
+"""MultiViewStereoNet on MI355X: the reference's module boundary over libmvsn_hip.so.
+
+Drop-in for multi_view_stereonet/multi_view_stereonet.py:494-695 of the reference:
+
+* no-argument constructor, ``num_levels == 5``;
+* ``forward(left_image_pyr, K_pyr, T_right_in_lefts, right_image_pyrs, num_idepth_samples,
+  do_cost_volume_filter, do_refiners)`` with the same positional meaning (:538-545) and the same
+  output dict of three 5-level pyramids (:686-693);
+* the same 226-key ``state_dict`` (params.py), so pretrained tensors load with strict=True.
+
+The modules hold parameters only.  All compute is enqueued on the current HIP stream through
+the C ABI in include/mvsn_hip.h; PyTorch provides device memory and the stream, nothing else.
+There is no CPU path: CPU tensors, or a missing library, raise.
+
+Execution plan of one forward (B reference images, S sources each, N = S*B chains):
+  1. mvsn_plane_sweep_setup         poses -> idepth samples, homography families       (a3, a4)
+  2. mvsn_homography_warp           full-res source images at plane 0                   (a5)
+  3. feature extractor, ONE batch of (1+S)*B images through mvsn_conv_forward           (a2)
+  4. mvsn_incremental_cost_volume   the fused chain -> cost volume + mask               (a6-a8)
+  5. cost-volume regulariser: five mvsn_conv_forward (3-D), GroupNorm folded into the
+     next layer's tile load; mvsn_soft_argmin                                           (a9, a10)
+  6. refiner 4 on all N chains, mvsn_fuse_sources                                       (a11, a13)
+  7. levels 3..0: mvsn_upsample_bilinear / mvsn_upsample_mask + refiner                 (a12, a11)
+"""
+import ctypes
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _native
+from .params import REFINER_DILATIONS, build_parameter_tree
+
+ListTensor = List[torch.Tensor]
+
+
+class _Conv:
+    """One convolution's packed weights + descriptor fields that do not depend on the input size."""
+
+    def __init__(self, lib, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int = 1, dilation: int = 1):
+        self.lib = lib
+        self.cout, self.cin = int(weight.shape[0]), int(weight.shape[1])
+        self.dims = weight.dim() - 2
+        k = tuple(int(s) for s in weight.shape[2:])
+        self.kd, self.kh, self.kw = (k if self.dims == 3 else (1,) + k)
+        self.stride, self.dilation = stride, dilation
+        self.bias = bias.detach().contiguous().float() if bias is not None else None
+        d = self.desc(1, 1 if self.dims == 2 else 2, 8, 32)
+        n = lib.mvsn_conv_packed_floats(ctypes.byref(d))
+        if n == 0:
+            raise RuntimeError("mvsn_conv_packed_floats rejected the descriptor")
+        self.packed = torch.empty(n, dtype=torch.float32, device=weight.device)
+        w = weight.detach().contiguous().float()
+        _native.check(lib.mvsn_conv_pack_weights(ctypes.byref(d), _native.ptr(w), _native.ptr(self.packed),
+                                                 _native.stream()), "mvsn_conv_pack_weights")
+
+    def desc(self, n, depth, rows, cols):
+        return _native.ConvDesc(n, self.cin, self.cout, depth, rows, cols, self.kd, self.kh, self.kw,
+                                self.stride, self.dilation)
+
+
+class _Norm:
+    def __init__(self, p):
+        self.gamma = p.weight.detach().contiguous().float()
+        self.beta = p.bias.detach().contiguous().float()
+
+
+class PlaneSweepEngine:
+    """Packed weights + the launch sequence.  Built lazily from the module's parameters."""
+
+    def __init__(self, net: "MultiViewStereoNet"):
+        self.lib = lib = _native.load()
+        fe = net.left_feature_extractor
+        self.fe_down = [_Conv(lib, getattr(fe, f"conv{i}").weight, None, stride=2) for i in range(4)]
+        self.fe_res = [(_Conv(lib, getattr(fe, f"res{i}").conv1.weight, None), _Norm(getattr(fe, f"res{i}").bn1))
+                       for i in range(6)]
+        self.fe_final = _Conv(lib, fe.conv_final.weight, fe.conv_final.bias)
+
+        r = net.right_feature_extractor.refiner
+        dev = r.conv0.weight.device
+        self.refiner_packed = torch.empty(lib.mvsn_feature_refiner_packed_floats(), dtype=torch.float32, device=dev)
+        tensors = [r.conv0.weight, r.conv0.bias, r.bn0.weight, r.bn0.bias, r.res0.conv1.weight, r.res0.conv1.bias,
+                   r.res0.bn1.weight, r.res0.bn1.bias, r.conv_final.weight, r.conv_final.bias]
+        tensors = [t.detach().contiguous().float() for t in tensors]
+        _native.check(lib.mvsn_pack_feature_refiner(*[_native.ptr(t) for t in tensors],
+                                                    _native.ptr(self.refiner_packed), _native.stream()),
+                      "mvsn_pack_feature_refiner")
+
+        vf = net.volume_filter4
+        self.vf_convs = [_Conv(lib, getattr(vf, f"conv{i}").weight, getattr(vf, f"conv{i}").bias) for i in range(5)]
+        self.vf_norms = [_Norm(getattr(vf, f"bn{i}")) for i in range(4)]
+
+        self.refiners = []
+        for lvl in range(5):
+            m = getattr(net, f"refiner{lvl}")
+            self.refiners.append({
+                "conv0": _Conv(lib, m.conv0.weight, m.conv0.bias),
+                "bn0": _Norm(m.bn0),
+                "res": [(_Conv(lib, getattr(m, f"res{i}").conv1.weight, getattr(m, f"res{i}").conv1.bias,
+                               dilation=REFINER_DILATIONS[i]), _Norm(getattr(m, f"res{i}").bn1)) for i in range(6)],
+                "final": _Conv(lib, m.conv_final.weight, m.conv_final.bias),
+            })
+
+    # ---- primitive wrappers ------------------------------------------------------------------
+    def conv(self, c: _Conv, x: torch.Tensor, in_stats=None, in_norm: Optional[_Norm] = None, want_stats=False):
+        """x (N,C,[D,]H,W) -> (out, stats or None).  `in_stats`/`in_norm` fold LReLU(GN(x)) into the load."""
+        lib = self.lib
+        n = x.shape[0]
+        depth = x.shape[2] if c.dims == 3 else 1
+        rows, cols = x.shape[-2], x.shape[-1]
+        d = c.desc(n, depth, rows, cols)
+        ro, co = (rows - 1) // c.stride + 1, (cols - 1) // c.stride + 1
+        shape = (n, c.cout, depth, ro, co) if c.dims == 3 else (n, c.cout, ro, co)
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        partials = None
+        if want_stats:
+            tiles = lib.mvsn_conv_num_tiles(ctypes.byref(d))
+            partials = torch.empty((n, tiles, 4, 3), dtype=torch.float32, device=x.device)
+        _native.check(lib.mvsn_conv_forward(ctypes.byref(d), _native.ptr(x), _native.ptr(c.packed),
+                                            _native.ptr(c.bias), _native.ptr(in_stats),
+                                            _native.ptr(in_norm.gamma) if in_norm else None,
+                                            _native.ptr(in_norm.beta) if in_norm else None,
+                                            _native.ptr(out), _native.ptr(partials), _native.stream()),
+                      "mvsn_conv_forward")
+        stats = None
+        if want_stats:
+            stats = torch.empty((n, 4, 2), dtype=torch.float32, device=x.device)
+            _native.check(lib.mvsn_groupnorm_finalize(_native.ptr(partials), n, partials.shape[1],
+                                                      _native.ptr(stats), _native.stream()),
+                          "mvsn_groupnorm_finalize")
+        return out, stats
+
+    def gn_lrelu(self, r: torch.Tensor, stats: torch.Tensor, norm: _Norm, residual: Optional[torch.Tensor] = None,
+                 out: Optional[torch.Tensor] = None):
+        n = r.shape[0]
+        spatial = r[0, 0].numel()
+        out = torch.empty_like(r) if out is None else out
+        _native.check(self.lib.mvsn_groupnorm_lrelu_apply(_native.ptr(r), _native.ptr(stats), _native.ptr(norm.gamma),
+                                                          _native.ptr(norm.beta), _native.ptr(residual), n, spatial,
+                                                          _native.ptr(out), _native.stream()),
+                      "mvsn_groupnorm_lrelu_apply")
+        return out
+
+    def feature_network(self, image: torch.Tensor) -> List[torch.Tensor]:
+        pyr = [image]
+        x = image
+        for i in range(3):
+            x, _ = self.conv(self.fe_down[i], x)
+            pyr.append(x)
+        x, _ = self.conv(self.fe_down[3], x)
+        for conv, norm in self.fe_res:
+            r, st = self.conv(conv, x, want_stats=True)
+            x = self.gn_lrelu(r, st, norm, residual=x, out=r)
+        f, _ = self.conv(self.fe_final, x)
+        pyr.append(f)
+        return pyr
+
+    def cost_volume_filter(self, cost: torch.Tensor) -> torch.Tensor:
+        x, st = self.conv(self.vf_convs[0], cost, want_stats=True)
+        for i in range(1, 4):
+            x, st = self.conv(self.vf_convs[i], x, in_stats=st, in_norm=self.vf_norms[i - 1], want_stats=True)
+        out, _ = self.conv(self.vf_convs[4], x, in_stats=st, in_norm=self.vf_norms[3])
+        return out[:, 0]
+
+    def idepth_refiner(self, level: int, guide: torch.Tensor, prior: torch.Tensor, fx: torch.Tensor) -> torch.Tensor:
+        p = self.refiners[level]
+        scale = fx.view(-1, 1, 1, 1)
+        scaled = prior * scale
+        x_in = torch.cat([guide, scaled], 1)
+        r, st = self.conv(p["conv0"], x_in, want_stats=True)
+        x = self.gn_lrelu(r, st, p["bn0"], out=r)
+        for conv, norm in p["res"]:
+            r, st = self.conv(conv, x, want_stats=True)
+            x = self.gn_lrelu(r, st, norm, residual=x, out=r)
+        delta, _ = self.conv(p["final"], x)
+        return torch.relu(scaled + delta) / scale
+
+    def homography_warp(self, image: torch.Tensor, H: torch.Tensor):
+        B, C, rows, cols = image.shape
+        n = H.shape[1]
+        vol = torch.empty((B, C, n, rows, cols), dtype=torch.float32, device=image.device)
+        mask = torch.empty((B, n, rows, cols), dtype=torch.bool, device=image.device)
+        _native.check(self.lib.mvsn_homography_warp(_native.ptr(image), _native.ptr(H), B, C, n, rows, cols,
+                                                    _native.ptr(vol), _native.ptr(mask), _native.stream()),
+                      "mvsn_homography_warp")
+        return vol, mask
+
+    def plane_sweep_setup(self, T: torch.Tensor, K0: torch.Tensor, K4: torch.Tensor, rows4: int, cols4: int, D: int):
+        N, dev = T.shape[0], T.device
+        f = dict(dtype=torch.float32, device=dev)
+        samples = torch.empty((N, D), **f)
+        H4 = torch.empty((N, D, 3, 3), **f)
+        Hinc = torch.empty((N, D, 3, 3), **f)
+        H0 = torch.empty((N, 1, 3, 3), **f)
+        base = torch.empty((N,), **f)
+        _native.check(self.lib.mvsn_plane_sweep_setup(_native.ptr(T), _native.ptr(K0), _native.ptr(K4), N, rows4,
+                                                      cols4, D, _native.ptr(samples), _native.ptr(H4),
+                                                      _native.ptr(Hinc), _native.ptr(H0), _native.ptr(base),
+                                                      _native.stream()), "mvsn_plane_sweep_setup")
+        return samples, H4, Hinc, H0, base
+
+    def incremental_cost_volume(self, src4, H4, Hinc, plane0, left_feats, want_features=False):
+        N, _, rows, cols = src4.shape
+        B = left_feats.shape[0]
+        D = H4.shape[1]
+        dev = src4.device
+        cost = torch.empty((N, 32, D, rows, cols), dtype=torch.float32, device=dev)
+        mask = torch.empty((N, D, rows, cols), dtype=torch.bool, device=dev)
+        fvol = torch.empty_like(cost) if want_features else None
+        ws_bytes = self.lib.mvsn_incremental_cost_volume_workspace_bytes(N, rows, cols)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+        _native.check(self.lib.mvsn_incremental_cost_volume(
+            _native.ptr(src4), _native.ptr(H4), _native.ptr(Hinc), _native.ptr(plane0), _native.ptr(left_feats),
+            _native.ptr(self.refiner_packed), N, B, D, rows, cols, _native.ptr(cost), _native.ptr(mask),
+            _native.ptr(fvol), _native.ptr(ws), ws_bytes, _native.stream()), "mvsn_incremental_cost_volume")
+        return cost, mask, fvol
+
+    def soft_argmin(self, cost: torch.Tensor, samples: torch.Tensor) -> torch.Tensor:
+        N, D, rows, cols = cost.shape
+        out = torch.empty((N, 1, rows, cols), dtype=torch.float32, device=cost.device)
+        _native.check(self.lib.mvsn_soft_argmin(_native.ptr(cost.contiguous()), _native.ptr(samples), N, D,
+                                                rows * cols, _native.ptr(out), _native.stream()), "mvsn_soft_argmin")
+        return out
+
+    def upsample(self, x: torch.Tensor, size) -> torch.Tensor:
+        n, c, h, w = x.shape
+        out = torch.empty((n, c, int(size[0]), int(size[1])), dtype=torch.float32, device=x.device)
+        _native.check(self.lib.mvsn_upsample_bilinear(_native.ptr(x), n, c, h, w, int(size[0]), int(size[1]),
+                                                      _native.ptr(out), _native.stream()), "mvsn_upsample_bilinear")
+        return out
+
+    def upsample_mask(self, m: torch.Tensor, size) -> torch.Tensor:
+        n, c, h, w = m.shape
+        out = torch.empty((n, c, int(size[0]), int(size[1])), dtype=torch.bool, device=m.device)
+        _native.check(self.lib.mvsn_upsample_mask(_native.ptr(m), n, c, h, w, int(size[0]), int(size[1]),
+                                                  _native.ptr(out), _native.stream()), "mvsn_upsample_mask")
+        return out
+
+    def fuse_sources(self, raw, refined, baseline, mask, S, B, alias):
+        N, D, rows, cols = mask.shape
+        dev = raw.device
+        raw_out = torch.empty((B, 1, rows, cols), dtype=torch.float32, device=dev)
+        ref_out = torch.empty((B, 1, rows, cols), dtype=torch.float32, device=dev)
+        mask_out = torch.empty((B, D, rows, cols), dtype=torch.bool, device=dev)
+        _native.check(self.lib.mvsn_fuse_sources(_native.ptr(raw), _native.ptr(refined), _native.ptr(baseline),
+                                                 _native.ptr(mask), S, B, D, rows * cols, 1 if alias else 0,
+                                                 _native.ptr(raw_out), _native.ptr(ref_out), _native.ptr(mask_out),
+                                                 _native.stream()), "mvsn_fuse_sources")
+        return raw_out, ref_out, mask_out
+
+    # ---- the forward -------------------------------------------------------------------------
+    def forward(self, left_image_pyr, K_pyr, T_right_in_lefts, right_image_pyrs, D, do_filter, do_refiners,
+                capture: Optional[dict] = None):
+        S = len(T_right_in_lefts)
+        left0 = left_image_pyr[0].contiguous().float()
+        B = left0.shape[0]
+        rows4, cols4 = left_image_pyr[-1].shape[-2:]
+
+        # 1. set-up for all N = S*B chains (chain n = s*B + b)
+        T = torch.cat([t.float() for t in T_right_in_lefts], 0).contiguous()
+        K0 = K_pyr[0].float().repeat(S, 1, 1).contiguous()
+        K4 = K_pyr[-1].float().repeat(S, 1, 1).contiguous()
+        samples, H4, Hinc, H0, baseline = self.plane_sweep_setup(T, K0, K4, rows4, cols4, D)
+
+        # 2. full-resolution source images on plane 0, 3. one extractor batch
+        src0 = torch.cat([p[0].float() for p in right_image_pyrs], 0).contiguous()
+        warped0, _ = self.homography_warp(src0, H0)
+        feats = self.feature_network(torch.cat([left0, warped0[:, :, 0]], 0))
+        left_feats = [f[:B].contiguous() for f in feats]
+        plane0 = feats[-1][B:].contiguous()
+
+        # 4. the fused chain
+        src4 = torch.cat([p[-1].float() for p in right_image_pyrs], 0).contiguous()
+        cost, mask, fvol = self.incremental_cost_volume(src4, H4, Hinc, plane0, left_feats[-1],
+                                                        want_features=capture is not None)
+        # 5. regularise + soft-argmin
+        if do_filter:
+            filtered = self.cost_volume_filter(cost)
+        else:
+            filtered = torch.linalg.vector_norm(cost, dim=1)
+        raw = self.soft_argmin(filtered, samples)
+
+        # 6. level-4 refinement per chain, then fuse the sources
+        if do_refiners[4]:
+            guide4 = torch.cat([left_image_pyr[-1].float(), left_feats[-1]], 1).repeat(S, 1, 1, 1)
+            fx4 = K_pyr[-1][:, 0, 0].float().repeat(S)
+            refined = self.idepth_refiner(4, guide4, raw, fx4)
+        else:
+            refined = None
+        raw4, idepth4, mask4 = self.fuse_sources(raw, refined, baseline, mask, S, B, alias=refined is None)
+        if capture is not None:
+            capture.update(idepth_samples=samples, H=H4, H_inc=Hinc, H_lvl0_plane0=H0, baseline=baseline,
+                           warped_fullres=warped0, left_features=left_feats, plane0_features=plane0,
+                           cost_volume=cost, mask_volume=mask, feature_volume=fvol, filtered_cost=filtered,
+                           raw_per_chain=raw)
+
+        # 7. coarse-to-fine
+        idepth = [None] * 5
+        prior = [None] * 5
+        masks = [None] * 5
+        prior[4], idepth[4], masks[4] = raw4, idepth4, mask4
+        for lvl in (3, 2, 1, 0):
+            size = left_image_pyr[lvl].shape[-2:]
+            prior[lvl] = self.upsample(idepth[lvl + 1], size)
+            masks[lvl] = self.upsample_mask(masks[lvl + 1], size)
+            if do_refiners[lvl]:
+                img = left_image_pyr[lvl].float()
+                guide = img if lvl == 0 else torch.cat([img, left_feats[lvl]], 1)
+                idepth[lvl] = self.idepth_refiner(lvl, guide.contiguous(), prior[lvl], K_pyr[lvl][:, 0, 0].float())
+            else:
+                idepth[lvl] = prior[lvl]
+        return {"left_idepthmap_pyr": idepth, "left_idepthmap_raw_pyr": prior, "left_idepthmap_mask_pyr": masks}
+
+
+class MultiViewStereoNet(nn.Module):
+    """Multi-view plane-sweep stereo network; see the module docstring for the contract."""
+
+    num_levels = 5
+
+    def __init__(self):
+        super().__init__()
+        self.min_idepth = 0.0
+        build_parameter_tree(self)
+        self._engine: Optional[PlaneSweepEngine] = None
+        self._engine_key = None
+
+    # parameters changed -> packed copies are stale
+    def _invalidate(self):
+        self._engine = None
+        self._engine_key = None
+
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        self._invalidate()
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._invalidate()
+        return out
+
+    def engine(self) -> PlaneSweepEngine:
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._engine is None or key != self._engine_key:
+            self._engine = PlaneSweepEngine(self)
+            self._engine_key = key
+        return self._engine
+
+    @torch.no_grad()
+    def forward(self, left_image_pyr: ListTensor, K_pyr: ListTensor, T_right_in_lefts: ListTensor,
+                right_image_pyrs: List[ListTensor], num_idepth_samples: int, do_cost_volume_filter: bool,
+                do_refiners: List[bool], capture: Optional[dict] = None) -> Dict[str, List[Optional[torch.Tensor]]]:
+        assert len(K_pyr) == self.num_levels
+        assert len(left_image_pyr) == self.num_levels
+        assert len(T_right_in_lefts) == len(right_image_pyrs) and len(T_right_in_lefts) >= 1
+        assert len(do_refiners) == self.num_levels
+        if not left_image_pyr[0].is_cuda:
+            raise RuntimeError("MultiViewStereoNet (MI355X build) runs on HIP devices only: move the module and "
+                               "its inputs to 'cuda'; there is no CPU implementation of the plane-sweep path")
+        if next(self.parameters()).device != left_image_pyr[0].device:
+            raise RuntimeError("module parameters and inputs are on different devices")
+        with torch.cuda.device(left_image_pyr[0].device):
+            return self.engine().forward(left_image_pyr, K_pyr, T_right_in_lefts, right_image_pyrs,
+                                         int(num_idepth_samples), bool(do_cost_volume_filter), list(do_refiners),
+                                         capture)

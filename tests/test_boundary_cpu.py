@@ -1,0 +1,116 @@
+"""CPU-side checks of the drop-in boundary: checkpoint layout, the C-ABI library and its header,
+host plumbing.  No compute calls into the library here (no GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+from multi_view_stereonet_amd import MultiViewStereoNet, _native, synthetic
+from multi_view_stereonet_amd import multi_view_stereonet_utils as snu
+from multi_view_stereonet_amd.params import parameter_shapes
+from multi_view_stereonet_amd.weights import load_weights, PRETRAINED
+
+
+def test_state_dict_layout_matches_reference_checkpoints():
+    net = MultiViewStereoNet()
+    assert net.num_levels == 5
+    sd = net.state_dict()
+    assert len(sd) == 226
+    assert sum(v.numel() for v in sd.values()) == 752742
+    for name in PRETRAINED:
+        w = load_weights(name)
+        assert set(w) == set(sd)
+        missing, unexpected = net.load_state_dict(w, strict=True)
+        assert not missing and not unexpected
+    # the source extractor shares the left extractor's storage
+    a = net.left_feature_extractor.conv0.weight
+    b = net.right_feature_extractor.feature_extractor.conv0.weight
+    assert a.data_ptr() == b.data_ptr()
+    assert len(list(net.parameters())) == 202
+
+
+def test_parameter_shapes_examples():
+    ps = parameter_shapes()
+    assert ps["right_feature_extractor.refiner.conv0.weight"] == (32, 35, 3, 3)
+    assert ps["volume_filter4.conv4.weight"] == (1, 32, 3, 3, 3)
+    assert ps["refiner0.conv0.weight"] == (32, 4, 3, 3)
+    assert ps["refiner3.conv0.weight"] == (32, 36, 3, 3)
+    assert "left_feature_extractor.conv0.bias" not in ps and "left_feature_extractor.conv_final.bias" in ps
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "mvsn_hip.h")).read()
+    declared = set(re.findall(r"\b(mvsn_[a-z0-9_]+)\s*\(", header))
+    declared -= {"mvsn_stream_t"}
+    assert declared, "no declarations parsed"
+    lib = ctypes.CDLL(_native.library_path())
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/mvsn_hip.h but not exported"
+    assert declared == set(_native.SIGNATURES), (declared ^ set(_native.SIGNATURES))
+    typed = _native.load()
+    assert typed.mvsn_abi_version() == 1
+    assert typed.mvsn_feature_refiner_packed_floats() == 9 * 9 * 128 + 2 * 9 * 8 * 128 + 7 * 32
+
+
+def test_conv_planning_is_host_side_and_validates():
+    lib = _native.load()
+    d = _native.ConvDesc(2, 32, 32, 64, 16, 32, 3, 3, 3, 1, 1)
+    assert lib.mvsn_conv_num_tiles(ctypes.byref(d)) == 32 * 2 * 1
+    assert lib.mvsn_conv_packed_floats(ctypes.byref(d)) == 4 * 27 * 256
+    bad = _native.ConvDesc(2, 32, 33, 1, 16, 32, 1, 3, 3, 1, 1)      # c_out > 32
+    assert lib.mvsn_conv_packed_floats(ctypes.byref(bad)) == 0
+    even = _native.ConvDesc(2, 32, 32, 1, 16, 32, 1, 4, 4, 1, 1)     # even kernels unsupported
+    assert lib.mvsn_conv_num_tiles(ctypes.byref(even)) == 0
+    # argument validation happens before any device work
+    rc = lib.mvsn_soft_argmin(None, None, 1, 4, 16, None, None)
+    assert rc == -1 and b"null" in lib.mvsn_last_error()
+    assert lib.mvsn_incremental_cost_volume_workspace_bytes(4, 16, 32) == 0       # LDS-resident plan
+    assert lib.mvsn_incremental_cost_volume_workspace_bytes(4, 30, 40) > 0        # global planes
+
+
+def test_forward_refuses_cpu_tensors():
+    net = MultiViewStereoNet()
+    batch = synthetic.make_batch(64, 128, 1)
+    inp = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
+    with pytest.raises(RuntimeError, match="HIP devices only"):
+        net(inp["left_image_pyr"], inp["K_pyr"], inp["T_right_in_left"], inp["right_image_pyr"], 8, True, [True] * 5)
+
+
+def test_unpack_batch_semantics():
+    batch = synthetic.make_batch(60, 90, 3, batch=2, seed=4, pose_jitter=0.2)
+    inp = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
+    sizes = [tuple(p.shape[-2:]) for p in inp["left_image_pyr"]]
+    assert sizes == [(60, 90), (30, 45), (15, 23), (8, 12), (4, 6)]
+    # first source has unit baseline after normalisation, every pose shares that scale
+    t0 = inp["T_right_in_left"][0][:, :3, 3].norm(dim=1)
+    assert torch.allclose(t0, torch.ones(2), atol=1e-6)
+    raw1 = batch["T_right_in_left"][1].squeeze(1)[:, :3, 3]
+    assert torch.allclose(inp["T_right_in_left"][1][:, :3, 3], raw1 / inp["baseline"][:, None], atol=1e-6)
+    for T, Tinv in zip(inp["T_right_in_left"], inp["T_left_in_right"]):
+        assert torch.allclose(T @ Tinv, torch.eye(4).expand(2, 4, 4), atol=1e-5)
+    K4 = inp["K_pyr"][4]
+    sx = 6.0 / 90.0
+    assert torch.allclose(K4[:, 0, 0], inp["K_pyr"][0][:, 0, 0] * sx)
+    assert torch.allclose(K4[:, 0, 2], sx * (inp["K_pyr"][0][:, 0, 2] + 0.5) - 0.5)
+    # the caller's batch is not modified
+    assert batch["T_right_in_left"][0].shape == (2, 1, 4, 4)
+
+
+def test_multi_view_forward_wrapper_passes_params():
+    seen = {}
+
+    def fake(lp, kp, ts, rp, D, flt, refs):
+        seen.update(D=D, flt=flt, refs=refs)
+        z = [torch.zeros(1)] * 5
+        return {"left_idepthmap_pyr": z, "left_idepthmap_raw_pyr": z, "left_idepthmap_mask_pyr": z}
+
+    batch = synthetic.make_batch(32, 64, 1)
+    inp = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
+    out = snu.multi_view_forward(fake, inp, {"num_idepth_samples": 12})        # DeMoN yaml lacks the flags
+    assert seen == {"D": 12, "flt": True, "refs": [True] * 5} and out["stereo_time_ms"] >= 0.0
+    snu.multi_view_forward(fake, inp, {"num_idepth_samples": 7, "cost_volume_filter": False,
+                                       "refiners": [False, True, True, True, False]})
+    assert seen == {"D": 7, "flt": False, "refs": [False, True, True, True, False]}

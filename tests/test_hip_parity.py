@@ -1,0 +1,348 @@
+"""GPU parity: every entry point of libmvsn_hip.so against the CPU oracle on the same seeded inputs,
+and the whole forward against the reference-generated golden fixtures.
+
+Tolerances (fp32 path; the reference's own MKLDNN on/off spread is ~6e-6 max-rel):
+  single ops        rtol 1e-4 / atol 1e-5, masks bit-exact
+  chain (63 steps)  mean-rel 1e-4, max-rel (vs max |ref|) 2e-3
+  final idepth      mean-rel <= 1e-3 (the north-star contract), checked at 2e-4
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, t, unpack_mask, batch_from_meta, rel_err
+from multi_view_stereonet_amd import MultiViewStereoNet, _native, synthetic
+from multi_view_stereonet_amd import multi_view_stereonet_utils as snu
+from multi_view_stereonet_amd.weights import load_weights, default_init_weights
+from oracle import mvsn_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+DEV = "cuda"
+_NETS = {}
+
+
+def net_for(wname):
+    if wname not in _NETS:
+        net = MultiViewStereoNet()
+        net.load_state_dict(load_weights(wname) if wname else default_init_weights(0), strict=True)
+        _NETS[wname] = net.to(DEV).eval()
+    return _NETS[wname]
+
+
+def to_dev(inp):
+    mv = lambda x: x.to(DEV)
+    return ([mv(x) for x in inp["left_image_pyr"]], [mv(x) for x in inp["K_pyr"]],
+            [mv(x) for x in inp["T_right_in_left"]], [[mv(x) for x in p] for p in inp["right_image_pyr"]])
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    a, b = a.detach().cpu().double(), torch.as_tensor(b).double()
+    ok = torch.allclose(a, b, rtol=rtol, atol=atol)
+    assert ok, f"max abs diff {(a - b).abs().max().item():.3e} (ref max {b.abs().max().item():.3e})"
+
+
+# ------------------------------------------------------------------------------------------
+def test_mfma_fragment_mapping():
+    lib = _native.load()
+    assert lib.mvsn_selftest_mfma(_native.stream()) == 0, lib.mvsn_last_error()
+
+
+@pytest.mark.parametrize("rows,cols,S,B,D", [(64, 128, 1, 1, 16), (256, 512, 2, 2, 64), (480, 640, 1, 1, 96),
+                                              (80, 96, 2, 3, 8)])
+def test_plane_sweep_setup(rows, cols, S, B, D):
+    eng = net_for("gta_sfm_150epochs").engine()
+    batch = synthetic.make_batch(rows, cols, S, batch=B, seed=3, pose_jitter=0.3)
+    inp = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
+    r4, c4 = inp["left_image_pyr"][4].shape[-2:]
+    T = torch.cat(inp["T_right_in_left"], 0)
+    K0, K4 = inp["K_pyr"][0].repeat(S, 1, 1), inp["K_pyr"][4].repeat(S, 1, 1)
+    samples, H4, Hinc, H0, base = eng.plane_sweep_setup(T.to(DEV), K0.to(DEV), K4.to(DEV), r4, c4, D)
+    # oracle: renormalise per source, then the reference pipeline
+    Tn = T.clone()
+    b = Tn[:, :3, 3].pow(2).sum(1).sqrt()
+    Tn[:, :3, 3] /= b[:, None]
+    close(base, b, rtol=1e-6, atol=0)
+    s_ref = oracle.idepth_samples(Tn, K4, r4, c4, D)
+    close(samples, s_ref, rtol=2e-5, atol=1e-7)
+    close(H4, oracle.plane_sweep_homographies(Tn, K4, s_ref), rtol=1e-4, atol=2e-5)
+    close(H0[:, 0], oracle.plane_sweep_homographies(Tn, K0, s_ref[:, :1])[:, 0], rtol=1e-4, atol=1e-4)
+    H64 = H4.cpu().double()
+    inc_ref = torch.linalg.inv(H64[:, :-1]) @ H64[:, 1:]
+    close(Hinc[:, 1:], inc_ref, rtol=1e-5, atol=1e-6)
+    close(Hinc[:, 0], torch.eye(3).expand(S * B, 3, 3), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("B,C,n,rows,cols", [(2, 3, 1, 64, 128), (1, 3, 16, 4, 8), (2, 32, 3, 16, 32),
+                                              (1, 5, 4, 7, 9), (1, 3, 1, 256, 512)])
+def test_homography_warp(B, C, n, rows, cols):
+    eng = net_for("gta_sfm_150epochs").engine()
+    g = torch.Generator().manual_seed(rows * cols + n)
+    img = torch.rand(B, C, rows, cols, generator=g) * 2 - 1
+    H = torch.eye(3).repeat(B, n, 1, 1) + 0.04 * (torch.rand(B, n, 3, 3, generator=g) - 0.5)
+    H[..., 0, 2] += (torch.rand(B, n, generator=g) - 0.5) * cols * 0.5
+    H[..., 1, 2] += (torch.rand(B, n, generator=g) - 0.5) * rows * 0.5
+    H[..., 2, :2] *= 0.02
+    vol, mask = eng.homography_warp(img.to(DEV), H.to(DEV))
+    vref, mref = oracle.homography_warp(img, H)
+    mism = int((mask.cpu() != mref).sum())
+    assert mism <= max(1, mref.numel() // 20000), f"{mism} mask voxels differ"
+    agree = (mask.cpu() == mref)[:, None].expand_as(vref)
+    close(vol.cpu()[agree], vref[agree], rtol=1e-4, atol=2e-5)
+
+
+def test_homography_warp_golden_units():
+    fix = load_golden("g4_units.npz")
+    eng = net_for("gta_sfm_150epochs").engine()
+    vol, mask = eng.homography_warp(t(fix["psw_image"]).to(DEV), t(fix["psw_H"]).to(DEV))
+    assert torch.equal(mask.cpu(), t(fix["psw_mask"])[:, 0])
+    close(vol, fix["psw_volume"], rtol=1e-5, atol=2e-6)
+    img, H = t(fix["hip_image"]), t(fix["hip_H"])
+    vol, mask = eng.homography_warp(img.to(DEV), H[:, None].contiguous().to(DEV))
+    ref_mask = t(fix["hip_mask"])[:, 0]
+    assert torch.equal(mask.cpu()[:, 0], ref_mask)
+    close(vol[:, :, 0], t(fix["hip_pred"]) * (~ref_mask).float()[:, None], rtol=1e-5, atol=2e-6)
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, dil, rows, cols, n
+    (32, 32, 3, 1, 1, 16, 32, 2), (32, 32, 3, 1, 2, 20, 24, 1), (32, 32, 3, 1, 4, 33, 47, 1),
+    (32, 32, 3, 1, 8, 64, 96, 1), (3, 32, 5, 2, 1, 64, 128, 2), (32, 32, 5, 2, 1, 30, 45, 1),
+    (32, 32, 5, 2, 1, 15, 23, 1), (36, 32, 3, 1, 1, 8, 12, 2), (4, 32, 3, 1, 1, 40, 70, 1),
+    (35, 32, 3, 1, 1, 4, 8, 1), (32, 1, 3, 1, 1, 16, 32, 2), (32, 1, 3, 1, 1, 9, 5, 1),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,dil,rows,cols,n", CONV_CASES)
+def test_conv2d(cin, cout, k, stride, dil, rows, cols, n):
+    from multi_view_stereonet_amd.multi_view_stereonet import _Conv, _Norm
+    eng = net_for("gta_sfm_150epochs").engine()
+    g = torch.Generator().manual_seed(cin * 1000 + rows)
+    w = torch.randn(cout, cin, k, k, generator=g) * 0.1
+    b = torch.randn(cout, generator=g) * 0.1
+    x = torch.randn(n, cin, rows, cols, generator=g)
+    c = _Conv(eng.lib, w.to(DEV), b.to(DEV), stride=stride, dilation=dil)
+    out, stats = eng.conv(c, x.to(DEV), want_stats=(cout == 32))
+    ref = F.conv2d(x, w, b, stride=stride, padding=dil * (k // 2), dilation=dil)
+    close(out, ref, rtol=1e-4, atol=1e-4)
+    if cout == 32:
+        rg = ref.reshape(n, 4, -1).double()
+        close(stats[:, :, 0], rg.mean(2), rtol=1e-4, atol=1e-5)
+        close(stats[:, :, 1], 1.0 / (rg.var(2, unbiased=False) + 1e-5).sqrt(), rtol=1e-4, atol=1e-5)
+        # fused GroupNorm + LeakyReLU (+ residual)
+        gamma, beta = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.1
+
+        class P:  # parameter holder
+            weight, bias = gamma.to(DEV), beta.to(DEV)
+        y = eng.gn_lrelu(out, stats, _Norm(P))
+        yref = F.leaky_relu(F.group_norm(ref, 4, gamma, beta, 1e-5), 0.2)
+        close(y, yref, rtol=1e-4, atol=1e-4)
+        y2 = eng.gn_lrelu(out, stats, _Norm(P), residual=out)
+        close(y2, yref + ref, rtol=1e-4, atol=2e-4)
+
+
+def test_conv_with_folded_groupnorm_input():
+    from multi_view_stereonet_amd.multi_view_stereonet import _Conv, _Norm
+    eng = net_for("gta_sfm_150epochs").engine()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 32, 6, 10, 14, generator=g) * 2 + 0.5
+    w1 = torch.randn(32, 32, 3, 3, 3, generator=g) * 0.05
+    b1 = torch.randn(32, generator=g) * 0.1
+    gamma, beta = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.1
+    w2 = torch.randn(32, 32, 3, 3, 3, generator=g) * 0.05
+    b2 = torch.randn(32, generator=g) * 0.1
+
+    class P:
+        weight, bias = gamma.to(DEV), beta.to(DEV)
+    c1 = _Conv(eng.lib, w1.to(DEV), b1.to(DEV))
+    c2 = _Conv(eng.lib, w2.to(DEV), b2.to(DEV))
+    r1, st = eng.conv(c1, x.to(DEV), want_stats=True)
+    r2, _ = eng.conv(c2, r1, in_stats=st, in_norm=_Norm(P))
+    ref1 = F.conv3d(x, w1, b1, padding=1)
+    close(r1, ref1, rtol=1e-4, atol=1e-4)
+    ref2 = F.conv3d(F.leaky_relu(F.group_norm(ref1, 4, gamma, beta, 1e-5), 0.2), w2, b2, padding=1)
+    close(r2, ref2, rtol=1e-4, atol=2e-4)
+
+
+def test_cost_volume_filter_and_soft_argmin_golden_unit():
+    fix = load_golden("g4_units.npz")
+    eng = net_for("gta_sfm_150epochs").engine()
+    out = eng.cost_volume_filter(t(fix["cvf_in"]).to(DEV))
+    close(out, fix["cvf_out"], rtol=1e-4, atol=2e-5)
+    raw = eng.soft_argmin(out, t(fix["sm_idepth"]).to(DEV))
+    close(raw, fix["sm_out"], rtol=1e-4, atol=1e-5)
+    # constant cost -> mean of the samples
+    samples = torch.linspace(0, 1.7, 9)[None].to(DEV)
+    flat = eng.soft_argmin(torch.full((1, 9, 2, 2), 3.0, device=DEV), samples)
+    close(flat, samples.mean().cpu().expand(1, 1, 2, 2), rtol=1e-6, atol=1e-6)
+
+
+def test_idepth_refiner_golden_units():
+    fix = load_golden("g4_units.npz")
+    eng = net_for("gta_sfm_150epochs").engine()
+    ones = torch.ones(2, device=DEV)
+    for lvl in (1, 0):
+        out = eng.idepth_refiner(lvl, t(fix[f"idr{lvl}_guide"]).to(DEV), t(fix[f"idr{lvl}_prior"]).to(DEV), ones)
+        close(out, fix[f"idr{lvl}_out"], rtol=1e-4, atol=2e-4)
+
+
+def test_upsamplers_golden_units():
+    fix = load_golden("g4_units.npz")
+    eng = net_for("gta_sfm_150epochs").engine()
+    assert torch.equal(eng.upsample_mask(t(fix["mu_in"]).to(DEV), (15, 30)).cpu(), t(fix["mu_out"]))
+    close(eng.upsample(t(fix["up_in"]).to(DEV), (15, 30)), fix["up_out"], rtol=1e-6, atol=1e-6)
+    g = torch.Generator().manual_seed(8)
+    m = torch.rand(1, 64, 16, 32, generator=g) > 0.45
+    assert torch.equal(eng.upsample_mask(m.to(DEV), (32, 64)).cpu(), oracle.upsample_mask(m, (32, 64)))
+
+
+@pytest.mark.parametrize("rows,cols,D,S,B,wname", [(64, 128, 16, 1, 1, "gta_sfm_150epochs"),
+                                                   (256, 512, 64, 2, 1, "gta_sfm_150epochs"),
+                                                   (80, 96, 8, 2, 2, "gta_sfm_150epochs"),
+                                                   (480, 640, 12, 1, 1, "demon_45epochs")])
+def test_incremental_chain_vs_oracle(rows, cols, D, S, B, wname):
+    """The fused chain (features, cost, mask) against the oracle's step-by-step recurrence, fed
+    with the SAME plane-0 features and homographies so only the chain itself is compared."""
+    w = load_weights(wname)
+    eng = net_for(wname).engine()
+    batch = synthetic.make_batch(rows, cols, S, batch=B, seed=11, pose_jitter=0.2)
+    inp = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
+    r4, c4 = inp["left_image_pyr"][4].shape[-2:]
+    g = torch.Generator().manual_seed(2)
+    FL = torch.randn(B, 32, r4, c4, generator=g)
+    for s in range(S):
+        T = inp["T_right_in_left"][s].clone()
+        T[:, :3, 3] /= T[:, :3, 3].pow(2).sum(1).sqrt()[:, None]
+        samples = oracle.idepth_samples(T, inp["K_pyr"][4], r4, c4, D)
+        H = oracle.plane_sweep_homographies(T, inp["K_pyr"][4], samples)
+        Hinc = torch.eye(3).repeat(B, D, 1, 1)
+        Hinc[:, 1:] = torch.linalg.inv(H[:, :-1]) @ H[:, 1:]
+        F0 = torch.randn(B, 32, r4, c4, generator=g)
+        src4 = inp["right_image_pyr"][s][4]
+        # oracle recurrence
+        image_vol, mask_ref = oracle.homography_warp(src4, H)
+        planes = [F0]
+        for d in range(1, D):
+            moved, _ = oracle.homography_warp(planes[-1], Hinc[:, d:d + 1])
+            planes.append(oracle.feature_refiner(w, "right_feature_extractor.refiner", image_vol[:, :, d], moved[:, :, 0]))
+        fvol_ref = torch.stack(planes, 2) * (~mask_ref).float()[:, None]
+        cost_ref = (~mask_ref).float()[:, None] * (FL[:, :, None] - fvol_ref).abs()
+        cost, mask, fvol = eng.incremental_cost_volume(src4.to(DEV), H.to(DEV), Hinc.to(DEV), F0.to(DEV), FL.to(DEV),
+                                                       want_features=True)
+        assert int((mask.cpu() != mask_ref).sum()) == 0
+        for name, a, b in (("features", fvol, fvol_ref), ("cost", cost, cost_ref)):
+            mean_rel, max_rel = rel_err(a.cpu(), b)
+            assert mean_rel < 1e-4 and max_rel < 2e-3, (name, s, mean_rel, max_rel)
+
+
+def _forward(net, fix, smooth=False, **kw):
+    batch, D = batch_from_meta(fix["meta"], fix.get("jitter", 0.0), smooth)
+    inp = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
+    lp, kp, ts, rp = to_dev(inp)
+    return net(lp, kp, ts, rp, D, kw.get("flt", True), kw.get("refs", [True] * 5), capture=kw.get("capture"))
+
+
+@pytest.mark.parametrize("name,wname", [("g1_gta_128x64_d16_s1.npz", "gta_sfm_150epochs"),
+                                        ("g1_init_128x64_d16_s1.npz", None),
+                                        ("g1b_gta_96x80_d8_s2_b2.npz", "gta_sfm_150epochs")])
+def test_forward_full_capture_golden(name, wname):
+    """Config 1 (and a batch-2 / two-source variant): every named intermediate of the reference."""
+    fix = load_golden(name)
+    cap = {}
+    out = _forward(net_for(wname), fix, capture=cap)
+    S, B = int(fix["meta"][3]), int(fix["meta"][4])
+    for s in range(S):
+        sl = slice(s * B, (s + 1) * B)
+        close(cap["idepth_samples"][sl], fix[f"idepth_samples_{s}"], rtol=2e-5, atol=1e-7)
+        close(cap["H"][sl], fix[f"H_{s}"], rtol=1e-4, atol=2e-5)
+        close(cap["plane0_features"][sl], fix[f"plane0_features_{s}"], rtol=1e-3, atol=2e-5)
+        assert int((cap["mask_volume"][sl].cpu() != t(fix[f"mask_volume_{s}"])).sum()) == 0
+        for key in ("feature_volume", "cost_volume", "filtered_cost"):
+            mean_rel, max_rel = rel_err(cap[key][sl].cpu(), fix[f"{key}_{s}"])
+            assert mean_rel < 2e-4 and max_rel < 3e-3, (key, s, mean_rel, max_rel)
+    close(cap["warped_fullres"][:B], fix["warped_fullres_0"], rtol=1e-4, atol=2e-5)
+    for lvl in range(1, 5):
+        close(cap["left_features"][lvl], fix[f"left_feat_{lvl}"], rtol=1e-3, atol=2e-5)
+    for lvl in range(5):
+        for kind, key in (("idepth", "left_idepthmap_pyr"), ("raw", "left_idepthmap_raw_pyr")):
+            mean_rel, max_rel = rel_err(out[key][lvl].cpu(), fix[f"{kind}_{lvl}"])
+            assert mean_rel < 2e-4 and max_rel < 2e-3, (kind, lvl, mean_rel, max_rel)
+        m = out["left_idepthmap_mask_pyr"][lvl]
+        assert m.dtype == torch.bool and np.array_equal(m.cpu().numpy(), unpack_mask(fix, lvl))
+
+
+@pytest.mark.parametrize("name,wname,smooth", [("g2_gta_512x256_d64_s2.npz", "gta_sfm_150epochs", False),
+                                               ("g2s_gta_512x256_d64_s2.npz", "gta_sfm_150epochs", True),
+                                               ("g3_demon_640x480_d96_s1.npz", "demon_45epochs", False)])
+def test_forward_headline_golden(name, wname, smooth):
+    """BASELINE configs 2-4 shapes with pretrained weights: final depth within the 1e-3 contract."""
+    fix = load_golden(name)
+    cap = {}
+    out = _forward(net_for(wname), fix, smooth=smooth, capture=cap)
+    S = int(fix["meta"][3])
+    for s in range(S):
+        close(cap["idepth_samples"][s:s + 1], fix[f"idepth_samples_{s}"], rtol=2e-5, atol=1e-7)
+        assert abs(int(cap["mask_volume"][s].sum()) - int(fix[f"mask_volume_count_{s}"])) <= 2
+        mean_rel, _ = rel_err(cap["feature_volume"][s:s + 1, :, -1].cpu(), fix[f"feature_volume_last_plane_{s}"])
+        assert mean_rel < 3e-4, ("last plane", s, mean_rel)
+        mean_rel, _ = rel_err(cap["filtered_cost"][s:s + 1].cpu(), fix[f"filtered_cost_{s}"])
+        assert mean_rel < 3e-4, ("filtered", s, mean_rel)
+    l1 = (out["left_idepthmap_pyr"][0].cpu() - t(fix["idepth_0"])).abs().mean().item()
+    mean_rel, max_rel = rel_err(out["left_idepthmap_pyr"][0].cpu(), fix["idepth_0"])
+    print(f"{name}: L1 {l1:.3e} mean-rel {mean_rel:.3e} max-rel {max_rel:.3e}")
+    assert mean_rel < 2e-4 and max_rel < 1e-3
+    mean_rel, max_rel = rel_err(out["left_idepthmap_pyr"][4].cpu(), fix["idepth_4"])
+    assert mean_rel < 2e-4 and max_rel < 1e-3
+    for lvl in range(5):
+        assert abs(int(out["left_idepthmap_mask_pyr"][lvl].sum()) - int(fix[f"mask_count_{lvl}"])) <= 2 * 4 ** (4 - lvl)
+
+
+def test_forward_flag_variants_golden():
+    fix = load_golden("g6_flags_128x64.npz")
+    net = net_for("gta_sfm_150epochs")
+    variants = {"nofilter": (False, [True] * 5),
+                "norefine4": (True, [True, True, True, True, False]),
+                "norefine_all": (True, [False] * 5),
+                "norefine_0_2": (True, [False, True, False, True, True])}
+    for key, (flt, refs) in variants.items():
+        out = _forward(net, fix, flt=flt, refs=refs)
+        for lvl in (0, 4):
+            for kind, okey in (("idepth", "left_idepthmap_pyr"), ("raw", "left_idepthmap_raw_pyr")):
+                mean_rel, max_rel = rel_err(out[okey][lvl].cpu(), fix[f"{key}:{kind}_{lvl}"])
+                assert mean_rel < 2e-4 and max_rel < 2e-3, (key, kind, lvl, mean_rel, max_rel)
+
+
+def test_forward_batch_independence_and_determinism():
+    """Images are independent units: a batch of 3 equals three batches of 1, bit for
+    bit except GroupNorm partial-combination order (none here: same tiles), and reruns agree."""
+    net = net_for("gta_sfm_150epochs")
+    batch = synthetic.make_batch(128, 256, 2, batch=3, seed=21, pose_jitter=0.2)
+    inp = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
+    lp, kp, ts, rp = to_dev(inp)
+    full = net(lp, kp, ts, rp, 24, True, [True] * 5)
+    again = net(lp, kp, ts, rp, 24, True, [True] * 5)
+    assert torch.equal(full["left_idepthmap_pyr"][0], again["left_idepthmap_pyr"][0])
+    for b in range(3):
+        one = net([x[b:b + 1] for x in lp], [x[b:b + 1] for x in kp], [x[b:b + 1] for x in ts],
+                  [[x[b:b + 1] for x in p] for p in rp], 24, True, [True] * 5)
+        close(one["left_idepthmap_pyr"][0], full["left_idepthmap_pyr"][0][b:b + 1].cpu(), rtol=1e-5, atol=1e-6)
+        assert torch.equal(one["left_idepthmap_mask_pyr"][0], full["left_idepthmap_mask_pyr"][0][b:b + 1])
+
+
+def test_forward_vs_oracle_small_batch():
+    """Fresh seeds (no fixture): HIP forward vs the oracle run here on the host."""
+    wname = "gta_sfm_150epochs"
+    w = load_weights(wname)
+    batch = synthetic.make_batch(96, 160, 3, batch=2, seed=33, pose_jitter=0.25, smooth=True)
+    inp = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
+    ref = oracle.forward(w, inp["left_image_pyr"], inp["K_pyr"], inp["T_right_in_left"], inp["right_image_pyr"], 20)
+    lp, kp, ts, rp = to_dev(inp)
+    out = net_for(wname)(lp, kp, ts, rp, 20, True, [True] * 5)
+    for lvl in range(5):
+        mean_rel, max_rel = rel_err(out["left_idepthmap_pyr"][lvl].cpu(), ref["left_idepthmap_pyr"][lvl])
+        assert mean_rel < 2e-4 and max_rel < 2e-3, (lvl, mean_rel, max_rel)
+        diff = int((out["left_idepthmap_mask_pyr"][lvl].cpu() != ref["left_idepthmap_mask_pyr"][lvl]).sum())
+        assert diff <= 2 * 4 ** (4 - lvl), (lvl, diff)
