@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""depthmaps/sec of the MI355X plane-sweep forward at 512x256, 64 hypotheses, 2 source views.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one MultiViewStereoNet.forward() over a batch of B synthetic reference images (each
+with 2 source views) already resident in HBM; every rank runs its own B images (weak scaling,
+images are independent -- SURVEY 8e) and the ranks all-gather one metric row per image at the end.
+Rank 0 prints ONE JSON line.  At N=1 it also reports
+  roofline      the dominant kernel's algorithmic flops / measured launch time (device events on the
+                stream the kernels run on) against the fp32 MFMA peak, plus the fused chain kernel
+                against both peaks,
+  cpu_baseline  the CPU oracle (the build's restatement of the reference forward) timed on the host,
+  l1_vs_ref     L1 / relative error of image 0 against the reference-generated golden depth map.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from multi_view_stereonet_amd import MultiViewStereoNet, synthetic  # noqa: E402
+from multi_view_stereonet_amd import multi_view_stereonet_utils as snu  # noqa: E402
+from multi_view_stereonet_amd import distributed as mdist  # noqa: E402
+from multi_view_stereonet_amd.weights import load_weights  # noqa: E402
+
+ROWS, COLS, D, S = 256, 512, 64, 2
+WEIGHTS = "gta_sfm_150epochs"
+GOLDEN = os.path.join(ROOT, "tests", "golden", "g2_gta_512x256_d64_s2.npz")
+GOLDEN_SEED = 7
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def make_inputs(batch, first_seed, device):
+    """B independent (image, 2 sources) sets; set i uses seed first_seed+i, so image 0 of rank 0 is
+    the golden fixture's input."""
+    parts = [synthetic.make_batch(ROWS, COLS, S, batch=1, seed=first_seed + i) for i in range(batch)]
+    merged = {"left_image": torch.cat([p["left_image"] for p in parts], 0),
+              "right_image": [torch.cat([p["right_image"][s] for p in parts], 0) for s in range(S)],
+              "K": torch.cat([p["K"] for p in parts], 0),
+              "T_right_in_left": [torch.cat([p["T_right_in_left"][s] for p in parts], 0) for s in range(S)]}
+    return merged, snu.multi_view_unpack_batch(merged, device, 5)
+
+
+def run_forward(net, inp):
+    return net(inp["left_image_pyr"], inp["K_pyr"], inp["T_right_in_left"], inp["right_image_pyr"], D, True,
+               [True] * 5)
+
+
+def kernel_breakdown(net, inp):
+    """One instrumented forward: per-kernel launch counts, device time, algorithmic flops/bytes."""
+    eng = net.engine()
+    eng.timeline = []
+    run_forward(net, inp)
+    torch.cuda.synchronize()
+    tl, eng.timeline = eng.timeline, None
+    agg = {}
+    for name, a, b, flops, nbytes in tl:
+        e = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        e["launches"] += 1
+        e["ms"] += a.elapsed_time(b)
+        e["flops"] += flops
+        e["bytes"] += nbytes
+    return agg
+
+
+def cpu_baseline(budget_s=20.0):
+    """The oracle (CPU restatement of the reference forward) on the host cores, B=1, same workload."""
+    from oracle import mvsn_oracle as oracle
+    w = load_weights(WEIGHTS)
+    batch = synthetic.make_batch(ROWS, COLS, S, batch=1, seed=GOLDEN_SEED)
+    inp = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+
+    def once():
+        t0 = time.time()
+        out = oracle.forward(w, inp["left_image_pyr"], inp["K_pyr"], inp["T_right_in_left"], inp["right_image_pyr"], D)
+        return time.time() - t0, out
+
+    once()  # warm-up
+    times, t_start = [], time.time()
+    while len(times) < 3 or (time.time() - t_start < budget_s and len(times) < 50):
+        dt, out = once()
+        times.append(dt)
+    mean = sum(times) / len(times)
+    return {"value": 1.0 / mean, "unit": "depthmaps/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times)} forwards of 1 image (512x256, D=64, S=2, fp32, torch CPU, "
+                      f"{threads} threads of {cores} host cpus), mean {mean * 1e3:.1f} ms"}, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("MVSN_BENCH_BATCH", "32")),
+                    help="reference images per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = mdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.set_grad_enabled(False)
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    net = MultiViewStereoNet()
+    net.load_state_dict(load_weights(WEIGHTS), strict=True)
+    net = net.to(dev).eval()
+    B = args.batch
+    _, inp = make_inputs(B, GOLDEN_SEED + rank * B, dev)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        out = run_forward(net, inp)
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = run_forward(net, inp)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # per-image metric rows, all-gathered (the path's only exchange step)
+    idepth = out["left_idepthmap_pyr"][0]
+    rows = torch.stack([idepth.mean(dim=(1, 2, 3)), (idepth > 0).float().mean(dim=(1, 2, 3)),
+                        out["left_idepthmap_mask_pyr"][0].float().mean(dim=(1, 2, 3))], 1)
+    idx = torch.arange(rank * B, (rank + 1) * B, device=dev)
+    all_rows, all_idx = mdist.gather_metric_rows(rows, idx)
+    assert all_rows.shape[0] == B * world and bool(torch.isfinite(all_rows).all())
+
+    if rank == 0:
+        line = {"metric": "depthmaps/sec at 512x256, 64 hypotheses, 2 src views; L1 vs ref",
+                "value": B * world * args.steps / elapsed, "unit": "depthmaps/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic (seeded uniform frames, pretrained gta_sfm_150epochs weights)",
+                "config": {"workload": "GTA-SfM-shaped 512x256, D=64 hypotheses, 2 source views, "
+                                       "cost-volume filter + 5 refiners", "images_per_gpu_per_step": B,
+                           "global_batch": B * world, "parallelism": f"dp{world} (independent images, "
+                                                                      "all-gather of metric rows)"},
+                "mean_idepth": float(mdist.average_rows(all_rows)[0])}
+        if world == 1:
+            import numpy as np
+            gold = np.load(GOLDEN)
+            ref0 = torch.from_numpy(gold["idepth_0"])
+            got0 = idepth[:1].cpu()
+            l1 = float((got0 - ref0).abs().mean())
+            line["l1_vs_ref"] = {"l1": l1, "mean_rel": l1 / float(ref0.abs().mean()),
+                                 "max_rel": float((got0 - ref0).abs().max() / ref0.abs().max()),
+                                 "reference": "tests/golden/g2_gta_512x256_d64_s2.npz (reference PyTorch-CPU forward)"}
+            agg = kernel_breakdown(net, inp)
+            total_ms = sum(e["ms"] for e in agg.values())
+            name, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+            per_launch_ms = dom["ms"] / dom["launches"]
+            tfl = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12
+            line["roofline"] = {"kernel": name, "bound": "mfma", "achieved": tfl, "peak": PEAK_FP32_MFMA_TFLOPS,
+                                "unit": "TFLOP/s", "frac": tfl / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                                "launches_per_step": dom["launches"], "avg_launch_ms": per_launch_ms,
+                                "share_of_step": dom["ms"] / total_ms}
+            ch = agg.get("mvsn_incremental_cost_volume")
+            if ch:
+                sec = ch["ms"] * 1e-3
+                line["chain_kernel"] = {"kernel": "mvsn_incremental_cost_volume (warp + refine + cost volume, fused)",
+                                        "avg_launch_ms": ch["ms"] / ch["launches"],
+                                        "algorithmic_GBps": ch["bytes"] / sec / 1e9,
+                                        "frac_of_hbm_peak": ch["bytes"] / sec / 1e9 / PEAK_HBM_GBS,
+                                        "algorithmic_TFLOPs": ch["flops"] / sec / 1e12,
+                                        "frac_of_fp32_mfma_peak": ch["flops"] / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                        "share_of_step": ch["ms"] / total_ms}
+            line["kernel_ms_per_step"] = {k: round(v["ms"], 3) for k, v in
+                                          sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]}
+            if not args.no_cpu_baseline:
+                cb, ref_out = cpu_baseline()
+                line["cpu_baseline"] = cb
+                o0 = ref_out["left_idepthmap_pyr"][0]
+                line["l1_vs_oracle"] = float((got0 - o0).abs().mean())
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -70,6 +70,9 @@ class PlaneSweepEngine:
 
     def __init__(self, net: "MultiViewStereoNet"):
         self.lib = lib = _native.load()
+        # When set to a list, every library call is bracketed by device events on the current
+        # stream and appended as (kernel, start, end, algorithmic_flops, algorithmic_bytes).
+        self.timeline: Optional[list] = None
         fe = net.left_feature_extractor
         self.fe_down = [_Conv(lib, getattr(fe, f"conv{i}").weight, None, stride=2) for i in range(4)]
         self.fe_res = [(_Conv(lib, getattr(fe, f"res{i}").conv1.weight, None), _Norm(getattr(fe, f"res{i}").bn1))
@@ -102,6 +105,16 @@ class PlaneSweepEngine:
             })
 
     # ---- primitive wrappers ------------------------------------------------------------------
+    def _call(self, kernel: str, fn, *args, flops: float = 0.0, nbytes: float = 0.0):
+        if self.timeline is None:
+            _native.check(fn(*args), kernel)
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        _native.check(fn(*args), kernel)
+        b.record()
+        self.timeline.append((kernel, a, b, float(flops), float(nbytes)))
+
     def conv(self, c: _Conv, x: torch.Tensor, in_stats=None, in_norm: Optional[_Norm] = None, want_stats=False):
         """x (N,C,[D,]H,W) -> (out, stats or None).  `in_stats`/`in_norm` fold LReLU(GN(x)) into the load."""
         lib = self.lib
@@ -116,18 +129,19 @@ class PlaneSweepEngine:
         if want_stats:
             tiles = lib.mvsn_conv_num_tiles(ctypes.byref(d))
             partials = torch.empty((n, tiles, 4, 3), dtype=torch.float32, device=x.device)
-        _native.check(lib.mvsn_conv_forward(ctypes.byref(d), _native.ptr(x), _native.ptr(c.packed),
-                                            _native.ptr(c.bias), _native.ptr(in_stats),
-                                            _native.ptr(in_norm.gamma) if in_norm else None,
-                                            _native.ptr(in_norm.beta) if in_norm else None,
-                                            _native.ptr(out), _native.ptr(partials), _native.stream()),
-                      "mvsn_conv_forward")
+        taps = c.kd * c.kh * c.kw
+        tag = (f"conv{c.dims}d k{c.kh}" + (f"s{c.stride}" if c.stride > 1 else "") +
+               (f"d{c.dilation}" if c.dilation > 1 else "") + f" {c.cin}->{c.cout}")
+        self._call("mvsn_conv_forward[" + tag + "]", lib.mvsn_conv_forward, ctypes.byref(d), _native.ptr(x),
+                   _native.ptr(c.packed), _native.ptr(c.bias), _native.ptr(in_stats),
+                   _native.ptr(in_norm.gamma) if in_norm else None, _native.ptr(in_norm.beta) if in_norm else None,
+                   _native.ptr(out), _native.ptr(partials), _native.stream(),
+                   flops=2.0 * c.cin * taps * c.cout * out[:, 0].numel(), nbytes=4.0 * (x.numel() + out.numel()))
         stats = None
         if want_stats:
             stats = torch.empty((n, 4, 2), dtype=torch.float32, device=x.device)
-            _native.check(lib.mvsn_groupnorm_finalize(_native.ptr(partials), n, partials.shape[1],
-                                                      _native.ptr(stats), _native.stream()),
-                          "mvsn_groupnorm_finalize")
+            self._call("mvsn_groupnorm_finalize", lib.mvsn_groupnorm_finalize, _native.ptr(partials), n,
+                       partials.shape[1], _native.ptr(stats), _native.stream())
         return out, stats
 
     def gn_lrelu(self, r: torch.Tensor, stats: torch.Tensor, norm: _Norm, residual: Optional[torch.Tensor] = None,
@@ -135,10 +149,10 @@ class PlaneSweepEngine:
         n = r.shape[0]
         spatial = r[0, 0].numel()
         out = torch.empty_like(r) if out is None else out
-        _native.check(self.lib.mvsn_groupnorm_lrelu_apply(_native.ptr(r), _native.ptr(stats), _native.ptr(norm.gamma),
-                                                          _native.ptr(norm.beta), _native.ptr(residual), n, spatial,
-                                                          _native.ptr(out), _native.stream()),
-                      "mvsn_groupnorm_lrelu_apply")
+        self._call("mvsn_groupnorm_lrelu_apply", self.lib.mvsn_groupnorm_lrelu_apply, _native.ptr(r),
+                   _native.ptr(stats), _native.ptr(norm.gamma), _native.ptr(norm.beta), _native.ptr(residual), n,
+                   spatial, _native.ptr(out), _native.stream(),
+                   nbytes=4.0 * r.numel() * (3 if residual is not None else 2))
         return out
 
     def feature_network(self, image: torch.Tensor) -> List[torch.Tensor]:
@@ -180,9 +194,9 @@ class PlaneSweepEngine:
         n = H.shape[1]
         vol = torch.empty((B, C, n, rows, cols), dtype=torch.float32, device=image.device)
         mask = torch.empty((B, n, rows, cols), dtype=torch.bool, device=image.device)
-        _native.check(self.lib.mvsn_homography_warp(_native.ptr(image), _native.ptr(H), B, C, n, rows, cols,
-                                                    _native.ptr(vol), _native.ptr(mask), _native.stream()),
-                      "mvsn_homography_warp")
+        self._call("mvsn_homography_warp", self.lib.mvsn_homography_warp, _native.ptr(image), _native.ptr(H), B, C, n,
+                   rows, cols, _native.ptr(vol), _native.ptr(mask), _native.stream(),
+                   nbytes=4.0 * (image.numel() + vol.numel()) + mask.numel())
         return vol, mask
 
     def plane_sweep_setup(self, T: torch.Tensor, K0: torch.Tensor, K4: torch.Tensor, rows4: int, cols4: int, D: int):
@@ -193,10 +207,9 @@ class PlaneSweepEngine:
         Hinc = torch.empty((N, D, 3, 3), **f)
         H0 = torch.empty((N, 1, 3, 3), **f)
         base = torch.empty((N,), **f)
-        _native.check(self.lib.mvsn_plane_sweep_setup(_native.ptr(T), _native.ptr(K0), _native.ptr(K4), N, rows4,
-                                                      cols4, D, _native.ptr(samples), _native.ptr(H4),
-                                                      _native.ptr(Hinc), _native.ptr(H0), _native.ptr(base),
-                                                      _native.stream()), "mvsn_plane_sweep_setup")
+        self._call("mvsn_plane_sweep_setup", self.lib.mvsn_plane_sweep_setup, _native.ptr(T), _native.ptr(K0),
+                   _native.ptr(K4), N, rows4, cols4, D, _native.ptr(samples), _native.ptr(H4), _native.ptr(Hinc),
+                   _native.ptr(H0), _native.ptr(base), _native.stream())
         return samples, H4, Hinc, H0, base
 
     def incremental_cost_volume(self, src4, H4, Hinc, plane0, left_feats, want_features=False):
@@ -209,31 +222,34 @@ class PlaneSweepEngine:
         fvol = torch.empty_like(cost) if want_features else None
         ws_bytes = self.lib.mvsn_incremental_cost_volume_workspace_bytes(N, rows, cols)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
-        _native.check(self.lib.mvsn_incremental_cost_volume(
-            _native.ptr(src4), _native.ptr(H4), _native.ptr(Hinc), _native.ptr(plane0), _native.ptr(left_feats),
-            _native.ptr(self.refiner_packed), N, B, D, rows, cols, _native.ptr(cost), _native.ptr(mask),
-            _native.ptr(fvol), _native.ptr(ws), ws_bytes, _native.stream()), "mvsn_incremental_cost_volume")
+        P = rows * cols
+        self._call("mvsn_incremental_cost_volume", self.lib.mvsn_incremental_cost_volume,
+                   _native.ptr(src4), _native.ptr(H4), _native.ptr(Hinc), _native.ptr(plane0), _native.ptr(left_feats),
+                   _native.ptr(self.refiner_packed), N, B, D, rows, cols, _native.ptr(cost), _native.ptr(mask),
+                   _native.ptr(fvol), _native.ptr(ws), ws_bytes, _native.stream(),
+                   flops=N * (D - 1) * 2.0 * 9 * 32 * (35 + 32 + 32) * P,
+                   nbytes=N * (4.0 * 67 * P + 128.0 * D * P + D * P))  # Kernel A algorithmic bytes
         return cost, mask, fvol
 
     def soft_argmin(self, cost: torch.Tensor, samples: torch.Tensor) -> torch.Tensor:
         N, D, rows, cols = cost.shape
         out = torch.empty((N, 1, rows, cols), dtype=torch.float32, device=cost.device)
-        _native.check(self.lib.mvsn_soft_argmin(_native.ptr(cost.contiguous()), _native.ptr(samples), N, D,
-                                                rows * cols, _native.ptr(out), _native.stream()), "mvsn_soft_argmin")
+        self._call("mvsn_soft_argmin", self.lib.mvsn_soft_argmin, _native.ptr(cost.contiguous()), _native.ptr(samples),
+                   N, D, rows * cols, _native.ptr(out), _native.stream(), nbytes=4.0 * (cost.numel() + out.numel()))
         return out
 
     def upsample(self, x: torch.Tensor, size) -> torch.Tensor:
         n, c, h, w = x.shape
         out = torch.empty((n, c, int(size[0]), int(size[1])), dtype=torch.float32, device=x.device)
-        _native.check(self.lib.mvsn_upsample_bilinear(_native.ptr(x), n, c, h, w, int(size[0]), int(size[1]),
-                                                      _native.ptr(out), _native.stream()), "mvsn_upsample_bilinear")
+        self._call("mvsn_upsample_bilinear", self.lib.mvsn_upsample_bilinear, _native.ptr(x), n, c, h, w, int(size[0]),
+                   int(size[1]), _native.ptr(out), _native.stream(), nbytes=4.0 * (x.numel() + out.numel()))
         return out
 
     def upsample_mask(self, m: torch.Tensor, size) -> torch.Tensor:
         n, c, h, w = m.shape
         out = torch.empty((n, c, int(size[0]), int(size[1])), dtype=torch.bool, device=m.device)
-        _native.check(self.lib.mvsn_upsample_mask(_native.ptr(m), n, c, h, w, int(size[0]), int(size[1]),
-                                                  _native.ptr(out), _native.stream()), "mvsn_upsample_mask")
+        self._call("mvsn_upsample_mask", self.lib.mvsn_upsample_mask, _native.ptr(m), n, c, h, w, int(size[0]),
+                   int(size[1]), _native.ptr(out), _native.stream(), nbytes=float(m.numel() + out.numel()))
         return out
 
     def fuse_sources(self, raw, refined, baseline, mask, S, B, alias):
@@ -242,10 +258,10 @@ class PlaneSweepEngine:
         raw_out = torch.empty((B, 1, rows, cols), dtype=torch.float32, device=dev)
         ref_out = torch.empty((B, 1, rows, cols), dtype=torch.float32, device=dev)
         mask_out = torch.empty((B, D, rows, cols), dtype=torch.bool, device=dev)
-        _native.check(self.lib.mvsn_fuse_sources(_native.ptr(raw), _native.ptr(refined), _native.ptr(baseline),
-                                                 _native.ptr(mask), S, B, D, rows * cols, 1 if alias else 0,
-                                                 _native.ptr(raw_out), _native.ptr(ref_out), _native.ptr(mask_out),
-                                                 _native.stream()), "mvsn_fuse_sources")
+        self._call("mvsn_fuse_sources", self.lib.mvsn_fuse_sources, _native.ptr(raw), _native.ptr(refined),
+                   _native.ptr(baseline), _native.ptr(mask), S, B, D, rows * cols, 1 if alias else 0,
+                   _native.ptr(raw_out), _native.ptr(ref_out), _native.ptr(mask_out), _native.stream(),
+                   nbytes=float(mask.numel() + mask_out.numel()))
         return raw_out, ref_out, mask_out
 
     # ---- the forward -------------------------------------------------------------------------

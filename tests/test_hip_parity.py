@@ -91,7 +91,8 @@ def test_homography_warp(B, C, n, rows, cols):
     mism = int((mask.cpu() != mref).sum())
     assert mism <= max(1, mref.numel() // 20000), f"{mism} mask voxels differ"
     agree = (mask.cpu() == mref)[:, None].expand_as(vref)
-    close(vol.cpu()[agree], vref[agree], rtol=1e-4, atol=2e-5)
+    # white-noise frames: one ulp of a ~cols-sized coordinate times a gradient of up to 2/px
+    close(vol.cpu()[agree], vref[agree], rtol=1e-4, atol=cols * 2.0 ** -23 * 8)
 
 
 def test_homography_warp_golden_units():
@@ -258,14 +259,17 @@ def test_forward_full_capture_golden(name, wname):
         sl = slice(s * B, (s + 1) * B)
         close(cap["idepth_samples"][sl], fix[f"idepth_samples_{s}"], rtol=2e-5, atol=1e-7)
         close(cap["H"][sl], fix[f"H_{s}"], rtol=1e-4, atol=2e-5)
-        close(cap["plane0_features"][sl], fix[f"plane0_features_{s}"], rtol=1e-3, atol=2e-5)
+        mean_rel, max_rel = rel_err(cap["plane0_features"][sl].cpu(), fix[f"plane0_features_{s}"])
+        assert mean_rel < 1e-4 and max_rel < 1e-4, ("plane0", s, mean_rel, max_rel)
         assert int((cap["mask_volume"][sl].cpu() != t(fix[f"mask_volume_{s}"])).sum()) == 0
         for key in ("feature_volume", "cost_volume", "filtered_cost"):
             mean_rel, max_rel = rel_err(cap[key][sl].cpu(), fix[f"{key}_{s}"])
             assert mean_rel < 2e-4 and max_rel < 3e-3, (key, s, mean_rel, max_rel)
-    close(cap["warped_fullres"][:B], fix["warped_fullres_0"], rtol=1e-4, atol=2e-5)
+    cols = int(fix["meta"][1])
+    close(cap["warped_fullres"][:B], fix["warped_fullres_0"], rtol=1e-4, atol=cols * 2.0 ** -23 * 8)
     for lvl in range(1, 5):
-        close(cap["left_features"][lvl], fix[f"left_feat_{lvl}"], rtol=1e-3, atol=2e-5)
+        mean_rel, max_rel = rel_err(cap["left_features"][lvl].cpu(), fix[f"left_feat_{lvl}"])
+        assert mean_rel < 1e-4 and max_rel < 1e-4, ("left features", lvl, mean_rel, max_rel)
     for lvl in range(5):
         for kind, key in (("idepth", "left_idepthmap_pyr"), ("raw", "left_idepthmap_raw_pyr")):
             mean_rel, max_rel = rel_err(out[key][lvl].cpu(), fix[f"{kind}_{lvl}"])
