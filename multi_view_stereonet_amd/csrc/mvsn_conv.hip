@@ -4,12 +4,12 @@
 // Implicit GEMM with A = weights (16 couts x 4 cins per v_mfma_f32_16x16x4_f32) and
 // B = activations (4 cins x 16 consecutive output columns).  A 256-thread workgroup owns an
 // output tile of TZ x TY x 32 positions and all (<= 32) output channels; the input is walked in
-// chunks of 8 channels: the haloed chunk tile and that chunk's weight fragments are staged in
+// chunks of 4 channels: the haloed chunk tile and that chunk's weight fragments are staged in
 // LDS, then every tap is a plain offset read.  The previous layer's GroupNorm + LeakyReLU can be
 // applied while the tile is staged, and the epilogue emits per-tile GroupNorm partials
 // (count, mean, M2) so normalisation never needs its own pass over the volume.
 //
-// LDS tile: [8 ch][HZ][HY][XS], channel stride CST = 16 (mod 32) -> the 16-column x 4-channel
+// LDS tile: [4 ch][HZ][HY][XS], channel stride CST = 16 (mod 32) -> the 16-column x 4-channel
 // fragment read is bank-conflict-free at stride 1.
 #include "mvsn_common.h"
 
@@ -18,7 +18,7 @@ namespace mvsn {
 constexpr int CV_THREADS = 256;
 constexpr int CV_WAVES = 4;
 constexpr int CV_TX = 32;   // output columns per tile
-constexpr int CV_CK = 8;    // input channels per staged chunk
+constexpr int CV_CK = 4;    // input channels per staged chunk = one MFMA k-step
 constexpr float CV_EPS = 1e-5f;
 
 struct ConvGeom {
@@ -29,8 +29,9 @@ struct ConvGeom {
   int CST;              // channel stride in LDS (floats)
   int ntz, nty, ntx, tiles;
   int ntaps, nchunks;
-  int wfloats_chunk;    // ntaps * 2 ksteps * 2 cout-tiles * 64
+  int wfloats_chunk;    // ntaps * 2 cout-tiles * 64
   size_t lds_bytes;
+  int se;               // staged elements per thread per channel
 };
 
 static bool make_geom(const mvsn_conv_desc *d, ConvGeom *g) {
@@ -49,7 +50,8 @@ static bool make_geom(const mvsn_conv_desc *d, ConvGeom *g) {
   g->Wo = (d->cols - 1) / d->stride + 1;
   const bool is3d = d->depth > 1 || d->kd > 1;
   g->TZ = is3d ? 2 : 1;
-  g->TY = 8;
+  // 2-D 3x3 layers on tall images use 16-row tiles (less halo per output, more MFMAs per staging)
+  g->TY = (!is3d && d->kh == 3 && d->stride == 1 && (d->rows - 1) / d->stride + 1 > 8) ? 16 : 8;
   g->HZ = g->TZ + d->kd - 1;
   g->HY = (g->TY - 1) * d->stride + d->dilation * (d->kh - 1) + 1;
   g->HX = (CV_TX - 1) * d->stride + d->dilation * (d->kw - 1) + 1;
@@ -63,39 +65,56 @@ static bool make_geom(const mvsn_conv_desc *d, ConvGeom *g) {
   g->tiles = g->ntz * g->nty * g->ntx;
   g->ntaps = d->kd * d->kh * d->kw;
   g->nchunks = (d->c_in + CV_CK - 1) / CV_CK;
-  g->wfloats_chunk = g->ntaps * 2 * 2 * 64;
+  g->wfloats_chunk = g->ntaps * 2 * 64;
   g->lds_bytes = ((size_t)CV_CK * g->CST + g->wfloats_chunk + 64 /*in scale/shift*/ + 64 /*red*/) * sizeof(float);
+  g->se = (g->HZ * g->HY * g->HX + CV_THREADS - 1) / CV_THREADS;
+  if (g->se > 6) return false;
+  const bool k333 = d->kd == 3 && d->kh == 3 && d->kw == 3 && d->stride == 1;
+  const bool k133 = d->kd == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1;
+  const bool k155 = d->kd == 1 && d->kh == 5 && d->kw == 5 && d->stride == 2 && d->dilation == 1;
+  if (!(k333 || k133 || k155)) return false;
   return g->lds_bytes <= 160 * 1024;
 }
 
-// packed weights: [chunk][tap][kstep 2][cout-tile 2][lane 64]; lane = k*16 + i holds
-// W[cout = t*16 + i][cin = chunk*8 + ks*4 + k][tap], zero outside (c_in, c_out).
+// packed weights: [chunk of 4 cin][tap][cout-tile 2][lane 64]; lane = k*16 + i holds
+// W[cout = t*16 + i][cin = chunk*4 + k][tap], zero outside (c_in, c_out).
 __global__ void conv_pack_kernel(const float *__restrict__ w, int cin, int cout, int ntaps, int nchunks,
                                  float *__restrict__ out) {
-  const int total = nchunks * ntaps * 256;
+  const int total = nchunks * ntaps * 128;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const int lane = i & 63, t = (i >> 6) & 1, ks = (i >> 7) & 1;
-  const int tap = (i >> 8) % ntaps, chunk = (i >> 8) / ntaps;
+  const int lane = i & 63, t = (i >> 6) & 1;
+  const int tap = (i >> 7) % ntaps, chunk = (i >> 7) / ntaps;
   const int co = t * 16 + (lane & 15);
-  const int ci = chunk * CV_CK + ks * 4 + (lane >> 4);
+  const int ci = chunk * CV_CK + (lane >> 4);
   out[i] = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * ntaps + tap] : 0.0f;
 }
 
-template <int NPT>  // pixel tiles (16 columns each) per wave: TZ*TY*2/4
-__global__ __launch_bounds__(CV_THREADS) void conv_mfma_kernel(ConvGeom g, const float *__restrict__ in,
-                                                               const float *__restrict__ wpk,
-                                                               const float *__restrict__ bias,
-                                                               const float *__restrict__ in_stats,
-                                                               const float *__restrict__ in_gamma,
-                                                               const float *__restrict__ in_beta,
-                                                               float *__restrict__ out,
-                                                               float *__restrict__ out_partials) {
+// NPT   pixel tiles (16 output columns each) per wave = TZ*TY*2/4
+// KD/KH/KW/STRIDE compile-time so the tap loops unroll completely and LDS reads run ahead of the MFMAs
+// SE    staged input elements per thread per channel (upper bound, ceil(HZ*HY*HX/256))
+// CT    cout tiles (1 when c_out <= 16: the second MFMA of every pair is dropped)
+//
+// Pipeline per 4-channel chunk (one MFMA k-step per tap): the chunk's haloed tile and weight fragments are fetched from
+// HBM/L2 into registers while the MFMAs of the previous chunk run, then written to LDS between
+// two barriers (register-staged double buffering, one LDS copy).
+template <int NPT, int KD, int KH, int KW, int STRIDE, int SE, int CT>
+__global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, const float *__restrict__ in,
+                                                                  const float *__restrict__ wpk,
+                                                                  const float *__restrict__ bias,
+                                                                  const float *__restrict__ in_stats,
+                                                                  const float *__restrict__ in_gamma,
+                                                                  const float *__restrict__ in_beta,
+                                                                  float *__restrict__ out,
+                                                                  float *__restrict__ out_partials) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NTAPS = KD * KH * KW;
+  constexpr int WFL = NTAPS * 128;            // weight floats per chunk
+  constexpr int WR = (WFL / 4 + CV_THREADS - 1) / CV_THREADS;  // float4 per thread
   float *tile = smem;                               // CV_CK * CST
-  float *wl = tile + (size_t)CV_CK * g.CST;         // wfloats_chunk
-  float *scsh = wl + g.wfloats_chunk;               // 32 scale + 32 shift of the input transform
-  float *red = scsh + 64;                           // 4 waves x 4 groups x (sum | M2)
+  float *wl = tile + (size_t)CV_CK * g.CST;         // WFL
+  float *scsh = wl + WFL;                           // 32 scale + 32 shift of the input transform
+  float *red = scsh + 64;                           // 4 waves x 4 groups
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = blockIdx.y;
@@ -105,127 +124,152 @@ __global__ __launch_bounds__(CV_THREADS) void conv_mfma_kernel(ConvGeom g, const
   const int tyi = tix % g.nty;
   const int tzi = tix / g.nty;
   const int z0 = tzi * g.TZ, y0 = tyi * g.TY, x0 = txi * CV_TX;  // output-space origin
-  const int gz0 = z0 - g.pd, gy0 = y0 * g.stride - g.ph, gx0 = x0 * g.stride - g.pw;  // input-space origin
+  const int gz0 = z0 - g.pd, gy0 = y0 * STRIDE - g.ph, gx0 = x0 * STRIDE - g.pw;  // input-space origin
   const size_t in_plane = (size_t)g.H * g.W, in_chan = (size_t)g.D * in_plane;
   const float *inn = in + (size_t)n * g.cin * in_chan;
 
   // this lane's output positions
   int lpos[NPT];      // offset of (z, y, x) in the staged tile (tap (0,0,0))
-  int oz[NPT], oy[NPT], ox[NPT];
-  bool valid[NPT];
+  int opos[NPT];      // offset in the output plane, -1 when outside
 #pragma unroll
   for (int j = 0; j < NPT; ++j) {
     const int pt = wave * NPT + j;
     const int xt = pt & 1, yy = (pt >> 1) % g.TY, zz = (pt >> 1) / g.TY;
     const int xx = xt * 16 + (lane & 15);
-    oz[j] = z0 + zz, oy[j] = y0 + yy, ox[j] = x0 + xx;
-    valid[j] = oz[j] < g.Do && oy[j] < g.Ho && ox[j] < g.Wo;
-    lpos[j] = (zz * g.HY + yy * g.stride) * g.XS + xx * g.stride;
+    const int oz = z0 + zz, oy = y0 + yy, ox = x0 + xx;
+    const bool ok = oz < g.Do && oy < g.Ho && ox < g.Wo;
+    opos[j] = ok ? (oz * g.Ho + oy) * g.Wo + ox : -1;
+    lpos[j] = (zz * g.HY + yy * STRIDE) * g.XS + xx * STRIDE + (lane >> 4) * g.CST;
   }
 
-  floatx4 acc[NPT][2];
+  // staging plan: element e = tid + k*256 of the HZ x HY x HX chunk tile (same for every channel)
+  int goff[SE];
+  const int tile_elems = g.HZ * g.HY * g.HX;
 #pragma unroll
-  for (int j = 0; j < NPT; ++j) acc[j][0] = acc[j][1] = floatx4{0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < SE; ++k) {
+    const int e = tid + k * CV_THREADS;
+    int off = -2;  // -2: beyond the tile, -1: zero padding
+    if (e < tile_elems) {
+      const int row = e / g.HX, x = e - row * g.HX;
+      const int z = row / g.HY, y = row - z * g.HY;
+      const int gz = gz0 + z, gy = gy0 + y, gx = gx0 + x;
+      off = (gz >= 0 && gz < g.D && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) ? (gz * g.H + gy) * g.W + gx : -1;
+    }
+    goff[k] = off;
+  }
 
   const bool xform = in_stats != nullptr;
-  const int rows_per_ch = g.HZ * g.HY;
-  const int kbase = (lane >> 4) * g.CST;
+  if (xform && tid < 32) {
+    const int grp = tid >> 3;
+    const float mean = in_stats[((size_t)n * 4 + grp) * 2 + 0];
+    const float rstd = in_stats[((size_t)n * 4 + grp) * 2 + 1];
+    const float sc = rstd * in_gamma[tid];
+    scsh[tid] = sc;
+    scsh[32 + tid] = in_beta[tid] - mean * sc;
+  }
 
-  for (int chunk = 0; chunk < g.nchunks; ++chunk) {
+  floatx4 acc[NPT][CT];
+#pragma unroll
+  for (int j = 0; j < NPT; ++j)
+#pragma unroll
+    for (int t = 0; t < CT; ++t) acc[j][t] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  float sreg[CV_CK][SE];
+  floatx4 wreg[WR];
+  auto stage_load = [&](int chunk) {
     const int c0 = chunk * CV_CK;
     const int cc = min(CV_CK, g.cin - c0);
-    __syncthreads();  // previous chunk fully consumed
-    if (xform && tid < cc) {
-      const int c = c0 + tid;
-      const int grp = c >> 3;
-      const float mean = in_stats[((size_t)n * 4 + grp) * 2 + 0];
-      const float rstd = in_stats[((size_t)n * 4 + grp) * 2 + 1];
-      const float sc = rstd * in_gamma[c];
-      scsh[tid] = sc;
-      scsh[32 + tid] = in_beta[c] - mean * sc;
-    }
-    // weights of this chunk
-    {
-      const float *wsrc = wpk + (size_t)chunk * g.wfloats_chunk;
-      for (int i = tid * 4; i < g.wfloats_chunk; i += CV_THREADS * 4)
-        *reinterpret_cast<floatx4 *>(wl + i) = *reinterpret_cast<const floatx4 *>(wsrc + i);
-    }
-    if (xform) __syncthreads();
-    // haloed input rows: one wave per (channel, z, y) row, lanes along x
-    const int total_rows = CV_CK * rows_per_ch;
-    for (int r = wave; r < total_rows; r += CV_WAVES) {
-      const int c = r / rows_per_ch;
-      const int rem = r - c * rows_per_ch;
-      const int z = rem / g.HY, y = rem - z * g.HY;
-      const int gz = gz0 + z, gy = gy0 + y;
-      const bool row_ok = c < cc && gz >= 0 && gz < g.D && gy >= 0 && gy < g.H;
-      float *dst = tile + (size_t)c * g.CST + (z * g.HY + y) * g.XS;
-      const float *srow = inn + (size_t)(c0 + c) * in_chan + (size_t)(row_ok ? gz : 0) * in_plane +
-                          (size_t)(row_ok ? gy : 0) * g.W;
-      float sc = 1.0f, sh = 0.0f;
-      if (xform && c < cc) {
-        sc = scsh[c];
-        sh = scsh[32 + c];
-      }
-      for (int x = lane; x < g.HX; x += 64) {
-        const int gx = gx0 + x;
-        float v = 0.0f;
-        if (row_ok && gx >= 0 && gx < g.W) {
-          v = srow[gx];
-          if (xform) v = lrelu02(v * sc + sh);
-        }
-        dst[x] = v;
-      }
-    }
-    __syncthreads();
-
-    const int nks = (cc + 3) >> 2;  // 1 or 2 k-steps carry data in this chunk
-    int tap = 0;
-    for (int tz = 0; tz < g.kd; ++tz)
-      for (int ty = 0; ty < g.kh; ++ty)
-        for (int tx = 0; tx < g.kw; ++tx, ++tap) {
-          const int toff = (tz * g.HY + ty * g.dil) * g.XS + tx * g.dil;
-          const float *wt = wl + tap * 256 + lane;
-          for (int ks = 0; ks < nks; ++ks) {
-            const float w0 = wt[ks * 128];
-            const float w1 = wt[ks * 128 + 64];
-            const float *bp = tile + ks * 4 * g.CST + kbase + toff;
 #pragma unroll
-            for (int j = 0; j < NPT; ++j) {
-              const float b = bp[lpos[j]];
-              acc[j][0] = mfma16x16x4(w0, b, acc[j][0]);
-              acc[j][1] = mfma16x16x4(w1, b, acc[j][1]);
-            }
+    for (int c = 0; c < CV_CK; ++c) {
+      const float *src = inn + (size_t)(c0 + c) * in_chan;
+#pragma unroll
+      for (int k = 0; k < SE; ++k) sreg[c][k] = (c < cc && goff[k] >= 0) ? src[goff[k]] : 0.0f;
+    }
+    const float *wsrc = wpk + (size_t)chunk * WFL;
+#pragma unroll
+    for (int k = 0; k < WR; ++k) {
+      const int idx = (tid + k * CV_THREADS) * 4;
+      if (idx < WFL) wreg[k] = *reinterpret_cast<const floatx4 *>(wsrc + idx);
+    }
+  };
+  auto stage_store = [&](int chunk) {
+    const int c0 = chunk * CV_CK;
+#pragma unroll
+    for (int c = 0; c < CV_CK; ++c) {
+      float sc = 1.0f, sh = 0.0f;
+      if (xform) {
+        sc = scsh[c0 + c];
+        sh = scsh[32 + c0 + c];
+      }
+#pragma unroll
+      for (int k = 0; k < SE; ++k) {
+        if (goff[k] != -2) {
+          float v = sreg[c][k];
+          if (xform && goff[k] >= 0) v = lrelu02(v * sc + sh);
+          tile[c * g.CST + tid + k * CV_THREADS] = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < WR; ++k) {
+      const int idx = (tid + k * CV_THREADS) * 4;
+      if (idx < WFL) *reinterpret_cast<floatx4 *>(wl + idx) = wreg[k];
+    }
+  };
+
+  stage_load(0);
+  for (int chunk = 0; chunk < g.nchunks; ++chunk) {
+    __syncthreads();  // the previous chunk's MFMAs are done with LDS (and scsh is visible)
+    stage_store(chunk);
+    __syncthreads();
+    if (chunk + 1 < g.nchunks) stage_load(chunk + 1);
+    const float *wt = wl + lane;
+#pragma unroll
+    for (int tz = 0; tz < KD; ++tz)
+#pragma unroll
+      for (int ty = 0; ty < KH; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < KW; ++tx) {
+          const int tap = (tz * KH + ty) * KW + tx;
+          const float *bp = tile + (tz * g.HY + ty * g.dil) * g.XS + tx * g.dil;
+          const float w0 = wt[tap * 128];
+          const float w1 = CT == 2 ? wt[tap * 128 + 64] : 0.0f;
+#pragma unroll
+          for (int j = 0; j < NPT; ++j) {
+            const float b = bp[lpos[j]];
+            acc[j][0] = mfma16x16x4(w0, b, acc[j][0]);
+            if (CT == 2) acc[j][CT - 1] = mfma16x16x4(w1, b, acc[j][CT - 1]);
           }
         }
   }
 
   // ---- epilogue: bias, store, GroupNorm partials ---------------------------------------------
   const int cbase = (lane >> 4) * 4;
-  const size_t out_plane = (size_t)g.Ho * g.Wo, out_chan = (size_t)g.Do * out_plane;
+  const size_t out_chan = (size_t)g.Do * g.Ho * g.Wo;
   float *outn = out + (size_t)n * g.cout * out_chan;
   float s[2] = {0.f, 0.f};
   int cnt = 0;
 #pragma unroll
   for (int j = 0; j < NPT; ++j) {
-    const size_t pos = (size_t)oz[j] * out_plane + (size_t)oy[j] * g.Wo + ox[j];
-    if (valid[j]) cnt += 1;
+    const bool ok = opos[j] >= 0;
+    if (ok) cnt += 1;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < CT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int c = t * 16 + cbase + r;
         if (c < g.cout) {
           const float v = acc[j][t][r] + (bias ? bias[c] : 0.0f);
           acc[j][t][r] = v;
-          if (valid[j]) {
-            outn[(size_t)c * out_chan + pos] = v;
+          if (ok) {
+            outn[(size_t)c * out_chan + opos[j]] = v;
             s[t] += v;
           }
         }
       }
   }
   if (out_partials == nullptr) return;  // uniform across the grid
+  if (CT != 2) return;                  // partials need all 32 channels (checked on the host)
 
   // group of channel t*16 + cbase + r is 2t + (lane >> 5): reduce over the 32 lanes of a half-wave
   auto half_wave_sum = [&](float v) {
@@ -237,12 +281,11 @@ __global__ __launch_bounds__(CV_THREADS) void conv_mfma_kernel(ConvGeom g, const
     return v;
   };
   const int hi = lane >> 5;
-  // valid positions in this tile (same for every group): count over lanes 0..15 of each wave
   int cnt_tile;
   {
     float c = (lane < 16) ? (float)cnt : 0.0f;
     c = half_wave_sum(c);
-    __syncthreads();  // red is free (first use in this kernel)
+    __syncthreads();
     if (lane == 0) red[wave] = c;
     __syncthreads();
     cnt_tile = (int)(red[0] + red[1] + red[2] + red[3]);
@@ -267,9 +310,9 @@ __global__ __launch_bounds__(CV_THREADS) void conv_mfma_kernel(ConvGeom g, const
   float q[2] = {0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < NPT; ++j)
-    if (valid[j]) {
+    if (opos[j] >= 0) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < CT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float dv = acc[j][t][r] - m[t];
@@ -413,7 +456,7 @@ extern "C" int mvsn_conv_pack_weights(const mvsn_conv_desc *desc, const float *w
   mvsn::ConvGeom g;
   MVSN_REQUIRE(mvsn::make_geom(desc, &g), MVSN_E_BADARG, "mvsn_conv_pack_weights: unsupported descriptor");
   MVSN_REQUIRE(weight && packed, MVSN_E_BADARG, "mvsn_conv_pack_weights: null pointer");
-  const int total = g.nchunks * g.ntaps * 256;
+  const int total = g.nchunks * g.ntaps * 128;
   hipLaunchKernelGGL(mvsn::conv_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, weight,
                      g.cin, g.cout, g.ntaps, g.nchunks, packed);
   return mvsn::check_launch("mvsn_conv_pack_weights");
@@ -431,9 +474,9 @@ extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, co
   MVSN_REQUIRE(!out_partials || g.cout == 32, MVSN_E_BADARG, "mvsn_conv_forward: partials need 32 output channels");
   MVSN_REQUIRE(g.n <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_forward: batch too large for one launch");
   dim3 grid(g.tiles, g.n);
-#define MVSN_CONV_LAUNCH(NPTV)                                                                                   \
+#define MVSN_CONV_LAUNCH(...)                                                                                    \
   do {                                                                                                           \
-    auto kern = conv_mfma_kernel<NPTV>;                                                                          \
+    auto kern = conv_mfma_kernel<__VA_ARGS__>;                                                                   \
     static size_t opted = 0;                                                                                     \
     if (g.lds_bytes > opted) {                                                                                   \
       hipError_t e =                                                                                             \
@@ -447,10 +490,19 @@ extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, co
     hipLaunchKernelGGL(kern, grid, dim3(CV_THREADS), g.lds_bytes, (hipStream_t)stream, g, in, weight_packed, bias, \
                        in_stats, in_gamma, in_beta, out, out_partials);                                          \
   } while (0)
-  if (g.TZ == 2)
-    MVSN_CONV_LAUNCH(8);
-  else
-    MVSN_CONV_LAUNCH(4);
+  const bool one_tile = g.cout <= 16;
+  const bool se3 = g.se <= 3;
+  if (g.kd == 3) {                       // 3-D 3x3x3, TZ=2 TY=8 -> NPT 8, SE 6
+    if (one_tile) MVSN_CONV_LAUNCH(8, 3, 3, 3, 1, 6, 1); else MVSN_CONV_LAUNCH(8, 3, 3, 3, 1, 6, 2);
+  } else if (g.kh == 5) {                // 2-D 5x5 stride 2, TY=8 -> NPT 4
+    MVSN_CONV_LAUNCH(4, 1, 5, 5, 2, 6, 2);
+  } else if (g.TY == 16) {               // 2-D 3x3, NPT 8
+    if (one_tile) { if (se3) MVSN_CONV_LAUNCH(8, 1, 3, 3, 1, 3, 1); else MVSN_CONV_LAUNCH(8, 1, 3, 3, 1, 6, 1); }
+    else          { if (se3) MVSN_CONV_LAUNCH(8, 1, 3, 3, 1, 3, 2); else MVSN_CONV_LAUNCH(8, 1, 3, 3, 1, 6, 2); }
+  } else {                               // 2-D 3x3, NPT 4
+    if (one_tile) { if (se3) MVSN_CONV_LAUNCH(4, 1, 3, 3, 1, 3, 1); else MVSN_CONV_LAUNCH(4, 1, 3, 3, 1, 6, 1); }
+    else          { if (se3) MVSN_CONV_LAUNCH(4, 1, 3, 3, 1, 3, 2); else MVSN_CONV_LAUNCH(4, 1, 3, 3, 1, 6, 2); }
+  }
 #undef MVSN_CONV_LAUNCH
   return check_launch("mvsn_conv_forward");
 }
