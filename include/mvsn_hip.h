@@ -100,13 +100,18 @@ int mvsn_incremental_cost_volume(const float *src_image_lvl4, const float *H_lvl
  * Direct convolution on fp32 MFMA (implicit GEMM, weights = A, activations = B), 2-D or 3-D,
  * C_out in {1..32}, 'same' padding = dilation*(k/2), stride 1 or 2 (2-D only), with
  *   - an optional input transform fused into the tile load:
- *         x = LeakyReLU_0.2(GroupNorm_4(in))            (in_stats != NULL)
+ *         x = LeakyReLU_0.2(GroupNorm_4(in))                        (in_stats != NULL)
+ *         x = in_residual + LeakyReLU_0.2(GroupNorm_4(in))          (in_residual != NULL: a residual
+ *             block x + LReLU(GN(conv(x))), utils/resnet.py:93-109, folded into the NEXT layer's load)
+ *     and, with out_staged != NULL, x itself written out once (N,C_in,H,W) as a by-product
+ *     (2-D 3x3 stride-1 layers only) -- the normalise/activate/add pass never runs on its own;
  *   - bias add, and per-workgroup GroupNorm partials of the OUTPUT (out_partials != NULL) that
  *     mvsn_groupnorm_finalize turns into (mean, rstd) per (sample, group).
  * Replaces every conv2d/conv3d + GroupNorm + LeakyReLU call site of FeatureNetwork (:109-129),
  * CostVolumeFilter (:341-353) and IDepthmapRefiner (:468-484).
  *   in (N,C_in,[D,]H,W)  weight_packed: mvsn_conv_packed_floats() floats  bias (C_out) or NULL
- *   in_stats (N,4,2) mean,rstd   in_gamma,in_beta (C_in)   out (N,C_out,[D,]Ho,Wo)
+ *   in_stats (N,4,2) mean,rstd   in_gamma,in_beta (C_in)   in_residual, out_staged (N,C_in,H,W)
+ *   out (N,C_out,[D,]Ho,Wo)
  *   out_partials (N, tiles, 4, 3) {count, mean, M2}
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
@@ -126,7 +131,8 @@ int mvsn_conv_pack_weights(const mvsn_conv_desc *desc, const float *weight, floa
 int mvsn_conv_num_tiles(const mvsn_conv_desc *desc);
 int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, const float *weight_packed,
                       const float *bias, const float *in_stats, const float *in_gamma,
-                      const float *in_beta, float *out, float *out_partials, mvsn_stream_t stream);
+                      const float *in_beta, const float *in_residual, float *out_staged, float *out,
+                      float *out_partials, mvsn_stream_t stream);
 /* partials (N,tiles,4,3) -> stats (N,4,2) = {mean, rstd}, eps 1e-5, biased variance */
 int mvsn_groupnorm_finalize(const float *partials, int n, int tiles, float *stats, mvsn_stream_t stream);
 /* out = [residual +] LeakyReLU_0.2(GroupNorm(x)) on (N,32,spatial); residual may be NULL; out may alias x */

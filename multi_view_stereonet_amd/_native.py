@@ -34,7 +34,7 @@ SIGNATURES = {
     "mvsn_conv_packed_floats": (c_size_t, [POINTER(ConvDesc)]),
     "mvsn_conv_pack_weights": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p]),
     "mvsn_conv_num_tiles": (c_int, [POINTER(ConvDesc)]),
-    "mvsn_conv_forward": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 8 + [c_void_p]),
+    "mvsn_conv_forward": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 10 + [c_void_p]),
     "mvsn_groupnorm_finalize": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mvsn_groupnorm_lrelu_apply": (c_int, [c_void_p] * 5 + [c_int, c_long, c_void_p, c_void_p]),
     "mvsn_soft_argmin": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p, c_void_p]),

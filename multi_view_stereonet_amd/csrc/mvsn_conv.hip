@@ -51,7 +51,9 @@ static bool make_geom(const mvsn_conv_desc *d, ConvGeom *g) {
   const bool is3d = d->depth > 1 || d->kd > 1;
   g->TZ = is3d ? 2 : 1;
   // 2-D 3x3 layers on tall images use 16-row tiles (less halo per output, more MFMAs per staging)
-  g->TY = (!is3d && d->kh == 3 && d->stride == 1 && (d->rows - 1) / d->stride + 1 > 8) ? 16 : 8;
+  // (measured on MI355X, B=128: dilation 4/8 layers are 10-17 % faster with 8-row tiles -- the 16-row
+  // halo no longer fits two workgroups' worth of staging registers -- dilation 1/2 layers are equal)
+  g->TY = (!is3d && d->kh == 3 && d->stride == 1 && d->dilation <= 2 && (d->rows - 1) / d->stride + 1 > 8) ? 16 : 8;
   g->HZ = g->TZ + d->kd - 1;
   g->HY = (g->TY - 1) * d->stride + d->dilation * (d->kh - 1) + 1;
   g->HX = (CV_TX - 1) * d->stride + d->dilation * (d->kw - 1) + 1;
@@ -98,13 +100,19 @@ __global__ void conv_pack_kernel(const float *__restrict__ w, int cin, int cout,
 // Pipeline per 4-channel chunk (one MFMA k-step per tap): the chunk's haloed tile and weight fragments are fetched from
 // HBM/L2 into registers while the MFMAs of the previous chunk run, then written to LDS between
 // two barriers (register-staged double buffering, one LDS copy).
-template <int NPT, int KD, int KH, int KW, int STRIDE, int SE, int CT>
+// RES   residual-capable variant: the staged input is [in_residual +] LeakyReLU(GN(in)) (a residual
+//       block folded into the load);
+//       with out_staged != null every workgroup also writes the staged values of its own output
+//       positions, so the block's output tensor is produced as a by-product (stride 1 only).
+template <int NPT, int KD, int KH, int KW, int STRIDE, int SE, int CT, bool RES>
 __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, const float *__restrict__ in,
                                                                   const float *__restrict__ wpk,
                                                                   const float *__restrict__ bias,
                                                                   const float *__restrict__ in_stats,
                                                                   const float *__restrict__ in_gamma,
                                                                   const float *__restrict__ in_beta,
+                                                                  const float *__restrict__ in_residual,
+                                                                  float *__restrict__ out_staged,
                                                                   float *__restrict__ out,
                                                                   float *__restrict__ out_partials) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -144,6 +152,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
 
   // staging plan: element e = tid + k*256 of the HZ x HY x HX chunk tile (same for every channel)
   int goff[SE];
+  unsigned interior = 0;  // bit k: staged element k is one of this workgroup's own output positions
   const int tile_elems = g.HZ * g.HY * g.HX;
 #pragma unroll
   for (int k = 0; k < SE; ++k) {
@@ -154,9 +163,14 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
       const int z = row / g.HY, y = row - z * g.HY;
       const int gz = gz0 + z, gy = gy0 + y, gx = gx0 + x;
       off = (gz >= 0 && gz < g.D && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) ? (gz * g.H + gy) * g.W + gx : -1;
+      if (RES && off >= 0 && z >= g.pd && z < g.pd + g.TZ && y >= g.ph && y < g.ph + g.TY && x >= g.pw &&
+          x < g.pw + CV_TX)
+        interior |= 1u << k;
     }
     goff[k] = off;
   }
+  const float *resn = (RES && in_residual) ? in_residual + (size_t)n * g.cin * in_chan : nullptr;
+  float *stgn = (RES && out_staged) ? out_staged + (size_t)n * g.cin * in_chan : nullptr;
 
   const bool xform = in_stats != nullptr;
   if (xform && tid < 32) {
@@ -175,6 +189,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
     for (int t = 0; t < CT; ++t) acc[j][t] = floatx4{0.f, 0.f, 0.f, 0.f};
 
   float sreg[CV_CK][SE];
+  float rreg[RES ? CV_CK : 1][RES ? SE : 1];
   floatx4 wreg[WR];
   auto stage_load = [&](int chunk) {
     const int c0 = chunk * CV_CK;
@@ -184,6 +199,11 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
       const float *src = inn + (size_t)(c0 + c) * in_chan;
 #pragma unroll
       for (int k = 0; k < SE; ++k) sreg[c][k] = (c < cc && goff[k] >= 0) ? src[goff[k]] : 0.0f;
+      if constexpr (RES) {
+        const float *rsrc = resn + (size_t)(c0 + c) * in_chan;
+#pragma unroll
+        for (int k = 0; k < SE; ++k) rreg[c][k] = (resn && c < cc && goff[k] >= 0) ? rsrc[goff[k]] : 0.0f;
+      }
     }
     const float *wsrc = wpk + (size_t)chunk * WFL;
 #pragma unroll
@@ -206,7 +226,11 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
         if (goff[k] != -2) {
           float v = sreg[c][k];
           if (xform && goff[k] >= 0) v = lrelu02(v * sc + sh);
+          if constexpr (RES) v += rreg[c][k];
           tile[c * g.CST + tid + k * CV_THREADS] = v;
+          if constexpr (RES) {
+            if (stgn && ((interior >> k) & 1u) && c0 + c < g.cin) stgn[(size_t)(c0 + c) * in_chan + goff[k]] = v;
+          }
         }
       }
     }
@@ -464,7 +488,8 @@ extern "C" int mvsn_conv_pack_weights(const mvsn_conv_desc *desc, const float *w
 
 extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, const float *weight_packed,
                                  const float *bias, const float *in_stats, const float *in_gamma,
-                                 const float *in_beta, float *out, float *out_partials, mvsn_stream_t stream) {
+                                 const float *in_beta, const float *in_residual, float *out_staged, float *out,
+                                 float *out_partials, mvsn_stream_t stream) {
   using namespace mvsn;
   ConvGeom g;
   MVSN_REQUIRE(make_geom(desc, &g), MVSN_E_BADARG, "mvsn_conv_forward: unsupported descriptor");
@@ -472,6 +497,9 @@ extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, co
   MVSN_REQUIRE(!in_stats || (in_gamma && in_beta), MVSN_E_BADARG, "mvsn_conv_forward: input transform needs gamma/beta");
   MVSN_REQUIRE(!in_stats || g.cin == 32, MVSN_E_BADARG, "mvsn_conv_forward: input transform needs 32 channels");
   MVSN_REQUIRE(!out_partials || g.cout == 32, MVSN_E_BADARG, "mvsn_conv_forward: partials need 32 output channels");
+  MVSN_REQUIRE(!in_residual || in_stats, MVSN_E_BADARG, "mvsn_conv_forward: in_residual needs the input transform");
+  MVSN_REQUIRE(!(in_residual || out_staged) || (g.kd == 1 && g.kh == 3 && g.stride == 1), MVSN_E_BADARG,
+               "mvsn_conv_forward: residual / staged output only for 2-D 3x3 stride-1 layers");
   MVSN_REQUIRE(g.n <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_forward: batch too large for one launch");
   dim3 grid(g.tiles, g.n);
 #define MVSN_CONV_LAUNCH(...)                                                                                    \
@@ -488,21 +516,31 @@ extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, co
       opted = g.lds_bytes;                                                                                       \
     }                                                                                                            \
     hipLaunchKernelGGL(kern, grid, dim3(CV_THREADS), g.lds_bytes, (hipStream_t)stream, g, in, weight_packed, bias, \
-                       in_stats, in_gamma, in_beta, out, out_partials);                                          \
+                       in_stats, in_gamma, in_beta, in_residual, out_staged, out, out_partials);                 \
   } while (0)
   const bool one_tile = g.cout <= 16;
   const bool se3 = g.se <= 3;
+  const bool res = in_residual != nullptr || out_staged != nullptr;
+#define MVSN_CONV_2D(NPTV)                                                                      \
+  do {                                                                                          \
+    if (one_tile) {                                                                             \
+      if (se3) { if (res) MVSN_CONV_LAUNCH(NPTV, 1, 3, 3, 1, 3, 1, true); else MVSN_CONV_LAUNCH(NPTV, 1, 3, 3, 1, 3, 1, false); } \
+      else     { if (res) MVSN_CONV_LAUNCH(NPTV, 1, 3, 3, 1, 6, 1, true); else MVSN_CONV_LAUNCH(NPTV, 1, 3, 3, 1, 6, 1, false); } \
+    } else {                                                                                    \
+      if (se3) { if (res) MVSN_CONV_LAUNCH(NPTV, 1, 3, 3, 1, 3, 2, true); else MVSN_CONV_LAUNCH(NPTV, 1, 3, 3, 1, 3, 2, false); } \
+      else     { if (res) MVSN_CONV_LAUNCH(NPTV, 1, 3, 3, 1, 6, 2, true); else MVSN_CONV_LAUNCH(NPTV, 1, 3, 3, 1, 6, 2, false); } \
+    }                                                                                           \
+  } while (0)
   if (g.kd == 3) {                       // 3-D 3x3x3, TZ=2 TY=8 -> NPT 8, SE 6
-    if (one_tile) MVSN_CONV_LAUNCH(8, 3, 3, 3, 1, 6, 1); else MVSN_CONV_LAUNCH(8, 3, 3, 3, 1, 6, 2);
+    if (one_tile) MVSN_CONV_LAUNCH(8, 3, 3, 3, 1, 6, 1, false); else MVSN_CONV_LAUNCH(8, 3, 3, 3, 1, 6, 2, false);
   } else if (g.kh == 5) {                // 2-D 5x5 stride 2, TY=8 -> NPT 4
-    MVSN_CONV_LAUNCH(4, 1, 5, 5, 2, 6, 2);
+    MVSN_CONV_LAUNCH(4, 1, 5, 5, 2, 6, 2, false);
   } else if (g.TY == 16) {               // 2-D 3x3, NPT 8
-    if (one_tile) { if (se3) MVSN_CONV_LAUNCH(8, 1, 3, 3, 1, 3, 1); else MVSN_CONV_LAUNCH(8, 1, 3, 3, 1, 6, 1); }
-    else          { if (se3) MVSN_CONV_LAUNCH(8, 1, 3, 3, 1, 3, 2); else MVSN_CONV_LAUNCH(8, 1, 3, 3, 1, 6, 2); }
+    MVSN_CONV_2D(8);
   } else {                               // 2-D 3x3, NPT 4
-    if (one_tile) { if (se3) MVSN_CONV_LAUNCH(4, 1, 3, 3, 1, 3, 1); else MVSN_CONV_LAUNCH(4, 1, 3, 3, 1, 6, 1); }
-    else          { if (se3) MVSN_CONV_LAUNCH(4, 1, 3, 3, 1, 3, 2); else MVSN_CONV_LAUNCH(4, 1, 3, 3, 1, 6, 2); }
+    MVSN_CONV_2D(4);
   }
+#undef MVSN_CONV_2D
 #undef MVSN_CONV_LAUNCH
   return check_launch("mvsn_conv_forward");
 }

@@ -65,6 +65,87 @@ __global__ __launch_bounds__(256) void upsample_kernel(const TIn *__restrict__ i
     out[(plane * hout + y) * wout + x] = (TOut)v;
 }
 
+// Mask variant: each thread produces 16 consecutive output columns of one row and stores them as
+// one 128-bit word (the D-channel masks are the largest HBM stream of a forward; byte stores waste
+// most of every write transaction).  1-D grid over (plane, row, 16-column group).
+__global__ __launch_bounds__(256) void upsample_mask16_kernel(const uint8_t *__restrict__ in, int hin, int win,
+                                                              int hout, int wout, int groups_per_row,
+                                                              size_t total_groups, uint8_t *__restrict__ out) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total_groups) return;
+  const int gx = (int)(gid % groups_per_row);
+  const size_t rowid = gid / groups_per_row;  // plane * hout + y
+  const int y = (int)(rowid % hout);
+  const size_t plane = rowid / hout;
+  const int x16 = gx * 16;
+  ResizeTap ty = resize_tap(y, hin, hout);
+  const uint8_t *r0 = in + (plane * hin + ty.i0) * win;
+  const uint8_t *r1 = in + (plane * hin + ty.i1) * win;
+  uint32_t w[4] = {0, 0, 0, 0};
+  uint8_t vals[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int x = x16 + k < wout ? x16 + k : wout - 1;
+    ResizeTap tx = resize_tap(x, win, wout);
+    const float v00 = (float)r0[tx.i0], v01 = (float)r0[tx.i1], v10 = (float)r1[tx.i0], v11 = (float)r1[tx.i1];
+    const float v = ty.l0 * (tx.l0 * v00 + tx.l1 * v01) + ty.l1 * (tx.l0 * v10 + tx.l1 * v11);
+    vals[k] = v > 0.5f ? 1 : 0;
+    w[k >> 2] |= (uint32_t)vals[k] << (8 * (k & 3));
+  }
+  uint8_t *orow = out + rowid * wout;
+  if (x16 + 15 < wout && (((size_t)(orow + x16)) & 15) == 0) {
+    *reinterpret_cast<uint4 *>(orow + x16) = make_uint4(w[0], w[1], w[2], w[3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (x16 + k < wout) orow[x16 + k] = vals[k];
+  }
+}
+
+// Exact x2 case (every level of an even-sized pyramid): output column 2i takes taps (i-1, i) with
+// weights (0.25, 0.75), column 2i+1 taps (i, i+1) with (0.75, 0.25), edges clamped -- exactly what
+// resize_tap() yields, so the result is bit-identical to the generic kernel.  One thread makes 16
+// output bytes from two 12-byte input windows read as 32-bit words (8 loads instead of 64).
+__global__ __launch_bounds__(256) void upsample_mask2x_kernel(const uint8_t *__restrict__ in, int hin, int win,
+                                                              int groups_per_row, size_t total_groups,
+                                                              uint8_t *__restrict__ out) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total_groups) return;
+  const int hout = hin * 2, wout = win * 2;
+  const int gx = (int)(gid % groups_per_row);
+  const size_t rowid = gid / groups_per_row;
+  const int y = (int)(rowid % hout);
+  const size_t plane = rowid / hout;
+  const int i0 = gx * 8;  // first input column of this group's 8-column core
+  ResizeTap ty = resize_tap(y, hin, hout);
+  const uint8_t *r0 = in + (plane * hin + ty.i0) * win;
+  const uint8_t *r1 = in + (plane * hin + ty.i1) * win;
+  // columns i0-1 .. i0+8 of both rows (edges clamped); win % 8 == 0 so the 32-bit words are aligned
+  const uint32_t *w0 = reinterpret_cast<const uint32_t *>(r0 + i0);
+  const uint32_t *w1 = reinterpret_cast<const uint32_t *>(r1 + i0);
+  const uint32_t a0 = w0[0], a1 = w0[1], b0 = w1[0], b1 = w1[1];
+  const int il = i0 > 0 ? i0 - 1 : 0, ir = i0 + 8 < win ? i0 + 8 : win - 1;
+  float top[10], bot[10];
+  top[0] = (float)r0[il], bot[0] = (float)r1[il], top[9] = (float)r0[ir], bot[9] = (float)r1[ir];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    top[1 + k] = (float)((a0 >> (8 * k)) & 0xff);
+    top[5 + k] = (float)((a1 >> (8 * k)) & 0xff);
+    bot[1 + k] = (float)((b0 >> (8 * k)) & 0xff);
+    bot[5 + k] = (float)((b1 >> (8 * k)) & 0xff);
+  }
+  // same association as the generic kernel: ty.l0*(l0*v00 + l1*v01) + ty.l1*(l0*v10 + l1*v11)
+  uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int a = (k >> 1) + (k & 1), b = a + 1;              // window-relative taps (static)
+    const float l0 = (k & 1) ? 0.75f : 0.25f, l1 = (k & 1) ? 0.25f : 0.75f;
+    const float v = ty.l0 * (l0 * top[a] + l1 * top[b]) + ty.l1 * (l0 * bot[a] + l1 * bot[b]);
+    w[k >> 2] |= (uint32_t)(v > 0.5f ? 1 : 0) << (8 * (k & 3));
+  }
+  *reinterpret_cast<uint4 *>(out + rowid * wout + gx * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // ---- multi-source fusion -------------------------------------------------------------------
 __global__ __launch_bounds__(256) void fuse_idepth_kernel(const float *__restrict__ raw,
                                                           const float *__restrict__ refined,
@@ -131,10 +212,16 @@ extern "C" int mvsn_upsample_mask(const uint8_t *in, int n, int channels, int ro
   MVSN_REQUIRE(in && out, MVSN_E_BADARG, "mvsn_upsample_mask: null pointer");
   MVSN_REQUIRE(n > 0 && channels > 0 && rows_in > 0 && cols_in > 0 && rows_out > 0 && cols_out > 0, MVSN_E_BADARG,
                "mvsn_upsample_mask: bad sizes");
-  MVSN_REQUIRE((long)n * channels <= 65535 && rows_out <= 65535, MVSN_E_TOOLARGE, "mvsn_upsample_mask: grid");
-  dim3 grid((cols_out + 255) / 256, rows_out, n * channels);
-  hipLaunchKernelGGL((mvsn::upsample_kernel<uint8_t, uint8_t, true>), grid, dim3(256), 0, (hipStream_t)stream, in,
-                     rows_in, cols_in, rows_out, cols_out, out);
+  const int groups_per_row = (cols_out + 15) / 16;
+  const size_t total = (size_t)n * channels * rows_out * groups_per_row;
+  MVSN_REQUIRE((total + 255) / 256 < 2147483647ull, MVSN_E_TOOLARGE, "mvsn_upsample_mask: grid");
+  if (rows_out == 2 * rows_in && cols_out == 2 * cols_in && cols_in % 8 == 0 && (((size_t)in | (size_t)out) & 15) == 0) {
+    hipLaunchKernelGGL(mvsn::upsample_mask2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, in, rows_in, cols_in, groups_per_row, total, out);
+    return mvsn::check_launch("mvsn_upsample_mask(2x)");
+  }
+  hipLaunchKernelGGL(mvsn::upsample_mask16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, in, rows_in, cols_in, rows_out, cols_out, groups_per_row, total, out);
   return mvsn::check_launch("mvsn_upsample_mask");
 }
 

@@ -168,6 +168,36 @@ def test_conv_with_folded_groupnorm_input():
     close(r2, ref2, rtol=1e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("rows,cols,dil,cout", [(16, 32, 1, 32), (40, 50, 2, 32), (70, 33, 8, 32), (9, 20, 1, 1)])
+def test_conv_with_folded_residual_block(rows, cols, dil, cout):
+    """x' = x + LReLU(GN(r)) computed inside the next conv's tile load and written out once."""
+    from multi_view_stereonet_amd.multi_view_stereonet import _Conv, _Norm
+    eng = net_for("gta_sfm_150epochs").engine()
+    g = torch.Generator().manual_seed(rows + dil)
+    r = torch.randn(2, 32, rows, cols, generator=g) * 1.5 + 0.3
+    x = torch.randn(2, 32, rows, cols, generator=g)
+    gamma, beta = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.1
+    w = torch.randn(cout, 32, 3, 3, generator=g) * 0.05
+    b = torch.randn(cout, generator=g) * 0.1
+
+    class P:
+        weight, bias = gamma.to(DEV), beta.to(DEV)
+    rg = r.reshape(2, 4, -1).double()
+    stats = torch.stack([rg.mean(2), 1.0 / (rg.var(2, unbiased=False) + 1e-5).sqrt()], 2).float().contiguous()
+    c = _Conv(eng.lib, w.to(DEV), b.to(DEV), dilation=dil)
+    xs_ref = x + F.leaky_relu(F.group_norm(r, 4, gamma, beta, 1e-5), 0.2)
+    ref = F.conv2d(xs_ref, w, b, padding=dil, dilation=dil)
+    out, _, staged = eng.conv(c, r.to(DEV), in_stats=stats.to(DEV), in_norm=_Norm(P), in_residual=x.to(DEV),
+                              write_staged=True)
+    close(staged, xs_ref, rtol=1e-4, atol=1e-4)
+    close(out, ref, rtol=1e-4, atol=2e-4)
+    # without the residual, with the write-out (first block of a refiner)
+    out2, _, staged2 = eng.conv(c, r.to(DEV), in_stats=stats.to(DEV), in_norm=_Norm(P), write_staged=True)
+    x0_ref = F.leaky_relu(F.group_norm(r, 4, gamma, beta, 1e-5), 0.2)
+    close(staged2, x0_ref, rtol=1e-4, atol=1e-4)
+    close(out2, F.conv2d(x0_ref, w, b, padding=dil, dilation=dil), rtol=1e-4, atol=2e-4)
+
+
 def test_cost_volume_filter_and_soft_argmin_golden_unit():
     fix = load_golden("g4_units.npz")
     eng = net_for("gta_sfm_150epochs").engine()
@@ -198,6 +228,9 @@ def test_upsamplers_golden_units():
     g = torch.Generator().manual_seed(8)
     m = torch.rand(1, 64, 16, 32, generator=g) > 0.45
     assert torch.equal(eng.upsample_mask(m.to(DEV), (32, 64)).cpu(), oracle.upsample_mask(m, (32, 64)))
+    for (h, w, H, W) in ((30, 40, 60, 80), (8, 12, 15, 23), (4, 6, 8, 12), (5, 7, 9, 13)):
+        m = torch.rand(2, 12, h, w, generator=g) > 0.5
+        assert torch.equal(eng.upsample_mask(m.to(DEV), (H, W)).cpu(), oracle.upsample_mask(m, (H, W)))
 
 
 @pytest.mark.parametrize("rows,cols,D,S,B,wname", [(64, 128, 16, 1, 1, "gta_sfm_150epochs"),
