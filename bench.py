@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("MVSN_BENCH_BATCH", "32")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("MVSN_BENCH_BATCH", "128")),
                     help="reference images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -173,8 +173,16 @@ def main():
             name, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
             per_launch_ms = dom["ms"] / dom["launches"]
             tfl = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12
+            traffic = None
+            try:   # HBM bytes per launch from the committed PMC passes (profiles/), scaled to this batch
+                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                    t = json.load(f).get(name)
+                if t:
+                    traffic = (t["fetch_bytes_per_chain"] + t["write_bytes_per_chain"]) * B * S
+            except OSError:
+                pass
             line["roofline"] = {"kernel": name, "bound": "mfma", "achieved": tfl, "peak": PEAK_FP32_MFMA_TFLOPS,
-                                "unit": "TFLOP/s", "frac": tfl / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                                "unit": "TFLOP/s", "frac": tfl / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                                 "launches_per_step": dom["launches"], "avg_launch_ms": per_launch_ms,
                                 "share_of_step": dom["ms"] / total_ms}
             ch = agg.get("mvsn_incremental_cost_volume")

@@ -158,6 +158,14 @@ int mvsn_upsample_mask(const uint8_t *in, int n, int channels, int rows_in, int 
                        int cols_out, uint8_t *out, mvsn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * One level of the ceil-halving area pyramid the forward's inputs are built from
+ * (build_image_pyramid, utils/image_utils.py:111-128 = interpolate(mode="area")).
+ *   in (N,C,h,w) -> out (N,C,(h+1)/2,(w+1)/2)
+ * ------------------------------------------------------------------------------------------- */
+int mvsn_area_downsample(const float *in, int n, int channels, int rows_in, int cols_in, float *out,
+                         mvsn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Multi-source fusion (multi_view_stereonet.py:615-627): per chain divide by its baseline, mean
  * over the S sources; mask = mean(mask) > 0.5.
  *   raw, refined (S*B,P)  baseline (S*B)  mask (S*B,D,P) u8

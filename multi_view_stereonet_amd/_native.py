@@ -40,6 +40,7 @@ SIGNATURES = {
     "mvsn_soft_argmin": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p, c_void_p]),
     "mvsn_upsample_bilinear": (c_int, [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
     "mvsn_upsample_mask": (c_int, [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
+    "mvsn_area_downsample": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p, c_void_p]),
     "mvsn_fuse_sources": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p] * 3 + [c_void_p]),
     "mvsn_selftest_mfma": (c_int, [c_void_p]),
 }

@@ -479,8 +479,8 @@ extern "C" int mvsn_incremental_cost_volume(const float *src_image_lvl4, const f
   const int P = rows * cols;
   const int tiles = (P + 15) / 16;
   const int TP = (tiles + CH_WAVES - 1) / CH_WAVES;
-  MVSN_REQUIRE(TP <= 5, MVSN_E_TOOLARGE,
-               "mvsn_incremental_cost_volume: %dx%d coarse grid (%d px) exceeds the 1280 px plan", rows, cols, P);
+  MVSN_REQUIRE(TP <= 8, MVSN_E_TOOLARGE,
+               "mvsn_incremental_cost_volume: %dx%d coarse grid (%d px) exceeds the 2048 px plan", rows, cols, P);
   ChainArgs a;
   a.src = src_image_lvl4;
   a.H = H_lvl4;
@@ -532,7 +532,10 @@ extern "C" int mvsn_incremental_cost_volume(const float *src_image_lvl4, const f
       case 2: MVSN_CHAIN_LAUNCH(2, false); break;
       case 3: MVSN_CHAIN_LAUNCH(3, false); break;
       case 4: MVSN_CHAIN_LAUNCH(4, false); break;
-      default: MVSN_CHAIN_LAUNCH(5, false); break;
+      case 5: MVSN_CHAIN_LAUNCH(5, false); break;
+      case 6: MVSN_CHAIN_LAUNCH(6, false); break;
+      case 7: MVSN_CHAIN_LAUNCH(7, false); break;
+      default: MVSN_CHAIN_LAUNCH(8, false); break;
     }
   }
 #undef MVSN_CHAIN_LAUNCH

@@ -146,6 +146,25 @@ __global__ __launch_bounds__(256) void upsample_mask2x_kernel(const uint8_t *__r
   *reinterpret_cast<uint4 *>(out + rowid * wout + gx * 16) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// ---- area (adaptive average) downsample: one pyramid level ---------------------------------
+// out size ((h+1)/2, (w+1)/2); window [floor(i*in/out), ceil((i+1)*in/out)) as ATen's
+// adaptive_avg_pool2d (= interpolate(mode="area"), utils/image_utils.py:118-126): an exact 2x2
+// mean for even sizes, overlapping windows for odd ones.
+__global__ __launch_bounds__(256) void area_downsample_kernel(const float *__restrict__ in, int hin, int win,
+                                                              int hout, int wout, float *__restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  const size_t plane = blockIdx.z;
+  if (x >= wout) return;
+  const int y0 = (y * hin) / hout, y1 = ((y + 1) * hin + hout - 1) / hout;
+  const int x0 = (x * win) / wout, x1 = ((x + 1) * win + wout - 1) / wout;
+  const float *ip = in + plane * hin * win;
+  float sum = 0.0f;
+  for (int yy = y0; yy < y1; ++yy)
+    for (int xx = x0; xx < x1; ++xx) sum += ip[yy * win + xx];
+  out[(plane * hout + y) * wout + x] = sum / (float)((y1 - y0) * (x1 - x0));
+}
+
 // ---- multi-source fusion -------------------------------------------------------------------
 __global__ __launch_bounds__(256) void fuse_idepth_kernel(const float *__restrict__ raw,
                                                           const float *__restrict__ refined,
@@ -223,6 +242,18 @@ extern "C" int mvsn_upsample_mask(const uint8_t *in, int n, int channels, int ro
   hipLaunchKernelGGL(mvsn::upsample_mask16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, in, rows_in, cols_in, rows_out, cols_out, groups_per_row, total, out);
   return mvsn::check_launch("mvsn_upsample_mask");
+}
+
+extern "C" int mvsn_area_downsample(const float *in, int n, int channels, int rows_in, int cols_in, float *out,
+                                    mvsn_stream_t stream) {
+  MVSN_REQUIRE(in && out, MVSN_E_BADARG, "mvsn_area_downsample: null pointer");
+  MVSN_REQUIRE(n > 0 && channels > 0 && rows_in > 0 && cols_in > 0, MVSN_E_BADARG, "mvsn_area_downsample: bad sizes");
+  const int rows_out = (rows_in + 1) / 2, cols_out = (cols_in + 1) / 2;
+  MVSN_REQUIRE((long)n * channels <= 65535 && rows_out <= 65535, MVSN_E_TOOLARGE, "mvsn_area_downsample: grid");
+  dim3 grid((cols_out + 255) / 256, rows_out, n * channels);
+  hipLaunchKernelGGL(mvsn::area_downsample_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, rows_in, cols_in,
+                     rows_out, cols_out, out);
+  return mvsn::check_launch("mvsn_area_downsample");
 }
 
 extern "C" int mvsn_fuse_sources(const float *raw, const float *refined, const float *baseline, const uint8_t *mask,

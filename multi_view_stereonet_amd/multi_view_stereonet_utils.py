@@ -29,7 +29,18 @@ def build_image_pyramid(image: torch.Tensor, num_levels: int) -> List[torch.Tens
     while len(levels) < num_levels:
         prev = levels[-1]
         size = ((prev.shape[2] + 1) // 2, (prev.shape[3] + 1) // 2)
-        levels.append(F.adaptive_avg_pool2d(prev, size))
+        if prev.is_cuda:
+            # device frames: the HIP pyramid kernel (no ATen fallback; raises if the library is missing)
+            from . import _native
+            lib = _native.load()
+            prev = prev.contiguous().float()
+            nxt = torch.empty(prev.shape[:2] + size, dtype=torch.float32, device=prev.device)
+            _native.check(lib.mvsn_area_downsample(_native.ptr(prev), prev.shape[0], prev.shape[1], prev.shape[2],
+                                                   prev.shape[3], _native.ptr(nxt), _native.stream()),
+                          "mvsn_area_downsample")
+            levels.append(nxt)
+        else:
+            levels.append(F.adaptive_avg_pool2d(prev, size))   # host-side input prep for the oracle/tests
     return levels
 
 

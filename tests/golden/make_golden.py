@@ -18,6 +18,7 @@ Fixtures:
   g3_demon_640x480_d96_s1.npz   config 4 shape with DeMoN weights: outputs only
   g4_units.npz                  single-op pins on tiny tensors
   g6_flags_128x64.npz           do_cost_volume_filter=False / refiners off variants
+  g7_depth_metrics.npz          test.py's depth metrics on a synthetic truth/estimate pair
 """
 import os
 import sys
@@ -284,8 +285,27 @@ def unit_pins(name):
     print(name, "ok")
 
 
+def metric_pins(name):
+    """Depth metrics: run the reference's own get_depth_prediction_metrics (test.py:41-71).  test.py
+    imports the dataset stack (torchvision, pyquaternion: absent), so only that function is compiled
+    out of its source, here in the build container."""
+    import ast
+    mod = ast.parse(open("/root/reference/test.py").read())
+    fn = [n for n in mod.body if isinstance(n, ast.FunctionDef) and n.name == "get_depth_prediction_metrics"][0]
+    ns = {"np": np}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "ref_test.py", "exec"), ns)
+    rng = np.random.default_rng(5)
+    t_ = rng.uniform(0.6, 9.0, size=(40, 50)).astype(np.float32)
+    e_ = (t_ * rng.uniform(0.7, 1.5, size=t_.shape)).astype(np.float32)
+    m = ns["get_depth_prediction_metrics"](t_.reshape(-1), e_.reshape(-1))
+    np.savez_compressed(os.path.join(HERE, name), depth_true=t_, depth_est=e_,
+                        **{k: np.float64(v) for k, v in m.items()})
+    print(name, "ok")
+
+
 def main():
     torch.set_num_threads(8)
+    metric_pins("g7_depth_metrics.npz")
     full_capture("g1_gta_128x64_d16_s1.npz", "gta_sfm_150epochs", 64, 128, 16, 1, seed=1)
     full_capture("g1_init_128x64_d16_s1.npz", None, 64, 128, 16, 1, seed=1, init_seed=0, store_weights=False)
     full_capture("g1b_gta_96x80_d8_s2_b2.npz", "gta_sfm_150epochs", 80, 96, 8, 2, B=2, seed=2, jitter=0.3)

@@ -69,6 +69,7 @@ def test_conv_planning_is_host_side_and_validates():
     assert rc == -1 and b"null" in lib.mvsn_last_error()
     assert lib.mvsn_incremental_cost_volume_workspace_bytes(4, 16, 32) == 0       # LDS-resident plan
     assert lib.mvsn_incremental_cost_volume_workspace_bytes(4, 30, 40) > 0        # global planes
+    assert lib.mvsn_incremental_cost_volume_workspace_bytes(1, 32, 64) > 0        # config 5 grid
 
 
 def test_forward_refuses_cpu_tensors():

@@ -236,7 +236,8 @@ def test_upsamplers_golden_units():
 @pytest.mark.parametrize("rows,cols,D,S,B,wname", [(64, 128, 16, 1, 1, "gta_sfm_150epochs"),
                                                    (256, 512, 64, 2, 1, "gta_sfm_150epochs"),
                                                    (80, 96, 8, 2, 2, "gta_sfm_150epochs"),
-                                                   (480, 640, 12, 1, 1, "demon_45epochs")])
+                                                   (480, 640, 12, 1, 1, "demon_45epochs"),
+                                                   (512, 1024, 6, 1, 1, "gta_sfm_150epochs")])
 def test_incremental_chain_vs_oracle(rows, cols, D, S, B, wname):
     """The fused chain (features, cost, mask) against the oracle's step-by-step recurrence, fed
     with the SAME plane-0 features and homographies so only the chain itself is compared."""
@@ -352,6 +353,25 @@ def test_forward_flag_variants_golden():
                 assert mean_rel < 2e-4 and max_rel < 2e-3, (key, kind, lvl, mean_rel, max_rel)
 
 
+def test_unpack_batch_on_device_matches_host():
+    """pyramids built by the HIP kernel inside multi_view_unpack_batch."""
+    fix = load_golden("g4_units.npz")
+    pyr = snu.build_image_pyramid(t(fix["pyr_in"]).to(DEV), 4)
+    for i, p in enumerate(pyr):
+        close(p, fix[f"pyr_{i}"], rtol=1e-6, atol=1e-7)
+    batch = synthetic.make_batch(60, 90, 2, batch=2, seed=4, pose_jitter=0.2)
+    host = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
+    dev = snu.multi_view_unpack_batch(batch, torch.device(DEV), 5)
+    for a, b in zip(dev["left_image_pyr"], host["left_image_pyr"]):
+        assert a.shape == b.shape
+        close(a, b, rtol=1e-6, atol=1e-7)
+    for a, b in zip(dev["right_image_pyr"][1], host["right_image_pyr"][1]):
+        close(a, b, rtol=1e-6, atol=1e-7)
+    for a, b in zip(dev["K_pyr"], host["K_pyr"]):
+        close(a, b, rtol=1e-6, atol=1e-6)
+    close(dev["T_right_in_left"][1], host["T_right_in_left"][1], rtol=1e-6, atol=1e-7)
+
+
 def test_forward_batch_independence_and_determinism():
     """Images are independent units: a batch of 3 equals three batches of 1, bit for
     bit except GroupNorm partial-combination order (none here: same tiles), and reruns agree."""
@@ -367,6 +387,23 @@ def test_forward_batch_independence_and_determinism():
                   [[x[b:b + 1] for x in p] for p in rp], 24, True, [True] * 5)
         close(one["left_idepthmap_pyr"][0], full["left_idepthmap_pyr"][0][b:b + 1].cpu(), rtol=1e-5, atol=1e-6)
         assert torch.equal(one["left_idepthmap_mask_pyr"][0], full["left_idepthmap_mask_pyr"][0][b:b + 1])
+
+
+def test_forward_config5_shape_vs_oracle():
+    """BASELINE config 5's geometry (1024x512 frames, 32x64 coarse grid, 4 sources) in fp32; fewer
+    hypotheses than 128 so the host oracle finishes in seconds."""
+    wname = "gta_sfm_150epochs"
+    w = load_weights(wname)
+    batch = synthetic.make_batch(512, 1024, 4, batch=1, seed=44, smooth=True)
+    inp = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
+    ref = oracle.forward(w, inp["left_image_pyr"], inp["K_pyr"], inp["T_right_in_left"], inp["right_image_pyr"], 16)
+    lp, kp, ts, rp = to_dev(inp)
+    out = net_for(wname)(lp, kp, ts, rp, 16, True, [True] * 5)
+    for lvl in (0, 4):
+        mean_rel, max_rel = rel_err(out["left_idepthmap_pyr"][lvl].cpu(), ref["left_idepthmap_pyr"][lvl])
+        assert mean_rel < 2e-4 and max_rel < 2e-3, (lvl, mean_rel, max_rel)
+        diff = int((out["left_idepthmap_mask_pyr"][lvl].cpu() != ref["left_idepthmap_mask_pyr"][lvl]).sum())
+        assert diff <= 2 * 4 ** (4 - lvl), (lvl, diff)
 
 
 def test_forward_vs_oracle_small_batch():

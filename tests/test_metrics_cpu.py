@@ -1,0 +1,71 @@
+"""depth metrics + averaging harness (host code; pinned to the reference's function)."""
+import numpy as np
+import torch
+
+from conftest import load_golden
+from multi_view_stereonet_amd import metrics, synthetic
+
+
+def test_metrics_match_reference_function():
+    fix = load_golden("g7_depth_metrics.npz")
+    m = metrics.get_depth_prediction_metrics(fix["depth_true"].reshape(-1), fix["depth_est"].reshape(-1))
+    for k in metrics.METRIC_KEYS:
+        assert np.isclose(float(m[k]), float(fix[k]), rtol=1e-6, atol=0), k
+
+
+def test_known_answers_and_masking():
+    t = np.full((4, 5), 2.0, dtype=np.float32)
+    m = metrics.get_depth_prediction_metrics(t.reshape(-1), t.reshape(-1))
+    assert m["abs_rel"] == 0 and m["rmse"] == 0 and m["a1"] == 1.0
+    e = t * 1.3                                     # ratio 1.3: outside a1, inside a2
+    m = metrics.get_depth_prediction_metrics(t.reshape(-1), e.reshape(-1))
+    assert m["a1"] == 0.0 and m["a2"] == 1.0 and np.isclose(m["abs_rel"], 0.3, rtol=1e-6)
+    # DeMoN range (0.5, 10): truth or estimate outside is dropped; no valid truth -> None
+    lo, hi = metrics.depth_range("demon_test")
+    t2 = np.array([[0.2, 1.0, 3.0, 20.0]], dtype=np.float32)
+    e2 = np.array([[1.0, 1.0, 30.0, 5.0]], dtype=np.float32)
+    row = metrics.image_metric_row(t2, e2, lo, hi)
+    assert row["abs_rel"] == 0.0 and row["a1"] == 1.0            # only the (1.0, 1.0) pixel survives
+    assert metrics.image_metric_row(np.zeros((2, 2), np.float32), e2[:, :2].repeat(2, 0), lo, hi) is None
+    assert metrics.depth_range("gta_sfm_overlap0.5_test") == (0.0, 1e3)
+    avg = metrics.compute_avg_metrics([{"a": 1.0, "b": 2.0}, {"a": 3.0, "b": 6.0}])
+    assert avg == {"a": 2.0, "b": 4.0, "num_samples": 2}
+
+
+def test_idepth_to_depth_keeps_nonpositive():
+    idepth = torch.tensor([[[[0.5, 0.0], [2.0, -1.0]]]])
+    d = metrics.idepth_to_depth(idepth, torch.tensor([2.0]))
+    assert torch.allclose(d, torch.tensor([[[[4.0, 0.0], [1.0, -0.5]]]]))
+
+
+def test_evaluate_with_a_stand_in_network():
+    """The harness around forward(): a fake network that returns the true idepth must score perfectly;
+    an image without valid truth is skipped."""
+    truth = {}
+
+    class Net:
+        num_levels = 5
+
+        def __call__(self, lp, kp, ts, rp, D, flt, refs):
+            z = [truth["idepth_unit"]] * 5
+            return {"left_idepthmap_pyr": z, "left_idepthmap_raw_pyr": z, "left_idepthmap_mask_pyr": z}
+
+    batches = []
+    for i in range(3):
+        b = synthetic.make_batch(32, 64, 1, batch=1, seed=i)
+        depth = torch.full((1, 1, 32, 64), 2.0 + i) if i != 1 else torch.zeros(1, 1, 32, 64)
+        b["left_depthmap_true"] = depth
+        b["right_depthmap_true"] = [depth.clone()]
+        batches.append(b)
+
+    class Feeder:
+        def __iter__(self):
+            for b in batches:
+                base = b["T_right_in_left"][0][:, 0, :3, 3].norm(dim=1)
+                d = b["left_depthmap_true"]
+                truth["idepth_unit"] = torch.where(d > 0, base.view(-1, 1, 1, 1) / d, d)   # unit-baseline idepth
+                yield b
+
+    out = metrics.evaluate(Net(), Feeder(), {"num_idepth_samples": 8}, "gta_sfm", torch.device("cpu"))
+    assert out["num_samples"] == 2
+    assert out["abs_rel"] < 1e-6 and out["a1"] == 1.0 and out["runtime_ms"] >= 0.0

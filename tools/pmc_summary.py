@@ -14,5 +14,5 @@ for path in sys.argv[1:]:
             calls[k].add(row["Dispatch_Id"])
 names = sorted({c for v in agg.values() for c in v})
 print("kernel,dispatches," + ",".join(names))
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CYCLES", kv[1].get("GRBM_GUI_ACTIVE", 0))):
+for k, v in sorted(agg.items(), key=lambda kv: -max(kv[1].values())):
     print(k + "," + str(len(calls[k])) + "," + ",".join(f"{v.get(n, 0):.4g}" for n in names))
