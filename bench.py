@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("MVSN_BENCH_BATCH", "128")),
                     help="reference images per GPU per step")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("MVSN_BENCH_LANES", "1")),
+                    help="batch slices run on separate HIP streams (images are independent)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -118,6 +120,7 @@ def main():
     net = MultiViewStereoNet()
     net.load_state_dict(load_weights(WEIGHTS), strict=True)
     net = net.to(dev).eval()
+    net.stream_lanes = args.lanes
     B = args.batch
     _, inp = make_inputs(B, GOLDEN_SEED + rank * B, dev)
 

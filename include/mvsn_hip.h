@@ -140,6 +140,19 @@ int mvsn_groupnorm_lrelu_apply(const float *x, const float *stats, const float *
                                const float *residual, int n, long spatial, float *out, mvsn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * 32 -> 1 channel 3x3 (kd = 1) or 3x3x3 (kd = 3) convolution, 'same' padding, dilation 1: the last
+ * layer of CostVolumeFilter (conv4, :337,:351) and of every IDepthmapRefiner (conv_final, :464,:480).
+ * HBM-bound, so it runs on the vector ALUs with float4 rows and wave shuffles instead of MFMA.
+ * With prior != NULL it also applies the refiner's epilogue (:482 and the gain trick :607-611):
+ *     out = relu(prior * fx[n] + conv + bias) / fx[n]
+ *   in (N,32,[D,]H,W)  weight (1,32,[3,]3,3) UNPACKED  bias (1) or NULL  prior (N,1,H,W)  fx (N)
+ *   out (N,[D,]H,W).  Requires cols % 4 == 0 (mvsn_conv_to1_supported); otherwise use mvsn_conv_forward.
+ * ------------------------------------------------------------------------------------------- */
+int mvsn_conv_to1_supported(int rows, int cols);
+int mvsn_conv_to1(const float *in, const float *weight, const float *bias, const float *prior, const float *fx,
+                  int n, int depth, int rows, int cols, int kd, float *out, mvsn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Soft-argmin over the hypothesis axis: out = sum_d softmax(-cost)_d * idepth_d.
  * Replaces extract_idepthmap (multi_view_stereonet.py:486-492).
  *   cost (N,D,P)  idepth_samples (N,D)  ->  idepth (N,P)

@@ -20,6 +20,8 @@
 //                       ch 0..2 image plane d, ch 3..34 features, ch 35 zero (K padding).
 // When that exceeds 160 KiB the activation planes move to a per-chain global workspace
 // (L2-resident); the code path is otherwise identical.
+#include <stdlib.h>
+
 #include "mvsn_common.h"
 
 namespace mvsn {
@@ -45,6 +47,7 @@ struct ChainArgs {
   float *fvol;           // (N,32,D,P) or null
   float *workspace;      // global activation planes or null
   int B, D, rows, cols, CS;
+  unsigned long long *dbg;  // optional: s_memtime stamps of block 0 / lane 0 at phase boundaries (tuning only)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -273,26 +276,51 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a) {
     }
   }
   __syncthreads();
+
+  // Cost-volume slice of plane `dd` from the LDS-resident features: coalesced 16-byte HBM traffic
+  // (left features in, cost out), rows of the padded plane read back as 4 scalars.  Runs while the
+  // plane's features and mask are still in place, i.e. before barrier B1 of the following step.
+  auto write_cost_slice = [&](int dd) {
+    if ((cols & 3) == 0) {
+      const int quads = P >> 2;
+      for (int i = tid; i < 32 * quads; i += CH_THREADS) {
+        const int c = i / quads, p4 = (i - c * quads) * 4;
+        const int y = p4 / cols, x = p4 - y * cols;
+        const float *fr = act + (3 + c) * CS + y * RS + x;
+        const floatx4 l = *reinterpret_cast<const floatx4 *>(flp + (size_t)c * P + p4);
+        const floatx4 m = *reinterpret_cast<const floatx4 *>(maskb + p4);
+        floatx4 cst, ftr;
 #pragma unroll
-  for (int j = 0; j < TP; ++j) {
-    if (!valid[j]) continue;
-    const bool out = maskb[pb[j]] != 0.0f;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = t * 16 + cbase + r;
-        const float f = act[(3 + c) * CS + qb[j]];
-        costg[((size_t)c * D) * P + pb[j]] = out ? 0.0f : fabsf(flp[(size_t)c * P + pb[j]] - f);
-        if (fvolg) fvolg[((size_t)c * D) * P + pb[j]] = out ? 0.0f : f;
+        for (int k = 0; k < 4; ++k) {
+          const float f = fr[k];
+          cst[k] = m[k] != 0.0f ? 0.0f : fabsf(l[k] - f);
+          ftr[k] = m[k] != 0.0f ? 0.0f : f;
+        }
+        *reinterpret_cast<floatx4 *>(costg + ((size_t)c * D + dd) * P + p4) = cst;
+        if (fvolg) *reinterpret_cast<floatx4 *>(fvolg + ((size_t)c * D + dd) * P + p4) = ftr;
       }
-  }
+    } else {
+      for (int i = tid; i < 32 * P; i += CH_THREADS) {
+        const int c = i / P, p = i - c * P;
+        const float f = act[(3 + c) * CS + (p / cols) * RS + (p % cols)];
+        const bool out = maskb[p] != 0.0f;
+        costg[((size_t)c * D + dd) * P + p] = out ? 0.0f : fabsf(flp[(size_t)c * P + p] - f);
+        if (fvolg) fvolg[((size_t)c * D + dd) * P + p] = out ? 0.0f : f;
+      }
+    }
+  };
   const float inv_count = 1.0f / (8.0f * (float)P);
 
   // ---- the recurrence ------------------------------------------------------------------------
+#define MVSN_STAMP(i)                                                                   \
+  do {                                                                                  \
+    if (a.dbg && blockIdx.x == 0 && tid == 0 && d <= 4) a.dbg[(d - 1) * 16 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
   for (int d = 1; d < D; ++d) {
+    MVSN_STAMP(0);
     floatx4 wreg[3];
     load_weights_to_regs<W0_FLOATS>(a.packed, wreg, tid);
+    write_cost_slice(d - 1);
 
     // A1: image plane d and its mask (global gathers; the 6 KB source image stays in L1/L2)
     float img[IMG_IT][3];
@@ -341,7 +369,9 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a) {
           }
       }
     }
+    MVSN_STAMP(1);
     __syncthreads();  // B1: every gather of plane d-1 is done
+    MVSN_STAMP(2);
 
     // A3: lay out the refiner input [image(3) | moved features(32)]
 #pragma unroll
@@ -366,12 +396,15 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a) {
     }
     store_weights_to_lds<W0_FLOATS>(wbuf, wreg, tid);
     __syncthreads();  // B2
+    MVSN_STAMP(3);
 
     floatx4 acc[TP][2];
+    load_weights_to_regs<W1_FLOATS>(a.packed + W0_FLOATS, wreg, tid);  // in flight behind the MFMAs
     conv3x3_mfma<TP, 9>(act, wbuf, CS, RS, qb, lane, acc);
+    MVSN_STAMP(4);
     __syncthreads();  // B3: act and wbuf free
+    MVSN_STAMP(5);
 
-    load_weights_to_regs<W1_FLOATS>(a.packed + W0_FLOATS, wreg, tid);
     groupnorm_lrelu<TP>(acc, valid, bias0, gn0w, gn0b, red, red + 64, inv_count, lane, wave);
 #pragma unroll
     for (int j = 0; j < TP; ++j)
@@ -384,11 +417,14 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a) {
       }
     store_weights_to_lds<W1_FLOATS>(wbuf, wreg, tid);
     __syncthreads();  // B6
-
-    conv3x3_mfma<TP, 8>(act, wbuf, CS, RS, qb, lane, acc);
-    __syncthreads();  // B7
+    MVSN_STAMP(6);
 
     load_weights_to_regs<W1_FLOATS>(a.packed + W0_FLOATS + W1_FLOATS, wreg, tid);
+    conv3x3_mfma<TP, 8>(act, wbuf, CS, RS, qb, lane, acc);
+    MVSN_STAMP(7);
+    __syncthreads();  // B7
+    MVSN_STAMP(8);
+
     groupnorm_lrelu<TP>(acc, valid, bias1, gn1w, gn1b, red + 128, red + 192, inv_count, lane, wave);
 #pragma unroll
     for (int j = 0; j < TP; ++j)
@@ -401,28 +437,32 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a) {
       }
     store_weights_to_lds<W1_FLOATS>(wbuf, wreg, tid);
     __syncthreads();  // B10
+    MVSN_STAMP(9);
 
     conv3x3_mfma<TP, 8>(act, wbuf, CS, RS, qb, lane, acc);
+    MVSN_STAMP(10);
     __syncthreads();  // B11
+    MVSN_STAMP(11);
 
-    // epilogue: new features, cost slice, next step's gather source
+    // epilogue: the new features become the next step's gather source; their cost slice is
+    // written (coalesced) at the top of the next step / after the loop
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
       if (!valid[j]) continue;
-      const bool out = maskb[pb[j]] != 0.0f;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int c = t * 16 + cbase + r;
-          const float f = fp[j][t][r] + (acc[j][t][r] + bias2[c]);
-          act[(3 + c) * CS + qb[j]] = f;
-          costg[((size_t)c * D + d) * P + pb[j]] = out ? 0.0f : fabsf(flp[(size_t)c * P + pb[j]] - f);
-          if (fvolg) fvolg[((size_t)c * D + d) * P + pb[j]] = out ? 0.0f : f;
+          act[(3 + c) * CS + qb[j]] = fp[j][t][r] + (acc[j][t][r] + bias2[c]);
         }
     }
+    MVSN_STAMP(12);
     __syncthreads();  // B12
+    MVSN_STAMP(13);
   }
+#undef MVSN_STAMP
+  write_cost_slice(D - 1);
 }
 
 static size_t chain_lds_bytes(int P, int act_floats, bool lds_act) {
@@ -496,6 +536,11 @@ extern "C" int mvsn_incremental_cost_volume(const float *src_image_lvl4, const f
   a.rows = rows;
   a.cols = cols;
   a.CS = chain_cs(rows, cols);
+  a.dbg = nullptr;
+  {
+    const char *e = getenv("MVSN_CHAIN_DEBUG_PTR");  // tuning hook: device pointer to 64 x u64
+    if (e) a.dbg = (unsigned long long *)strtoull(e, nullptr, 0);
+  }
   const int act_floats = (cols + 2) + 36 * a.CS;
   const bool lds_act = chain_lds_bytes(P, act_floats, true) <= 160 * 1024;
   const size_t need = lds_act ? 0 : (size_t)n_chains * act_floats * sizeof(float);

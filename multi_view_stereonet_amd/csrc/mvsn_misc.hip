@@ -273,3 +273,201 @@ extern "C" int mvsn_fuse_sources(const float *raw, const float *refined, const f
                      (hipStream_t)stream, mask, n_sources, batch, DP, mask_out);
   return mvsn::check_launch("mvsn_fuse_sources(mask)");
 }
+
+// ---------------------------------------------------------------------------------------------
+// 32 -> 1 channel 3x3 / 3x3x3 convolution (the last layer of every refiner and of the regulariser)
+// ---------------------------------------------------------------------------------------------
+// One output channel has no cout dimension to put on MFMA (15/16 of a 16x16x4 tile would be wasted),
+// and at 128 input bytes per output the layer is HBM-bound: each thread owns 4 consecutive output
+// columns of one row, reads the three (or nine) neighbouring input rows of every channel as aligned
+// float4 and takes the two halo columns from its lane neighbours with wave shuffles (a 16-lane group
+// spans 64 columns; only the group's edge lanes touch memory for the halo).  Weights are wave-uniform
+// (scalar loads).  Optional refiner epilogue: relu(prior*fx + conv + bias) / fx
+// (multi_view_stereonet.py:482 with the gain trick of :607-611).
+namespace mvsn {
+
+// Load one input row segment (4 columns of this thread + the two halo columns).
+template <int GW = 16>
+__device__ __forceinline__ void load_row6(const float *__restrict__ row, bool ok, int x4, int W, int lane16,
+                                          float (&r)[6]) {
+  floatx4 v = {0.f, 0.f, 0.f, 0.f};
+  if (ok) v = *reinterpret_cast<const floatx4 *>(row + x4);
+  float left = __shfl_up(v[3], 1, GW);
+  float right = __shfl_down(v[0], 1, GW);
+  if (lane16 == 0) left = (ok && x4 > 0) ? row[x4 - 1] : 0.0f;
+  if (lane16 == GW - 1) right = (ok && x4 + 4 < W) ? row[x4 + 4] : 0.0f;
+  if (x4 + 4 >= W) right = 0.0f;  // last column group of a narrow image
+  r[0] = left, r[1] = v[0], r[2] = v[1], r[3] = v[2], r[4] = v[3], r[5] = right;
+}
+
+// Each thread owns 4 columns x RY rows (2-D) or 4 columns x 1 row x ZC planes (3-D) and walks the
+// input rows / planes once per channel with a rolling window, so a row is loaded once per RY (ZC)
+// outputs instead of three times.
+constexpr int TO1_RY = 4;   // 2-D: output rows per thread
+constexpr int TO1_ZC = 8;   // 3-D: output planes per thread
+
+__global__ __launch_bounds__(256) void conv_to1_2d_kernel(const float *__restrict__ in, const float *__restrict__ w,
+                                                          const float *__restrict__ bias,
+                                                          const float *__restrict__ prior, const float *__restrict__ fx,
+                                                          int H, int W, float *__restrict__ out) {
+  const int lane16 = threadIdx.x & 15;
+  const int x4 = (blockIdx.x * 16 + lane16) * 4;
+  const int y0 = (blockIdx.y * 16 + (threadIdx.x >> 4)) * TO1_RY;
+  const int n = blockIdx.z;
+  const size_t plane = (size_t)H * W;
+  const float *inn = in + (size_t)n * 32 * plane;
+  float acc[TO1_RY][4];
+#pragma unroll
+  for (int r = 0; r < TO1_RY; ++r)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[r][k] = 0.f;
+  for (int c = 0; c < 32; ++c) {
+    const float *ic = inn + (size_t)c * plane;
+    float wt[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wt[i] = w[c * 9 + i];
+#pragma unroll
+    for (int ry = 0; ry < TO1_RY + 2; ++ry) {   // input row y0 - 1 + ry feeds output rows ry-2 .. ry
+      const int yy = y0 - 1 + ry;
+      const bool ok = yy >= 0 && yy < H && x4 < W;
+      float r6[6];
+      load_row6(ic + (size_t)(ok ? yy : 0) * W, ok, x4, W, lane16, r6);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int orow = ry - dy;  // output row (relative) that sees this input row through tap dy
+        if (orow >= 0 && orow < TO1_RY) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            acc[orow][k] += wt[dy * 3 + 0] * r6[k] + wt[dy * 3 + 1] * r6[k + 1] + wt[dy * 3 + 2] * r6[k + 2];
+        }
+      }
+    }
+  }
+  if (x4 >= W) return;
+  const float b = bias ? bias[0] : 0.0f;
+  const float g = prior ? fx[n] : 1.0f;
+#pragma unroll
+  for (int r = 0; r < TO1_RY; ++r) {
+    const int y = y0 + r;
+    if (y >= H) break;
+    const size_t o = (size_t)n * plane + (size_t)y * W + x4;
+    floatx4 res;
+    if (prior) {
+      const floatx4 p = *reinterpret_cast<const floatx4 *>(prior + o);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float sv = p[k] * g + (acc[r][k] + b);
+        res[k] = (sv > 0.0f ? sv : 0.0f) / g;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) res[k] = acc[r][k] + b;
+    }
+    *reinterpret_cast<floatx4 *>(out + o) = res;
+  }
+}
+
+// GW lanes (GW*4 columns) per row group; the thread-row index runs over (plane chunk, image row)
+// jointly so that narrow coarse-level planes (e.g. 16x32) still fill the workgroup.
+template <int GW>
+__global__ __launch_bounds__(256) void conv_to1_3d_kernel(const float *__restrict__ in, const float *__restrict__ w,
+                                                          const float *__restrict__ bias, int D, int H, int W,
+                                                          float *__restrict__ out) {
+  const int lane16 = threadIdx.x % GW;
+  const int x4 = (blockIdx.x * GW + lane16) * 4;
+  const int zchunks = (D + TO1_ZC - 1) / TO1_ZC;
+  const int rowid = blockIdx.y * (256 / GW) + threadIdx.x / GW;   // over zchunks * H
+  const bool row_ok = rowid < zchunks * H;
+  const int z0 = (row_ok ? rowid / H : 0) * TO1_ZC;
+  const int y = row_ok ? rowid % H : 0;
+  const int n = blockIdx.z;
+  const size_t plane = (size_t)H * W, chan = (size_t)D * plane;
+  const float *inn = in + (size_t)n * 32 * chan;
+  float acc[TO1_ZC][4];
+#pragma unroll
+  for (int r = 0; r < TO1_ZC; ++r)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[r][k] = 0.f;
+  for (int c = 0; c < 32; ++c) {
+    const float *ic = inn + (size_t)c * chan;
+    const float *wc = w + (size_t)c * 27;
+#pragma unroll
+    for (int rz = 0; rz < TO1_ZC + 2; ++rz) {   // input plane z0 - 1 + rz feeds output planes rz-2 .. rz
+      const int zz = z0 - 1 + rz;
+      const bool zok = zz >= 0 && zz < D;
+      float s[3][4];                           // this plane's 3x3 row-convolved sums, one per dz weight slab
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[dz][k] = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const int yy = y + dy - 1;
+        const bool ok = row_ok && zok && yy >= 0 && yy < H && x4 < W;
+        float r6[6];
+        load_row6<GW>(ic + (size_t)(ok ? zz : 0) * plane + (size_t)(ok ? yy : 0) * W, ok, x4, W, lane16, r6);
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz) {
+          const float w0 = wc[dz * 9 + dy * 3], w1 = wc[dz * 9 + dy * 3 + 1], w2 = wc[dz * 9 + dy * 3 + 2];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) s[dz][k] += w0 * r6[k] + w1 * r6[k + 1] + w2 * r6[k + 2];
+        }
+      }
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz) {
+        const int oz = rz - dz;
+        if (oz >= 0 && oz < TO1_ZC) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[oz][k] += s[dz][k];
+        }
+      }
+    }
+  }
+  if (x4 >= W || !row_ok) return;
+  const float b = bias ? bias[0] : 0.0f;
+#pragma unroll
+  for (int r = 0; r < TO1_ZC; ++r) {
+    const int z = z0 + r;
+    if (z >= D) break;
+    floatx4 res;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) res[k] = acc[r][k] + b;
+    *reinterpret_cast<floatx4 *>(out + ((size_t)n * D + z) * plane + (size_t)y * W + x4) = res;
+  }
+}
+
+}  // namespace mvsn
+
+extern "C" int mvsn_conv_to1_supported(int rows, int cols) { return (cols % 4 == 0 && rows > 0) ? 1 : 0; }
+
+extern "C" int mvsn_conv_to1(const float *in, const float *weight, const float *bias, const float *prior,
+                             const float *fx, int n, int depth, int rows, int cols, int kd, float *out,
+                             mvsn_stream_t stream) {
+  MVSN_REQUIRE(in && weight && out, MVSN_E_BADARG, "mvsn_conv_to1: null pointer");
+  MVSN_REQUIRE(n > 0 && depth > 0 && rows > 0 && cols > 0 && (kd == 1 || kd == 3), MVSN_E_BADARG,
+               "mvsn_conv_to1: bad sizes");
+  MVSN_REQUIRE(cols % 4 == 0, MVSN_E_BADARG, "mvsn_conv_to1: cols must be a multiple of 4 (use mvsn_conv_forward)");
+  MVSN_REQUIRE(!prior || (fx && depth == 1), MVSN_E_BADARG, "mvsn_conv_to1: refiner epilogue needs fx and 2-D input");
+  if (kd == 3) {
+    const int zchunks = (depth + mvsn::TO1_ZC - 1) / mvsn::TO1_ZC;
+    const int gw = cols <= 32 ? 8 : 16;
+    const int rows_per_block = 256 / gw;
+    const int row_blocks = (zchunks * rows + rows_per_block - 1) / rows_per_block;
+    MVSN_REQUIRE(n <= 65535 && row_blocks <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_to1: grid");
+    dim3 grid((cols + gw * 4 - 1) / (gw * 4), row_blocks, n);
+    if (gw == 8)
+      hipLaunchKernelGGL(mvsn::conv_to1_3d_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, in, weight, bias, depth,
+                         rows, cols, out);
+    else
+      hipLaunchKernelGGL(mvsn::conv_to1_3d_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, in, weight, bias,
+                         depth, rows, cols, out);
+  } else {
+    MVSN_REQUIRE(depth == 1, MVSN_E_BADARG, "mvsn_conv_to1: kd = 1 needs depth = 1");
+    const int ry = 16 * mvsn::TO1_RY;
+    MVSN_REQUIRE(n <= 65535 && (rows + ry - 1) / ry <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_to1: grid");
+    dim3 grid((cols + 63) / 64, (rows + ry - 1) / ry, n);
+    hipLaunchKernelGGL(mvsn::conv_to1_2d_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, weight, bias, prior, fx,
+                       rows, cols, out);
+  }
+  return mvsn::check_launch("mvsn_conv_to1");
+}

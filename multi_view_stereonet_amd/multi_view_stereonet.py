@@ -45,6 +45,7 @@ class _Conv:
         self.kd, self.kh, self.kw = (k if self.dims == 3 else (1,) + k)
         self.stride, self.dilation = stride, dilation
         self.bias = bias.detach().contiguous().float() if bias is not None else None
+        self.weight = weight.detach().contiguous().float() if self.cout == 1 else None   # mvsn_conv_to1 takes it as is
         d = self.desc(1, 1 if self.dims == 2 else 2, 8, 32)
         n = lib.mvsn_conv_packed_floats(ctypes.byref(d))
         if n == 0:
@@ -159,7 +160,25 @@ class PlaneSweepEngine:
             return out, stats, staged
         return out, stats
 
-    def residual_tower_unfused(self, x, first, blocks, final: _Conv):
+    def conv_to1(self, c: _Conv, x: torch.Tensor, prior: Optional[torch.Tensor] = None,
+                 fx: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """32 -> 1 layer on the vector path (HBM-bound); None when the shape needs the MFMA kernel.
+        With `prior`/`fx` the refiner epilogue relu(prior*fx + conv)/fx is applied in the same pass."""
+        rows, cols = x.shape[-2], x.shape[-1]
+        if c.cin != 32 or c.cout != 1 or c.dilation != 1 or c.stride != 1 or \
+                not self.lib.mvsn_conv_to1_supported(rows, cols):
+            return None
+        n = x.shape[0]
+        depth = x.shape[2] if c.dims == 3 else 1
+        shape = (n, 1, depth, rows, cols) if c.dims == 3 else (n, 1, rows, cols)
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        self._call(f"mvsn_conv_to1[{c.dims}d]", self.lib.mvsn_conv_to1, _native.ptr(x), _native.ptr(c.weight),
+                   _native.ptr(c.bias), _native.ptr(prior), _native.ptr(fx), n, depth, rows, cols,
+                   3 if c.dims == 3 else 1, _native.ptr(out), _native.stream(),
+                   flops=2.0 * 32 * c.kd * 9 * out.numel(), nbytes=4.0 * (x.numel() + out.numel()))
+        return out
+
+    def residual_tower_unfused(self, x, first, blocks, final: _Conv, prior=None, fx=None):
         """Same tower with the normalise/activate/add as a stand-alone float4 pass per block."""
         if first is not None:
             r, st = self.conv(first[0], x, want_stats=True)
@@ -167,8 +186,12 @@ class PlaneSweepEngine:
         for conv, norm in blocks:
             r, st = self.conv(conv, x, want_stats=True)
             x = self.gn_lrelu(r, st, norm, residual=x, out=r)
+        if final.cout == 1:
+            out = self.conv_to1(final, x, prior, fx)
+            if out is not None:
+                return out, prior is not None
         out, _ = self.conv(final, x)
-        return out
+        return out, False
 
     def residual_tower(self, x, first, blocks, final: _Conv):
         """first? -> [x + LReLU(GN(conv(x)))]* -> final conv, with every normalise/activate/add folded
@@ -214,15 +237,21 @@ class PlaneSweepEngine:
             x, _ = self.conv(self.fe_down[i], x)
             pyr.append(x)
         x, _ = self.conv(self.fe_down[3], x)
-        tower = self.residual_tower if self.fold_residual_blocks else self.residual_tower_unfused
-        pyr.append(tower(x, None, self.fe_res, self.fe_final))
+        if self.fold_residual_blocks:
+            pyr.append(self.residual_tower(x, None, self.fe_res, self.fe_final))
+        else:
+            pyr.append(self.residual_tower_unfused(x, None, self.fe_res, self.fe_final)[0])
         return pyr
 
     def cost_volume_filter(self, cost: torch.Tensor) -> torch.Tensor:
         x, st = self.conv(self.vf_convs[0], cost, want_stats=True)
         for i in range(1, 4):
             x, st = self.conv(self.vf_convs[i], x, in_stats=st, in_norm=self.vf_norms[i - 1], want_stats=True)
-        out, _ = self.conv(self.vf_convs[4], x, in_stats=st, in_norm=self.vf_norms[3])
+        last = self.vf_convs[4]
+        if self.lib.mvsn_conv_to1_supported(x.shape[-2], x.shape[-1]):
+            x = self.gn_lrelu(x, st, self.vf_norms[3], out=x)     # materialise once, then the HBM-bound 32->1 pass
+            return self.conv_to1(last, x)[:, 0]
+        out, _ = self.conv(last, x, in_stats=st, in_norm=self.vf_norms[3])
         return out[:, 0]
 
     def idepth_refiner(self, level: int, guide: torch.Tensor, prior: torch.Tensor, fx: torch.Tensor) -> torch.Tensor:
@@ -230,8 +259,13 @@ class PlaneSweepEngine:
         scale = fx.view(-1, 1, 1, 1)
         scaled = prior * scale
         x_in = torch.cat([guide, scaled], 1)
-        tower = self.residual_tower if self.fold_residual_blocks else self.residual_tower_unfused
-        delta = tower(x_in, (p["conv0"], p["bn0"]), p["res"], p["final"])
+        if self.fold_residual_blocks:
+            delta, done = self.residual_tower(x_in, (p["conv0"], p["bn0"]), p["res"], p["final"]), False
+        else:
+            delta, done = self.residual_tower_unfused(x_in, (p["conv0"], p["bn0"]), p["res"], p["final"],
+                                                      prior=prior.contiguous(), fx=fx.contiguous())
+        if done:
+            return delta            # epilogue relu(prior*fx + delta)/fx already applied in the kernel
         return torch.relu(scaled + delta) / scale
 
     def homography_warp(self, image: torch.Tensor, H: torch.Tensor):
@@ -384,6 +418,8 @@ class MultiViewStereoNet(nn.Module):
         build_parameter_tree(self)
         self._engine: Optional[PlaneSweepEngine] = None
         self._engine_key = None
+        self.stream_lanes = 1          # >1: cut the batch into that many slices on separate HIP streams
+        self._lane_streams: List[torch.cuda.Stream] = []
 
     # parameters changed -> packed copies are stale
     def _invalidate(self):
@@ -421,6 +457,40 @@ class MultiViewStereoNet(nn.Module):
         if next(self.parameters()).device != left_image_pyr[0].device:
             raise RuntimeError("module parameters and inputs are on different devices")
         with torch.cuda.device(left_image_pyr[0].device):
-            return self.engine().forward(left_image_pyr, K_pyr, T_right_in_lefts, right_image_pyrs,
-                                         int(num_idepth_samples), bool(do_cost_volume_filter), list(do_refiners),
-                                         capture)
+            eng = self.engine()
+            args = (int(num_idepth_samples), bool(do_cost_volume_filter), list(do_refiners))
+            B = left_image_pyr[0].shape[0]
+            lanes = min(self.stream_lanes, B) if capture is None else 1
+            if lanes <= 1:
+                return eng.forward(left_image_pyr, K_pyr, T_right_in_lefts, right_image_pyrs, *args, capture)
+            return self._forward_lanes(eng, lanes, left_image_pyr, K_pyr, T_right_in_lefts, right_image_pyrs, args)
+
+    def _forward_lanes(self, eng, lanes, left_image_pyr, K_pyr, T_right_in_lefts, right_image_pyrs, args):
+        """Images are independent, so the batch is cut into `lanes` slices that run on their own HIP
+        streams: one slice's HBM-bound kernels (normalise/activate, upsamples) overlap another
+        slice's MFMA-bound convolutions.  All slices join the caller's stream before returning."""
+        B = left_image_pyr[0].shape[0]
+        main = torch.cuda.current_stream()
+        if len(self._lane_streams) < lanes:
+            self._lane_streams = [torch.cuda.Stream() for _ in range(lanes)]
+        bounds = [(B * i) // lanes for i in range(lanes + 1)]
+        parts = []
+        for i in range(lanes):
+            lo, hi = bounds[i], bounds[i + 1]
+            st = self._lane_streams[i]
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                parts.append(eng.forward([x[lo:hi] for x in left_image_pyr], [k[lo:hi] for k in K_pyr],
+                                         [t[lo:hi] for t in T_right_in_lefts],
+                                         [[x[lo:hi] for x in p] for p in right_image_pyrs], *args, None))
+        out = {}
+        for st in self._lane_streams[:lanes]:
+            main.wait_stream(st)
+        for key in parts[0]:
+            out[key] = []
+            for lvl in range(self.num_levels):
+                pieces = [p[key][lvl] for p in parts]
+                for t in pieces:
+                    t.record_stream(main)
+                out[key].append(torch.cat(pieces, 0))
+        return out

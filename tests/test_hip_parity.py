@@ -198,6 +198,30 @@ def test_conv_with_folded_residual_block(rows, cols, dil, cout):
     close(out2, F.conv2d(x0_ref, w, b, padding=dil, dilation=dil), rtol=1e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("dims,depth,rows,cols,n", [(2, 1, 16, 32, 2), (2, 1, 37, 68, 1), (2, 1, 256, 512, 1), (2, 1, 5, 4, 3),
+                                                    (3, 8, 4, 8, 2), (3, 12, 16, 32, 1), (3, 5, 30, 40, 1)])
+def test_conv_to1_vector_path(dims, depth, rows, cols, n):
+    from multi_view_stereonet_amd.multi_view_stereonet import _Conv
+    eng = net_for("gta_sfm_150epochs").engine()
+    g = torch.Generator().manual_seed(rows * 7 + depth)
+    shape = (n, 32, depth, rows, cols) if dims == 3 else (n, 32, rows, cols)
+    x = torch.randn(shape, generator=g)
+    w = torch.randn((1, 32) + (3,) * dims, generator=g) * 0.05
+    b = torch.randn(1, generator=g) * 0.1
+    c = _Conv(eng.lib, w.to(DEV), b.to(DEV))
+    out = eng.conv_to1(c, x.to(DEV))
+    ref = (F.conv3d if dims == 3 else F.conv2d)(x, w, b, padding=1)
+    assert out is not None
+    close(out, ref, rtol=1e-4, atol=1e-4)
+    if dims == 2:
+        prior = torch.rand(n, 1, rows, cols, generator=g) * 3.0
+        fx = torch.rand(n, generator=g) * 50 + 10
+        got = eng.conv_to1(c, x.to(DEV), prior.to(DEV), fx.to(DEV))
+        s = fx.view(-1, 1, 1, 1)
+        close(got, torch.relu(prior * s + ref) / s, rtol=1e-4, atol=1e-5)
+    assert eng.conv_to1(c, torch.zeros(1, 32, 6, 45, device=DEV)) is None if dims == 2 else True   # ragged width -> MFMA kernel
+
+
 def test_cost_volume_filter_and_soft_argmin_golden_unit():
     fix = load_golden("g4_units.npz")
     eng = net_for("gta_sfm_150epochs").engine()
