@@ -107,6 +107,7 @@ def main():
                     help="reference images per GPU per step")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("MVSN_BENCH_LANES", "1")),
                     help="batch slices run on separate HIP streams (images are independent)")
+    ap.add_argument("--fold", action="store_true", help="fold residual blocks into the next conv's tile load")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -121,6 +122,7 @@ def main():
     net.load_state_dict(load_weights(WEIGHTS), strict=True)
     net = net.to(dev).eval()
     net.stream_lanes = args.lanes
+    net.engine().fold_residual_blocks = args.fold
     B = args.batch
     _, inp = make_inputs(B, GOLDEN_SEED + rank * B, dev)
 

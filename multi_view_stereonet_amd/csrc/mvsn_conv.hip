@@ -27,11 +27,13 @@ struct ConvGeom {
   int TZ, TY;           // output tile (TX = 32)
   int HZ, HY, HX, XS;   // staged extent and padded row stride
   int CST;              // channel stride in LDS (floats)
+  int ipc;              // 64-element DMA runs per staged channel
   int ntz, nty, ntx, tiles;
   int ntaps, nchunks;
   int wfloats_chunk;    // ntaps * 2 cout-tiles * 64
   size_t lds_bytes;
   int se;               // staged elements per thread per channel
+  int dma_stage_floats; // LDS-DMA kernel: floats per pipeline stage without the residual tile
 };
 
 static bool make_geom(const mvsn_conv_desc *d, ConvGeom *g) {
@@ -58,9 +60,10 @@ static bool make_geom(const mvsn_conv_desc *d, ConvGeom *g) {
   g->HY = (g->TY - 1) * d->stride + d->dilation * (d->kh - 1) + 1;
   g->HX = (CV_TX - 1) * d->stride + d->dilation * (d->kw - 1) + 1;
   g->XS = g->HX;
-  int cst = g->HZ * g->HY * g->XS;
-  while ((cst & 31) != 16) ++cst;
-  g->CST = cst;
+  // channel stride: whole 64-element DMA runs (the last run may overshoot the tile and lands in the
+  // slot's tail) + 16 so that CST = 16 (mod 32)
+  g->ipc = (g->HZ * g->HY * g->XS + 63) / 64;
+  g->CST = g->ipc * 64 + 16;
   g->ntz = (g->Do + g->TZ - 1) / g->TZ;
   g->nty = (g->Ho + g->TY - 1) / g->TY;
   g->ntx = (g->Wo + CV_TX - 1) / CV_TX;
@@ -70,6 +73,10 @@ static bool make_geom(const mvsn_conv_desc *d, ConvGeom *g) {
   g->wfloats_chunk = g->ntaps * 2 * 64;
   g->lds_bytes = ((size_t)CV_CK * g->CST + g->wfloats_chunk + 64 /*in scale/shift*/ + 64 /*red*/) * sizeof(float);
   g->se = (g->HZ * g->HY * g->HX + CV_THREADS - 1) / CV_THREADS;
+  {
+    const int wslot = ((g->ntaps * 128 + 255) / 256) * 256;
+    g->dma_stage_floats = CV_CK * g->CST + wslot;   // + CV_CK * CST more when a residual tile is staged
+  }
   if (g->se > 6) return false;
   const bool k333 = d->kd == 3 && d->kh == 3 && d->kw == 3 && d->stride == 1;
   const bool k133 = d->kd == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1;
@@ -363,6 +370,287 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA variant (3x3 / 3x3x3, stride 1): the same implicit GEMM, but the haloed chunk tiles and the
+// weight fragments go HBM -> LDS with global_load_lds (no VGPR round trip, no LDS store pass) into a
+// two-stage ring, one barrier per chunk.  Wave w owns channel w of every 4-channel chunk: it issues
+// that channel's 64-element runs (per-lane source address, out-of-image lanes read a zero word), and
+// once its own loads have landed it applies the fused input transform IN LDS on exactly those
+// elements -- LeakyReLU(GN(.)), optionally + residual (a whole SimpleBasicBlock folded into the next
+// layer's load) -- and writes the block output for its own output positions as a by-product.
+//   MODE 0 plain input, 1 LReLU(GN(in)), 2 in_residual + LReLU(GN(in)) [+ out_staged]
+// ---------------------------------------------------------------------------------------------
+__device__ floatx4 g_zero16 = {0.f, 0.f, 0.f, 0.f};
+
+#define MVSN_GPTR(p) ((const __attribute__((address_space(1))) void *)(p))
+#define MVSN_LPTR(p) ((__attribute__((address_space(3))) void *)(p))
+
+template <int NPT, int KD, int IPC, int CT, int MODE>
+__global__ __launch_bounds__(CV_THREADS, 2) void conv_dma_kernel(ConvGeom g, const float *__restrict__ in,
+                                                                 const float *__restrict__ wpk,
+                                                                 const float *__restrict__ bias,
+                                                                 const float *__restrict__ in_stats,
+                                                                 const float *__restrict__ in_gamma,
+                                                                 const float *__restrict__ in_beta,
+                                                                 const float *__restrict__ in_residual,
+                                                                 float *__restrict__ out_staged,
+                                                                 float *__restrict__ out,
+                                                                 float *__restrict__ out_partials) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NTAPS = KD * 9;
+  constexpr int WFL = NTAPS * 128;
+  constexpr int WSLOT = ((WFL + 255) / 256) * 256;
+  constexpr int WRUNS = WSLOT / 256;            // 16-byte DMA runs (256 floats each) per chunk
+  const int tile_floats = CV_CK * g.CST;
+  const int stage_floats = tile_floats * (MODE == 2 ? 2 : 1) + WSLOT;
+  float *scsh = smem + 2 * stage_floats;        // 64
+  float *red = scsh + 64;                       // 16
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = blockIdx.y;
+  int tix = blockIdx.x;
+  const int txi = tix % g.ntx;
+  tix /= g.ntx;
+  const int tyi = tix % g.nty;
+  const int tzi = tix / g.nty;
+  const int z0 = tzi * g.TZ, y0 = tyi * g.TY, x0 = txi * CV_TX;
+  const int gz0 = z0 - g.pd, gy0 = y0 - g.ph, gx0 = x0 - g.pw;
+  const size_t in_plane = (size_t)g.H * g.W, in_chan = (size_t)g.D * in_plane;
+  const float *inn = in + (size_t)n * g.cin * in_chan;
+  const float *resn = (MODE == 2 && in_residual) ? in_residual + (size_t)n * g.cin * in_chan : nullptr;
+  float *stgn = (MODE == 2 && out_staged) ? out_staged + (size_t)n * g.cin * in_chan : nullptr;
+
+  int lpos[NPT], opos[NPT];
+#pragma unroll
+  for (int j = 0; j < NPT; ++j) {
+    const int pt = (tid >> 6) * NPT + j;
+    const int xt = pt & 1, yy = (pt >> 1) % g.TY, zz = (pt >> 1) / g.TY;
+    const int xx = xt * 16 + (lane & 15);
+    const int oz = z0 + zz, oy = y0 + yy, ox = x0 + xx;
+    const bool ok = oz < g.Do && oy < g.Ho && ox < g.Wo;
+    opos[j] = ok ? (oz * g.Ho + oy) * g.Wo + ox : -1;
+    lpos[j] = (zz * g.HY + yy) * g.XS + xx + (lane >> 4) * g.CST;
+  }
+
+  // DMA plan of this lane: run i covers tile elements i*64 .. i*64+63 of the wave's channel
+  int goff[IPC];
+  unsigned inimg = 0, interior = 0;
+  const int tile_elems = g.HZ * g.HY * g.HX;
+#pragma unroll
+  for (int i = 0; i < IPC; ++i) {
+    const int e = i * 64 + lane;
+    int off = -1;
+    if (i < g.ipc && e < tile_elems) {
+      const int row = e / g.HX, x = e - row * g.HX;
+      const int z = row / g.HY, y = row - z * g.HY;
+      const int gz = gz0 + z, gy = gy0 + y, gx = gx0 + x;
+      if (gz >= 0 && gz < g.D && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) {
+        off = (gz * g.H + gy) * g.W + gx;
+        inimg |= 1u << i;
+        if (z >= g.pd && z < g.pd + g.TZ && y >= g.ph && y < g.ph + g.TY && x >= g.pw && x < g.pw + CV_TX)
+          interior |= 1u << i;
+      }
+    }
+    goff[i] = off;
+  }
+
+  if (MODE >= 1 && tid < 32) {
+    const int grp = tid >> 3;
+    const float mean = in_stats[((size_t)n * 4 + grp) * 2 + 0];
+    const float rstd = in_stats[((size_t)n * 4 + grp) * 2 + 1];
+    const float sc = rstd * in_gamma[tid];
+    scsh[tid] = sc;
+    scsh[32 + tid] = in_beta[tid] - mean * sc;
+  }
+
+  const float *zero = reinterpret_cast<const float *>(&g_zero16);
+  auto issue = [&](int chunk, int stage) {
+    float *st = smem + stage * stage_floats;
+    const int c = chunk * CV_CK + wave;                      // this wave's channel
+    const bool cok = c < g.cin;
+    const float *src = inn + (size_t)(cok ? c : 0) * in_chan;
+    float *dst = st + wave * g.CST;
+#pragma unroll
+    for (int i = 0; i < IPC; ++i) {
+      if (i < g.ipc) {  // IPC is a compile-time upper bound; runs past g.ipc would leave the slot
+        const float *p = (cok && goff[i] >= 0) ? src + goff[i] : zero;
+        __builtin_amdgcn_global_load_lds(MVSN_GPTR(p), MVSN_LPTR(dst + i * 64), 4, 0, 0);
+      }
+    }
+    if constexpr (MODE == 2) {
+      const float *rsrc = resn ? resn + (size_t)(cok ? c : 0) * in_chan : nullptr;
+      float *rdst = st + tile_floats + wave * g.CST;
+#pragma unroll
+      for (int i = 0; i < IPC; ++i) {
+        if (i < g.ipc) {
+          const float *p = (rsrc && cok && goff[i] >= 0) ? rsrc + goff[i] : zero;
+          __builtin_amdgcn_global_load_lds(MVSN_GPTR(p), MVSN_LPTR(rdst + i * 64), 4, 0, 0);
+        }
+      }
+    }
+    const float *wsrc = wpk + (size_t)chunk * WFL;
+    float *wdst = st + tile_floats * (MODE == 2 ? 2 : 1);
+#pragma unroll
+    for (int r = 0; r < (WRUNS + CV_WAVES - 1) / CV_WAVES; ++r) {
+      const int run = r * CV_WAVES + wave;
+      if (run < WRUNS) {
+        const int idx = run * 256 + lane * 4;
+        const float *p = idx < WFL ? wsrc + idx : zero;
+        __builtin_amdgcn_global_load_lds(MVSN_GPTR(p), MVSN_LPTR(wdst + run * 256), 16, 0, 0);
+      }
+    }
+  };
+
+  floatx4 acc[NPT][CT];
+#pragma unroll
+  for (int j = 0; j < NPT; ++j)
+#pragma unroll
+    for (int t = 0; t < CT; ++t) acc[j][t] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  issue(0, 0);
+  for (int chunk = 0; chunk < g.nchunks; ++chunk) {
+    const int stage = chunk & 1;
+    float *st = smem + stage * stage_floats;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA runs for `chunk` have landed
+    if constexpr (MODE >= 1) {
+      // fused input transform on the elements this wave loaded (its channel of the chunk)
+      if (chunk == 0) __syncthreads();   // scsh visible
+      const int c = chunk * CV_CK + wave;
+      if (c < g.cin) {
+        const float sc = scsh[c], sh = scsh[32 + c];
+        float *tl = st + wave * g.CST + lane;
+        float *stg = stgn ? stgn + (size_t)c * in_chan : nullptr;
+#pragma unroll
+        for (int i = 0; i < IPC; ++i) {
+          if ((inimg >> i) & 1u) {
+            float v = lrelu02(tl[i * 64] * sc + sh);
+            if constexpr (MODE == 2) v += tl[tile_floats + i * 64];
+            tl[i * 64] = v;
+            if (MODE == 2 && stg && ((interior >> i) & 1u)) stg[goff[i]] = v;
+          }
+        }
+      }
+    }
+    __syncthreads();  // every wave's channel is in place; everyone is done with the other stage
+    if (chunk + 1 < g.nchunks) issue(chunk + 1, stage ^ 1);
+
+    const float *tile = st;
+    const float *wt = st + tile_floats * (MODE == 2 ? 2 : 1) + lane;
+#pragma unroll
+    for (int tz = 0; tz < KD; ++tz)
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx) {
+          const int tap = (tz * 3 + ty) * 3 + tx;
+          const float *bp = tile + (tz * g.HY + ty * g.dil) * g.XS + tx * g.dil;
+          const float w0 = wt[tap * 128];
+          const float w1 = CT == 2 ? wt[tap * 128 + 64] : 0.0f;
+#pragma unroll
+          for (int j = 0; j < NPT; ++j) {
+            const float b = bp[lpos[j]];
+            acc[j][0] = mfma16x16x4(w0, b, acc[j][0]);
+            if (CT == 2) acc[j][CT - 1] = mfma16x16x4(w1, b, acc[j][CT - 1]);
+          }
+        }
+  }
+
+  // ---- epilogue (same as the register-staged kernel) -----------------------------------------
+  const int cbase = (lane >> 4) * 4;
+  const size_t out_chan = (size_t)g.Do * g.Ho * g.Wo;
+  float *outn = out + (size_t)n * g.cout * out_chan;
+  float s[2] = {0.f, 0.f};
+  int cnt = 0;
+#pragma unroll
+  for (int j = 0; j < NPT; ++j) {
+    const bool ok = opos[j] >= 0;
+    if (ok) cnt += 1;
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = t * 16 + cbase + r;
+        if (c < g.cout) {
+          const float v = acc[j][t][r] + (bias ? bias[c] : 0.0f);
+          acc[j][t][r] = v;
+          if (ok) {
+            outn[(size_t)c * out_chan + opos[j]] = v;
+            s[t] += v;
+          }
+        }
+      }
+  }
+  if (out_partials == nullptr) return;
+  if (CT != 2) return;
+  auto half_wave_sum = [&](float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    return v;
+  };
+  const int hi = lane >> 5;
+  const int wv = tid >> 6;
+  int cnt_tile;
+  {
+    float c = (lane < 16) ? (float)cnt : 0.0f;
+    c = half_wave_sum(c);
+    __syncthreads();
+    if (lane == 0) red[wv] = c;
+    __syncthreads();
+    cnt_tile = (int)(red[0] + red[1] + red[2] + red[3]);
+    __syncthreads();
+  }
+  const float npos = (float)cnt_tile * 8.0f;
+  float m[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) s[t] = half_wave_sum(s[t]);
+  if ((lane & 31) == 0) {
+    red[wv * 4 + 0 + hi] = s[0];
+    red[wv * 4 + 2 + hi] = s[1];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float tot = 0.f;
+    for (int w = 0; w < CV_WAVES; ++w) tot += red[w * 4 + t * 2 + hi];
+    m[t] = cnt_tile > 0 ? tot / npos : 0.0f;
+  }
+  __syncthreads();
+  float q[2] = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < NPT; ++j)
+    if (opos[j] >= 0) {
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float dv = acc[j][t][r] - m[t];
+          q[t] += dv * dv;
+        }
+    }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) q[t] = half_wave_sum(q[t]);
+  if ((lane & 31) == 0) {
+    red[wv * 4 + 0 + hi] = q[0];
+    red[wv * 4 + 2 + hi] = q[1];
+  }
+  __syncthreads();
+  if (wv == 0 && (lane & 31) == 0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float tot = 0.f;
+      for (int w = 0; w < CV_WAVES; ++w) tot += red[w * 4 + t * 2 + hi];
+      float *p = out_partials + (((size_t)n * g.tiles + blockIdx.x) * 4 + (t * 2 + hi)) * 3;
+      p[0] = npos;
+      p[1] = m[t];
+      p[2] = tot;
+    }
+  }
+}
+
 // Chan et al. combination of per-tile (count, mean, M2) in double; one workgroup per (n, group).
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restrict__ partials, int tiles,
                                                           float *__restrict__ stats) {
@@ -502,6 +790,54 @@ extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, co
                "mvsn_conv_forward: residual / staged output only for 2-D 3x3 stride-1 layers");
   MVSN_REQUIRE(g.n <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_forward: batch too large for one launch");
   dim3 grid(g.tiles, g.n);
+  static_assert(CV_CK == CV_WAVES, "one DMA channel per wave");
+  // ---- LDS-DMA pipeline for the 2-D 3x3 stride-1 layers with dilation <= 4 ---------------------
+  // (measured on MI355X, B=128: 2-5 % faster than register staging there, 7 % slower on the 3-D
+  // layers where the in-LDS transform pass is exposed, and 8 % slower at dilation 8)
+  if (g.kd == 1 && g.kh == 3 && g.stride == 1 && g.dil <= 4) {
+    const int mode = (in_residual || out_staged) ? 2 : (in_stats ? 1 : 0);
+    const size_t stage = (size_t)g.dma_stage_floats + (mode == 2 ? (size_t)CV_CK * g.CST : 0);
+    const size_t lds = (2 * stage + 64 + 16) * sizeof(float);
+    const bool one = g.cout <= 16;
+#define MVSN_DMA_LAUNCH(...)                                                                                      \
+  do {                                                                                                            \
+    auto kern = conv_dma_kernel<__VA_ARGS__>;                                                                     \
+    static size_t opted = 0;                                                                                      \
+    if (lds > opted) {                                                                                            \
+      hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) {                                                                                      \
+        set_error("mvsn_conv_forward: LDS opt-in of %zu bytes failed: %s", lds, hipGetErrorString(e));            \
+        return (int)e;                                                                                            \
+      }                                                                                                           \
+      opted = lds;                                                                                                \
+    }                                                                                                             \
+    hipLaunchKernelGGL(kern, grid, dim3(CV_THREADS), lds, (hipStream_t)stream, g, in, weight_packed, bias, in_stats, \
+                       in_gamma, in_beta, in_residual, out_staged, out, out_partials);                            \
+    return check_launch("mvsn_conv_forward(dma)");                                                                \
+  } while (0)
+#define MVSN_DMA_MODES(NPTV, KDV, IPCV)                                                          \
+  do {                                                                                           \
+    if (one) {                                                                                   \
+      if (mode == 0) MVSN_DMA_LAUNCH(NPTV, KDV, IPCV, 1, 0);                                     \
+      else if (mode == 1) MVSN_DMA_LAUNCH(NPTV, KDV, IPCV, 1, 1);                                \
+      else MVSN_DMA_LAUNCH(NPTV, KDV, IPCV, 1, 2);                                               \
+    } else {                                                                                     \
+      if (mode == 0) MVSN_DMA_LAUNCH(NPTV, KDV, IPCV, 2, 0);                                     \
+      else if (mode == 1) MVSN_DMA_LAUNCH(NPTV, KDV, IPCV, 2, 1);                                \
+      else MVSN_DMA_LAUNCH(NPTV, KDV, IPCV, 2, 2);                                               \
+    }                                                                                            \
+  } while (0)
+    if (lds <= 160 * 1024) {
+      if (g.TY == 16) {
+        if (g.ipc <= 12) MVSN_DMA_MODES(8, 1, 12);
+      } else {
+        if (g.ipc <= 12) MVSN_DMA_MODES(4, 1, 12);
+        else if (g.ipc <= 18) MVSN_DMA_MODES(4, 1, 18);
+      }
+    }
+#undef MVSN_DMA_MODES
+#undef MVSN_DMA_LAUNCH
+  }
 #define MVSN_CONV_LAUNCH(...)                                                                                    \
   do {                                                                                                           \
     auto kern = conv_mfma_kernel<__VA_ARGS__>;                                                                   \
