@@ -79,14 +79,22 @@ def cpu_baseline(budget_s=20.0):
     batch = synthetic.make_batch(ROWS, COLS, S, batch=1, seed=GOLDEN_SEED)
     inp = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    torch.set_num_threads(threads)
 
     def once():
         t0 = time.time()
         out = oracle.forward(w, inp["left_image_pyr"], inp["K_pyr"], inp["T_right_in_left"], inp["right_image_pyr"], D)
         return time.time() - t0, out
 
+    # torch's intra-op scaling on this small per-image problem peaks well below the core count; take the
+    # best of a short sweep and report the thread count actually used
+    best, threads = None, 1
+    for cand in [c for c in (8, 16, 32, 64) if c <= cores] or [cores]:
+        torch.set_num_threads(cand)
+        once()
+        dt = min(once()[0] for _ in range(2))
+        if best is None or dt < best:
+            best, threads = dt, cand
+    torch.set_num_threads(threads)
     once()  # warm-up
     times, t_start = [], time.time()
     while len(times) < 3 or (time.time() - t_start < budget_s and len(times) < 50):

@@ -710,7 +710,30 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
   const long stride = (long)gridDim.x * blockDim.x * 4;
   const bool vec_ok = (spatial & 3) == 0;
   if (vec_ok) {
-    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < spatial; i += stride) {
+    // streaming pass: non-temporal 16-byte accesses, two independent iterations in flight per thread
+    long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    for (; i + stride < spatial; i += 2 * stride) {
+      const floatx4 v0 = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(xp + i));
+      const floatx4 v1 = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(xp + i + stride));
+      floatx4 o0, o1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        o0[k] = lrelu02(v0[k] * sc + sh);
+        o1[k] = lrelu02(v1[k] * sc + sh);
+      }
+      if (rp) {
+        const floatx4 r0 = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(rp + i));
+        const floatx4 r1 = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(rp + i + stride));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          o0[k] += r0[k];
+          o1[k] += r1[k];
+        }
+      }
+      *reinterpret_cast<floatx4 *>(op + i) = o0;
+      *reinterpret_cast<floatx4 *>(op + i + stride) = o1;
+    }
+    for (; i < spatial; i += stride) {
       floatx4 v = *reinterpret_cast<const floatx4 *>(xp + i);
       floatx4 o;
 #pragma unroll
@@ -893,8 +916,8 @@ extern "C" int mvsn_groupnorm_lrelu_apply(const float *x, const float *stats, co
   MVSN_REQUIRE(x && stats && gamma && beta && out && n > 0 && spatial > 0, MVSN_E_BADARG,
                "mvsn_groupnorm_lrelu_apply: bad argument");
   MVSN_REQUIRE((long)n * 32 <= 65535, MVSN_E_TOOLARGE, "mvsn_groupnorm_lrelu_apply: batch too large for one launch");
-  long per = (spatial + 1023) / 1024;
-  int gx = (int)(per < 1 ? 1 : (per > 64 ? 64 : per));
+  long per = (spatial + 2047) / 2048;
+  int gx = (int)(per < 1 ? 1 : (per > 16 ? 16 : per));
   hipLaunchKernelGGL(mvsn::gn_apply_kernel, dim3(gx, n * 32), dim3(256), 0, (hipStream_t)stream, x, stats, gamma,
                      beta, residual, spatial, out);
   return mvsn::check_launch("mvsn_groupnorm_lrelu_apply");

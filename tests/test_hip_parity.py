@@ -430,6 +430,24 @@ def test_forward_config5_shape_vs_oracle():
         assert diff <= 2 * 4 ** (4 - lvl), (lvl, diff)
 
 
+def test_graph_replay_matches_eager():
+    """hipGraph capture of the whole forward: replay on new inputs equals the eager launch sequence."""
+    from multi_view_stereonet_amd.graphed import GraphedForward
+    net = net_for("gta_sfm_150epochs")
+    inp_a = snu.multi_view_unpack_batch(synthetic.make_batch(128, 256, 2, batch=2, seed=51), torch.device(DEV), 5)
+    inp_b = snu.multi_view_unpack_batch(synthetic.make_batch(128, 256, 2, batch=2, seed=52, smooth=True),
+                                        torch.device(DEV), 5)
+    pack = lambda i: (i["left_image_pyr"], i["K_pyr"], i["T_right_in_left"], i["right_image_pyr"])
+    g = GraphedForward(net, *pack(inp_a), 16)
+    eager_b = net(*pack(inp_b), 16, True, [True] * 5)
+    out_b = g(*pack(inp_b))
+    assert torch.equal(out_b["left_idepthmap_pyr"][0], eager_b["left_idepthmap_pyr"][0])
+    assert torch.equal(out_b["left_idepthmap_mask_pyr"][0], eager_b["left_idepthmap_mask_pyr"][0])
+    eager_a = net(*pack(inp_a), 16, True, [True] * 5)
+    out_a = g(*pack(inp_a))
+    assert torch.equal(out_a["left_idepthmap_pyr"][0], eager_a["left_idepthmap_pyr"][0])
+
+
 def test_forward_vs_oracle_small_batch():
     """Fresh seeds (no fixture): HIP forward vs the oracle run here on the host."""
     wname = "gta_sfm_150epochs"
