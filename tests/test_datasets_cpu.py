@@ -1,0 +1,102 @@
+"""dataset readers + evaluation transforms on miniature datasets written in the
+reference's on-disk formats (the real data is not available; known-answer tests only)."""
+import os
+
+import numpy as np
+import torch
+from PIL import Image
+
+from multi_view_stereonet_amd import datasets as ds
+from multi_view_stereonet_amd import multi_view_stereonet_utils as snu
+
+
+def _jpg(path, rows, cols, seed):
+    rng = np.random.default_rng(seed)
+    Image.fromarray(rng.integers(0, 255, size=(rows, cols, 3), dtype=np.uint8), "RGB").save(path, quality=95)
+
+
+def _pose(tx, ang):
+    T = np.eye(4, dtype=np.float32)
+    T[0, 0], T[0, 2], T[2, 0], T[2, 2] = np.cos(ang), np.sin(ang), -np.sin(ang), np.cos(ang)
+    T[0, 3] = tx
+    return T
+
+
+def test_gta_sfm_reader(tmp_path):
+    root = tmp_path / "gta"
+    seq = root / "scene_a" / "0001"
+    (seq / "images").mkdir(parents=True)
+    (seq / "depth").mkdir()
+    ids = [3, 4, 7]
+    poses = {i: _pose(0.4 * i, 0.02 * i) for i in ids}
+    with open(seq / "intrinsics.txt", "w") as f, open(seq / "poses.txt", "w") as g:
+        f.write("id k00 k01 k02 k10 k11 k12 k20 k21 k22\n")
+        g.write("id p...\n")
+        for i in ids:
+            f.write(f"{i} 100 0 40 0 100 30 0 0 1\n")
+            g.write(str(i) + " " + " ".join(f"{v:.8f}" for v in poses[i].reshape(-1)) + "\n")
+            _jpg(seq / "images" / f"{i:04d}.jpg", 60, 80, i)
+            np.save(seq / "depth" / f"{i:04d}.npy", np.full((60, 80), 2.0 + i, np.float32))
+    split = tmp_path / "split.txt"
+    split.write_text("scene_a/0001/images/0004.jpg scene_a/0001/images/0003.jpg scene_a/0001/images/0007.jpg\n")
+    assert ds.read_images(str(split)) == (["scene_a/0001/images/0004.jpg"],
+                                          [["scene_a/0001/images/0003.jpg", "scene_a/0001/images/0007.jpg"]])
+    params = {"size": [30, 40]}
+    data = ds.GTASfMMultiViewStereoDataset(str(root), str(split), transform=ds.get_testing_transforms(params),
+                                           load_groundtruth_depthmaps=True, shuffle_on_read=False)
+    assert len(data) == 1
+    s = data[0]
+    assert s["left_image"].shape == (3, 30, 40) and s["left_image"].min() >= -1 and s["left_image"].max() <= 1
+    assert len(s["right_image"]) == 2 and s["K"].shape == (1, 4, 4)
+    # principal point fix (-0.5) then the resize scaling of the first two rows by 0.5
+    K = s["K"][0]
+    assert torch.allclose(K[0, :3], torch.tensor([50.0, 0.0, 19.75])) and torch.allclose(K[1, :3], torch.tensor([0.0, 50.0, 14.75]))
+    want = np.linalg.inv(poses[4]) @ poses[7]
+    assert np.allclose(s["T_right_in_left"][1][0].numpy(), want, atol=1e-5)
+    assert s["left_depthmap_true"].shape == (1, 60, 80) and float(s["left_depthmap_true"][0, 0, 0]) == 6.0   # not resized
+    # DataLoader batch -> the forward's inputs
+    batch = next(iter(torch.utils.data.DataLoader(data, batch_size=1)))
+    inp = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
+    assert inp["left_image_pyr"][4].shape == (1, 3, 2, 3) and len(inp["T_right_in_left"]) == 2
+    assert torch.allclose(inp["T_right_in_left"][0][:, :3, 3].norm(dim=1), torch.ones(1), atol=1e-6)
+    assert inp["left_depthmap_true"].shape == (1, 1, 60, 80)
+
+
+def test_demon_reader(tmp_path):
+    root = tmp_path / "demon"
+    scene = root / "scene_1"
+    scene.mkdir(parents=True)
+    n = 5
+    (scene / "cam.txt").write_text("120 0 31.5\n0 120 23.5\n0 0 1\n")
+    world_in = [_pose(0.1 * i, 0.01 * i) for i in range(n)]
+    with open(scene / "poses.txt", "w") as f:
+        for T in world_in:
+            f.write(" ".join(f"{v:.8f}" for v in T[:3].reshape(-1)) + "\n")
+    for i in range(n):
+        _jpg(scene / f"{i:07d}.jpg", 48, 64, 10 + i)
+        np.save(scene / f"{i:07d}.npy", np.full((48, 64), 1.0 + i, np.float32))
+    (root / "test.txt").write_text("scene_1\n")
+    data = ds.DeMoNDataset(str(root), "test.txt", num_right_images=2, transform=ds.get_testing_transforms({"size": [48, 64]}),
+                           shuffle_on_read=False)
+    assert len(data) == n
+    # neighbour windows: clamped at both ends, centred otherwise
+    assert ds.DeMoNDataset.neighbour_indices(0, 5, 2) == [1, 2]
+    assert ds.DeMoNDataset.neighbour_indices(2, 5, 2) == [1, 3]
+    assert ds.DeMoNDataset.neighbour_indices(4, 5, 2) == [2, 3]
+    assert ds.DeMoNDataset.neighbour_indices(3, 6, 1) == [2] or ds.DeMoNDataset.neighbour_indices(3, 6, 1) == [4]
+    s = data[2]
+    assert [os.path.basename(f) for f in s["right_filename"]] == ["0000001.jpg", "0000003.jpg"]
+    want = world_in[2] @ np.linalg.inv(world_in[3])
+    assert np.allclose(s["T_right_in_left"][1][0].numpy(), want, atol=1e-5)
+    assert torch.allclose(s["K"][0, :2, :3], torch.tensor([[120.0, 0.0, 31.5], [0.0, 120.0, 23.5]]))
+    assert float(s["left_depthmap_true"][0, 0, 0]) == 3.0 and len(s["right_depthmap_true"]) == 2
+
+
+def test_transforms_known_answers():
+    img = Image.fromarray(np.full((10, 20, 3), 255, np.uint8), "RGB")
+    sample = {"left_image": img, "right_image": [img.copy()], "K": np.eye(4, dtype=np.float32) * 2,
+              "T_right_in_left": [np.eye(4, dtype=np.float32)]}
+    out = ds.get_testing_transforms({"size": [5, 40]})(sample)
+    assert out["left_image"].shape == (3, 5, 40) and torch.allclose(out["left_image"], torch.ones(3, 5, 40))
+    assert torch.allclose(out["K"][0].diagonal(), torch.tensor([4.0, 1.0, 2.0, 2.0]))      # x2 cols, x0.5 rows
+    assert out["T_right_in_left"][0].shape == (1, 4, 4)

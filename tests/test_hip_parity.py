@@ -430,6 +430,38 @@ def test_forward_config5_shape_vs_oracle():
         assert diff <= 2 * 4 ** (4 - lvl), (lvl, diff)
 
 
+def test_evaluate_cli_on_miniature_dataset(tmp_path):
+    """datasets -> multi_view_unpack_batch (device) -> HIP forward -> depth metrics, end to end."""
+    import json
+    import numpy as np
+    from PIL import Image
+    from multi_view_stereonet_amd import evaluate
+    root = tmp_path / "gta"
+    seq = root / "scene" / "0000"
+    (seq / "images").mkdir(parents=True)
+    (seq / "depth").mkdir()
+    rng = np.random.default_rng(0)
+    with open(seq / "intrinsics.txt", "w") as f, open(seq / "poses.txt", "w") as g:
+        f.write("id K\n")
+        g.write("id T\n")
+        for i in range(3):
+            T = np.eye(4, dtype=np.float32)
+            T[0, 3] = 0.3 * i
+            f.write(f"{i} 200 0 128.5 0 200 64.5 0 0 1\n")
+            g.write(str(i) + " " + " ".join(str(v) for v in T.reshape(-1)) + "\n")
+            Image.fromarray(rng.integers(0, 255, (128, 256, 3), dtype=np.uint8), "RGB").save(seq / "images" / f"{i:04d}.jpg")
+            np.save(seq / "depth" / f"{i:04d}.npy", np.full((128, 256), 5.0, np.float32))
+    split = tmp_path / "split.txt"
+    split.write_text("scene/0000/images/0001.jpg scene/0000/images/0000.jpg scene/0000/images/0002.jpg\n"
+                     "scene/0000/images/0000.jpg scene/0000/images/0001.jpg scene/0000/images/0002.jpg\n")
+    out_dir = tmp_path / "out"
+    evaluate.main(["gta_sfm_150epochs", str(root), str(split), "--size", "128", "256", "--num_idepth_samples", "8",
+                   "--output_dir", str(out_dir)])
+    txt = (out_dir / "avg_depth_metrics.txt").read_text().split("\n")
+    vals = dict(zip(txt[0].split(), (float(v) for v in txt[1].split())))
+    assert set(["abs_rel", "rmse", "a1", "runtime_ms"]) <= set(vals) and all(np.isfinite(list(vals.values())))
+
+
 def test_graph_replay_matches_eager():
     """hipGraph capture of the whole forward: replay on new inputs equals the eager launch sequence."""
     from multi_view_stereonet_amd.graphed import GraphedForward
