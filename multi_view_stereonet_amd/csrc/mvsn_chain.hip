@@ -115,6 +115,64 @@ __device__ __forceinline__ void conv3x3_mfma(const float *__restrict__ act, cons
   }
 }
 
+// Same convolution when the activation planes live in the global workspace (coarse grids that do not
+// fit LDS): each 4-channel slab (with its halo guards) is staged into one of two LDS buffers while the
+// previous slab's 9 taps run, so the MFMA loop still reads its B fragments from LDS.  One barrier per
+// slab.  `slab` holds 2 x slab_floats, slab_floats = G + 4*CS.
+template <int TP, int NC>
+__device__ __forceinline__ void conv3x3_mfma_slab(const float *__restrict__ act, const float *__restrict__ wbuf,
+                                                  float *__restrict__ slab, int CS, int RS, const int (&qb)[TP],
+                                                  int tid, floatx4 (&acc)[TP][2]) {
+  const int lane = tid & 63;
+  const int G = RS + 1;
+  const int slab_floats = G + 4 * CS;
+  constexpr int PER = 9;  // staged floats per thread per slab (<= 9216 floats per slab)
+#pragma unroll
+  for (int j = 0; j < TP; ++j) {
+    acc[j][0] = floatx4{0.f, 0.f, 0.f, 0.f};
+    acc[j][1] = floatx4{0.f, 0.f, 0.f, 0.f};
+  }
+  float stage[PER];
+  auto fetch = [&](int c4) {
+    const float *src = act + c4 * 4 * CS - G;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + k * CH_THREADS;
+      stage[k] = i < slab_floats ? src[i] : 0.0f;
+    }
+  };
+  auto commit = [&](int buf) {
+    float *dst = slab + buf * slab_floats;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + k * CH_THREADS;
+      if (i < slab_floats) dst[i] = stage[k];
+    }
+  };
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  for (int c4 = 0; c4 < NC; ++c4) {
+    if (c4 + 1 < NC) fetch(c4 + 1);
+    const float *sb = slab + (c4 & 1) * slab_floats + G + (lane >> 4) * CS;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int off = (tap / 3 - 1) * RS + (tap % 3 - 1);
+      const float *wt = wbuf + (tap * NC + c4) * 128 + lane;
+      const float w0 = wt[0];
+      const float w1 = wt[64];
+#pragma unroll
+      for (int j = 0; j < TP; ++j) {
+        const float b = sb[qb[j] + off];
+        acc[j][0] = mfma16x16x4(w0, b, acc[j][0]);
+        acc[j][1] = mfma16x16x4(w1, b, acc[j][1]);
+      }
+    }
+    if (c4 + 1 < NC) commit((c4 + 1) & 1);
+    __syncthreads();
+  }
+}
+
 // Sum `v[t]` (t = 0,1: the two cout tiles) over the whole workgroup, per GroupNorm group.
 // Lanes 0..31 of a wave hold channels of group 2t, lanes 32..63 of group 2t+1.
 __device__ __forceinline__ void block_group_sum(float (&v)[2], float *red_slab, int lane, int wave) {
@@ -220,11 +278,13 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a) {
   float *maskb = red + RED_FLOATS;
   const int Ppad = (P + 3) & ~3;
   float *act;
+  float *slab = nullptr;
   const int act_floats = G + 36 * CS;
   if constexpr (LDS_ACT) {
     act = maskb + Ppad + G;
   } else {
     act = a.workspace + (size_t)n * act_floats + G;
+    slab = maskb + Ppad;   // 2 x (G + 4*CS) floats
   }
 
   // ---- one-time set-up ---------------------------------------------------------------------
@@ -400,7 +460,8 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a) {
 
     floatx4 acc[TP][2];
     load_weights_to_regs<W1_FLOATS>(a.packed + W0_FLOATS, wreg, tid);  // in flight behind the MFMAs
-    conv3x3_mfma<TP, 9>(act, wbuf, CS, RS, qb, lane, acc);
+    if constexpr (LDS_ACT) conv3x3_mfma<TP, 9>(act, wbuf, CS, RS, qb, lane, acc);
+    else conv3x3_mfma_slab<TP, 9>(act, wbuf, slab, CS, RS, qb, tid, acc);
     MVSN_STAMP(4);
     __syncthreads();  // B3: act and wbuf free
     MVSN_STAMP(5);
@@ -420,7 +481,8 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a) {
     MVSN_STAMP(6);
 
     load_weights_to_regs<W1_FLOATS>(a.packed + W0_FLOATS + W1_FLOATS, wreg, tid);
-    conv3x3_mfma<TP, 8>(act, wbuf, CS, RS, qb, lane, acc);
+    if constexpr (LDS_ACT) conv3x3_mfma<TP, 8>(act, wbuf, CS, RS, qb, lane, acc);
+    else conv3x3_mfma_slab<TP, 8>(act, wbuf, slab, CS, RS, qb, tid, acc);
     MVSN_STAMP(7);
     __syncthreads();  // B7
     MVSN_STAMP(8);
@@ -439,7 +501,8 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a) {
     __syncthreads();  // B10
     MVSN_STAMP(9);
 
-    conv3x3_mfma<TP, 8>(act, wbuf, CS, RS, qb, lane, acc);
+    if constexpr (LDS_ACT) conv3x3_mfma<TP, 8>(act, wbuf, CS, RS, qb, lane, acc);
+    else conv3x3_mfma_slab<TP, 8>(act, wbuf, slab, CS, RS, qb, tid, acc);
     MVSN_STAMP(10);
     __syncthreads();  // B11
     MVSN_STAMP(11);
@@ -465,10 +528,11 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a) {
   write_cost_slice(D - 1);
 }
 
-static size_t chain_lds_bytes(int P, int act_floats, bool lds_act) {
+static size_t chain_lds_bytes(int P, int act_floats, bool lds_act, int slab_floats = 0) {
   const int Ppad = (P + 3) & ~3;
   size_t f = (size_t)W0_FLOATS + SP_FLOATS + RED_FLOATS + Ppad;
   if (lds_act) f += act_floats;
+  else f += 2 * (size_t)slab_floats;
   return f * sizeof(float);
 }
 
@@ -547,7 +611,10 @@ extern "C" int mvsn_incremental_cost_volume(const float *src_image_lvl4, const f
   MVSN_REQUIRE(lds_act || (workspace && workspace_bytes >= need), MVSN_E_WORKSPACE,
                "mvsn_incremental_cost_volume: workspace of %zu bytes required", need);
   a.workspace = lds_act ? nullptr : (float *)workspace;
-  const size_t lds = chain_lds_bytes(P, act_floats, lds_act);
+  const int slab_floats = (cols + 2) + 4 * a.CS;
+  MVSN_REQUIRE(lds_act || slab_floats <= 9 * CH_THREADS, MVSN_E_TOOLARGE,
+               "mvsn_incremental_cost_volume: coarse grid too large for the slab staging plan");
+  const size_t lds = chain_lds_bytes(P, act_floats, lds_act, slab_floats);
 
 #define MVSN_CHAIN_LAUNCH(TPV, LDSV)                                                                           \
   do {                                                                                                         \

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Timing of the BASELINE.json configs that are parity cases rather than the bench line (GPU box)."""
+import os, sys, time, json, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multi_view_stereonet_amd import MultiViewStereoNet, synthetic
+from multi_view_stereonet_amd import multi_view_stereonet_utils as snu
+from multi_view_stereonet_amd.weights import load_weights
+torch.set_grad_enabled(False)
+CONFIGS = [("config 2: GTA 512x256 D=64 S=1", "gta_sfm_150epochs", 256, 512, 64, 1, (1, 64)),
+           ("config 3: GTA 512x256 D=64 S=5", "gta_sfm_150epochs", 256, 512, 64, 5, (1, 8, 48)),
+           ("config 4: DeMoN 640x480 D=96 S=1", "demon_45epochs", 480, 640, 96, 1, (1, 32)),
+           ("config 5 geometry: 1024x512 D=128 S=4 (fp32)", "gta_sfm_150epochs", 512, 1024, 128, 4, (1, 8)),
+           ("headline: GTA 512x256 D=64 S=2", "gta_sfm_150epochs", 256, 512, 64, 2, (1, 8, 128))]
+out = []
+for name, wname, rows, cols, D, S, batches in CONFIGS:
+    net = MultiViewStereoNet(); net.load_state_dict(load_weights(wname)); net = net.cuda().eval()
+    for B in batches:
+        parts = [synthetic.make_batch(rows, cols, S, batch=1, seed=100 + i) for i in range(B)]
+        merged = {"left_image": torch.cat([p["left_image"] for p in parts]),
+                  "right_image": [torch.cat([p["right_image"][s] for p in parts]) for s in range(S)],
+                  "K": torch.cat([p["K"] for p in parts]),
+                  "T_right_in_left": [torch.cat([p["T_right_in_left"][s] for p in parts]) for s in range(S)]}
+        inp = snu.multi_view_unpack_batch(merged, torch.device("cuda"), 5)
+        f = lambda: net(inp["left_image_pyr"], inp["K_pyr"], inp["T_right_in_left"], inp["right_image_pyr"], D, True, [True] * 5)
+        torch.cuda.reset_peak_memory_stats()
+        f(); f(); torch.cuda.synchronize()
+        t0 = time.perf_counter(); n = 3
+        for _ in range(n): o = f()
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+        rec = {"config": name, "batch": B, "ms_per_forward": round(dt * 1e3, 2), "depthmaps_per_s": round(B / dt, 1),
+               "peak_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+               "finite": bool(torch.isfinite(o["left_idepthmap_pyr"][0]).all())}
+        print(json.dumps(rec)); out.append(rec)
+    del net; torch.cuda.empty_cache()
+json.dump(out, open("gpurun_out/config_timings.json", "w"), indent=1)
