@@ -99,6 +99,15 @@ __global__ void conv_pack_kernel(const float *__restrict__ w, int cin, int cout,
   out[i] = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * ntaps + tap] : 0.0f;
 }
 
+// Workgroup b is observed to run on XCD b % 8, each XCD with its own L2.  Neighbouring tiles share halo
+// rows, so hand each XCD a contiguous range of tiles instead of every 8th one (bijective for any tile
+// count; placement only affects speed, never results).
+__device__ __forceinline__ int xcd_tile_index(int bid, int tiles) {
+  const int q = tiles >> 3, r = tiles & 7;
+  const int xcd = bid & 7, k = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 // NPT   pixel tiles (16 output columns each) per wave = TZ*TY*2/4
 // KD/KH/KW/STRIDE compile-time so the tap loops unroll completely and LDS reads run ahead of the MFMAs
 // SE    staged input elements per thread per channel (upper bound, ceil(HZ*HY*HX/256))
@@ -133,7 +142,8 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = blockIdx.y;
-  int tix = blockIdx.x;
+  const int tile_id = xcd_tile_index(blockIdx.x, g.tiles);
+  int tix = tile_id;
   const int txi = tix % g.ntx;
   tix /= g.ntx;
   const int tyi = tix % g.nty;
@@ -362,7 +372,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
     for (int t = 0; t < 2; ++t) {
       float tot = 0.f;
       for (int w = 0; w < CV_WAVES; ++w) tot += red[w * 4 + t * 2 + hi];
-      float *p = out_partials + (((size_t)n * g.tiles + blockIdx.x) * 4 + (t * 2 + hi)) * 3;
+      float *p = out_partials + (((size_t)n * g.tiles + tile_id) * 4 + (t * 2 + hi)) * 3;
       p[0] = npos;
       p[1] = m[t];
       p[2] = tot;
@@ -409,7 +419,8 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_dma_kernel(ConvGeom g, con
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = blockIdx.y;
-  int tix = blockIdx.x;
+  const int tile_id = xcd_tile_index(blockIdx.x, g.tiles);
+  int tix = tile_id;
   const int txi = tix % g.ntx;
   tix /= g.ntx;
   const int tyi = tix % g.nty;
@@ -643,7 +654,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_dma_kernel(ConvGeom g, con
     for (int t = 0; t < 2; ++t) {
       float tot = 0.f;
       for (int w = 0; w < CV_WAVES; ++w) tot += red[w * 4 + t * 2 + hi];
-      float *p = out_partials + (((size_t)n * g.tiles + blockIdx.x) * 4 + (t * 2 + hi)) * 3;
+      float *p = out_partials + (((size_t)n * g.tiles + tile_id) * 4 + (t * 2 + hi)) * 3;
       p[0] = npos;
       p[1] = m[t];
       p[2] = tot;
