@@ -6,6 +6,7 @@ directly either side of ``MultiViewStereoNet.forward``:
 * ``build_image_pyramid``      <- utils/image_utils.py:111-128
 * ``multi_view_unpack_batch``  <- multi_view_stereonet/multi_view_stereonet_utils.py:541-641
 * ``multi_view_forward``       <- multi_view_stereonet/multi_view_stereonet_utils.py:643-662
+* ``unpack_batch`` / ``forward`` (two-view twins, optional right-view estimate) <- :406-539
 
 Nothing here is compute-heavy; it is tensor plumbing on whatever device it is handed
 (PyTorch-ROCm on the GPU box, CPU in the oracle tests).
@@ -116,6 +117,63 @@ def multi_view_unpack_batch(batch: Dict[str, object], device, num_levels: int) -
     if inputs["left_image_pyr"][0].dtype != torch.float32:
         raise AssertionError("images must be float32")
     return inputs
+
+
+def unpack_batch(batch: Dict[str, object], device, num_levels: int) -> Dict[str, object]:
+    """Two-view twin of multi_view_unpack_batch (multi_view_stereonet_utils.py:406-501): one source
+    view, tensors instead of lists, the pose normalised by its own baseline."""
+    left = batch["left_image"].to(device)
+    right = batch["right_image"].to(device)
+    K = batch["K"].to(device).squeeze(1)
+    T = batch["T_right_in_left"].to(device).squeeze(1).clone()
+    baseline = T[:, :3, 3].pow(2).sum(1).sqrt()
+    if not bool((baseline > 0).all()):
+        raise AssertionError("baseline must be positive")
+    T[:, :3, 3] /= baseline[:, None]
+    left_pyr = build_image_pyramid(left, num_levels)
+    inputs = {"left_filename": batch.get("left_filename"), "right_filename": batch.get("right_filename"),
+              "T_right_in_left": T, "T_left_in_right": torch.linalg.inv(T),
+              "K_pyr": build_intrinsics_pyramid(K, left_pyr), "left_image_pyr": left_pyr,
+              "right_image_pyr": build_image_pyramid(right, num_levels), "baseline": baseline}
+    for key in ("left_disparity_true", "right_disparity_true"):
+        if key in batch:
+            inputs[key] = batch[key].to(device)
+    if "left_depthmap_true" in batch:
+        scale = baseline.view(-1, 1, 1, 1)
+        for side in ("left", "right"):
+            depth = batch[f"{side}_depthmap_true"].to(device) / scale
+            inputs[f"{side}_depthmap_true"] = depth
+            inputs[f"{side}_idepthmap_true"] = torch.where(depth > 0, 1.0 / depth, depth)
+    if inputs["left_image_pyr"][0].dtype != torch.float32:
+        raise AssertionError("images must be float32")
+    return inputs
+
+
+def forward(stereo_network, inputs: Dict[str, object], params: Dict[str, object]):
+    """Two-view twin of multi_view_forward (multi_view_stereonet_utils.py:503-539).  With
+    ``params["estimate_right_idepthmap"]`` the network runs a second time with the views swapped
+    (the source becomes the reference, the pose is inverted) and the two times are averaged."""
+    on_gpu = inputs["left_image_pyr"][0].is_cuda
+    D = int(params["num_idepth_samples"])
+    flt = bool(params.get("cost_volume_filter", True))
+    refs = list(params.get("refiners", [True] * 5))
+
+    def run(ref_pyr, pose, src_pyr):
+        a, b = _tick(on_gpu)
+        out = stereo_network(ref_pyr, inputs["K_pyr"], [pose], [src_pyr], D, flt, refs)
+        return out, _tock(on_gpu, a, b)
+
+    left, ms = run(inputs["left_image_pyr"], inputs["T_right_in_left"], inputs["right_image_pyr"])
+    outputs = {"left_idepthmap_pyr": left["left_idepthmap_pyr"],
+               "left_idepthmap_raw_pyr": left["left_idepthmap_raw_pyr"],
+               "left_idepthmap_mask_pyr": left["left_idepthmap_mask_pyr"], "stereo_time_ms": ms}
+    if params.get("estimate_right_idepthmap", False):
+        right, ms_r = run(inputs["right_image_pyr"], inputs["T_left_in_right"], inputs["left_image_pyr"])
+        outputs["right_idepthmap_pyr"] = right["left_idepthmap_pyr"]
+        outputs["right_idepthmap_raw_pyr"] = right["left_idepthmap_raw_pyr"]
+        outputs["right_idepthmap_mask_pyr"] = right["left_idepthmap_mask_pyr"]
+        outputs["stereo_time_ms"] = 0.5 * (ms + ms_r)
+    return outputs
 
 
 def _tick(device_is_gpu: bool):

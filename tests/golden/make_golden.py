@@ -19,6 +19,7 @@ Fixtures:
   g4_units.npz                  single-op pins on tiny tensors
   g6_flags_128x64.npz           do_cost_volume_filter=False / refiners off variants
   g7_depth_metrics.npz          test.py's depth metrics on a synthetic truth/estimate pair
+  g8_two_view_128x64_d12.npz    2-view twins (unpack_batch / forward) with the right-view estimate
 """
 import os
 import sys
@@ -303,8 +304,28 @@ def metric_pins(name):
     print(name, "ok")
 
 
+def two_view_pins(name):
+    """The 2-view twins snu.unpack_batch / snu.forward with estimate_right_idepthmap (section 8f rank 4)."""
+    import copy
+    net = ref_net("gta_sfm_150epochs")
+    mv = synthetic.make_batch(64, 128, 1, batch=2, seed=13, pose_jitter=0.2)
+    batch = {"left_image": mv["left_image"], "right_image": mv["right_image"][0], "K": mv["K"],
+             "T_right_in_left": mv["T_right_in_left"][0], "left_filename": ["l"] * 2, "right_filename": ["r"] * 2}
+    inputs = ref_snu.unpack_batch(copy.deepcopy(batch), torch.device("cpu"), 5)
+    params = {"num_idepth_samples": 12, "cost_volume_filter": True, "refiners": [True] * 5,
+              "estimate_right_idepthmap": True}
+    out = ref_snu.forward(net, inputs, params)
+    d = {"T_right_in_left": npy(inputs["T_right_in_left"]), "T_left_in_right": npy(inputs["T_left_in_right"]),
+         "baseline": npy(inputs["baseline"]),
+         "left_idepth_0": npy(out["left_idepthmap_pyr"][0]), "right_idepth_0": npy(out["right_idepthmap_pyr"][0]),
+         "left_idepth_4": npy(out["left_idepthmap_pyr"][4]), "right_idepth_4": npy(out["right_idepthmap_pyr"][4])}
+    np.savez_compressed(os.path.join(HERE, name), **d)
+    print(name, "ok")
+
+
 def main():
     torch.set_num_threads(8)
+    two_view_pins("g8_two_view_128x64_d12.npz")
     metric_pins("g7_depth_metrics.npz")
     full_capture("g1_gta_128x64_d16_s1.npz", "gta_sfm_150epochs", 64, 128, 16, 1, seed=1)
     full_capture("g1_init_128x64_d16_s1.npz", None, 64, 128, 16, 1, seed=1, init_seed=0, store_weights=False)

@@ -462,6 +462,17 @@ def test_evaluate_cli_on_miniature_dataset(tmp_path):
     assert set(["abs_rel", "rmse", "a1", "runtime_ms"]) <= set(vals) and all(np.isfinite(list(vals.values())))
 
 
+def test_two_view_bidirectional_golden():
+    """Two-view path with the right-view estimate (views swapped, pose inverted) on the HIP network."""
+    from test_oracle_golden import _two_view_batch
+    fix = load_golden("g8_two_view_128x64_d12.npz")
+    inputs = snu.unpack_batch(_two_view_batch(), torch.device(DEV), 5)
+    out = snu.forward(net_for("gta_sfm_150epochs"), inputs, {"num_idepth_samples": 12, "estimate_right_idepthmap": True})
+    for key, lvl in (("left", 0), ("right", 0), ("left", 4), ("right", 4)):
+        mean_rel, max_rel = rel_err(out[f"{key}_idepthmap_pyr"][lvl].cpu(), fix[f"{key}_idepth_{lvl}"])
+        assert mean_rel < 2e-4 and max_rel < 2e-3, (key, lvl, mean_rel, max_rel)
+
+
 def test_graph_replay_matches_eager():
     """hipGraph capture of the whole forward: replay on new inputs equals the eager launch sequence."""
     from multi_view_stereonet_amd.graphed import GraphedForward

@@ -159,3 +159,29 @@ def test_analytic_known_answers():
     samples = torch.linspace(0, 1.7, 9)[None]
     out = oracle.soft_argmin(torch.full((1, 9, 2, 2), 3.0), samples)
     assert torch.allclose(out, samples.mean().expand_as(out), atol=1e-6)
+
+
+def _two_view_batch():
+    from multi_view_stereonet_amd import synthetic
+    mv = synthetic.make_batch(64, 128, 1, batch=2, seed=13, pose_jitter=0.2)
+    return {"left_image": mv["left_image"], "right_image": mv["right_image"][0], "K": mv["K"],
+            "T_right_in_left": mv["T_right_in_left"][0], "left_filename": ["l"] * 2, "right_filename": ["r"] * 2}
+
+
+def test_two_view_twins_against_reference():
+    """snu.unpack_batch / snu.forward (2-view, with the right-view estimate) driving the oracle network."""
+    fix = load_golden("g8_two_view_128x64_d12.npz")
+    w = load_weights("gta_sfm_150epochs")
+    inputs = snu.unpack_batch(_two_view_batch(), torch.device("cpu"), 5)
+    assert torch.equal(inputs["T_right_in_left"], t(fix["T_right_in_left"]))
+    assert torch.allclose(inputs["T_left_in_right"], t(fix["T_left_in_right"]), atol=1e-6)
+    assert torch.equal(inputs["baseline"], t(fix["baseline"]))
+
+    def net(lp, kp, ts, rp, D, flt, refs):
+        return oracle.forward(w, lp, kp, ts, rp, D, flt, refs)
+
+    out = snu.forward(net, inputs, {"num_idepth_samples": 12, "estimate_right_idepthmap": True})
+    for key, lvl in (("left", 0), ("right", 0), ("left", 4), ("right", 4)):
+        mean_rel, max_rel = rel_err(out[f"{key}_idepthmap_pyr"][lvl], fix[f"{key}_idepth_{lvl}"])
+        assert mean_rel < 1e-4 and max_rel < 1e-3, (key, lvl, mean_rel, max_rel)
+    assert "right_idepthmap_pyr" not in snu.forward(net, inputs, {"num_idepth_samples": 12})
