@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("MVSN_BENCH_LANES", "1")),
                     help="batch slices run on separate HIP streams (images are independent)")
     ap.add_argument("--fold", action="store_true", help="fold residual blocks into the next conv's tile load")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default=os.environ.get("MVSN_BENCH_PRECISION", "fp32"),
+                    help="arithmetic of the 32->32 3x3 layers: exact fp32 MFMA, or the 3 x bf16 split tier")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -131,6 +133,7 @@ def main():
     net = net.to(dev).eval()
     net.stream_lanes = args.lanes
     net.engine().fold_residual_blocks = args.fold
+    net.engine().conv_precision = args.precision
     B = args.batch
     _, inp = make_inputs(B, GOLDEN_SEED + rank * B, dev)
 

@@ -123,7 +123,19 @@ typedef struct {
   int kd, kh, kw;/* kernel extent; kd = 1 for 2-D */
   int stride;    /* 1 or 2 (rows/cols only) */
   int dilation;  /* rows/cols only */
+  int precision; /* MVSN_CONV_FP32 (exact fp32 MFMA) or MVSN_CONV_BF16X3 (3 x bf16 split, see below) */
 } mvsn_conv_desc;
+
+/* Arithmetic of mvsn_conv_forward.
+ *   MVSN_CONV_FP32    v_mfma_f32_16x16x4_f32: bit-for-bit an fp32 fmaf chain.
+ *   MVSN_CONV_BF16X3  fp32 operands split into bf16 hi + lo, a*b ~= ah*bh + ah*bl + al*bh on
+ *                     v_mfma_f32_16x16x32_bf16 with fp32 accumulation (~2^-16 relative per product;
+ *                     "3 x bf16 split", the fp32-equivalent tier BASELINE.md section 2 allows).  Only the
+ *                     32 -> 32 channel 3x3 / 3x3x3 stride-1 layers (mvsn_conv_bf16x3_supported); weights are
+ *                     packed per precision, in_residual / out_staged are not available. */
+#define MVSN_CONV_FP32 0
+#define MVSN_CONV_BF16X3 1
+int mvsn_conv_bf16x3_supported(const mvsn_conv_desc *desc);
 
 size_t mvsn_conv_packed_floats(const mvsn_conv_desc *desc);
 int mvsn_conv_pack_weights(const mvsn_conv_desc *desc, const float *weight, float *packed,

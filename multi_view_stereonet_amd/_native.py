@@ -18,7 +18,10 @@ class ConvDesc(Structure):
     """mvsn_conv_desc"""
     _fields_ = [("n", c_int), ("c_in", c_int), ("c_out", c_int), ("depth", c_int), ("rows", c_int),
                 ("cols", c_int), ("kd", c_int), ("kh", c_int), ("kw", c_int), ("stride", c_int),
-                ("dilation", c_int)]
+                ("dilation", c_int), ("precision", c_int)]
+
+
+CONV_FP32, CONV_BF16X3 = 0, 1
 
 
 # name -> (restype, argtypes); mirrors include/mvsn_hip.h one to one
@@ -31,6 +34,7 @@ SIGNATURES = {
     "mvsn_pack_feature_refiner": (c_int, [c_void_p] * 11 + [c_void_p]),
     "mvsn_incremental_cost_volume_workspace_bytes": (c_size_t, [c_int] * 3),
     "mvsn_incremental_cost_volume": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 4 + [c_size_t, c_void_p]),
+    "mvsn_conv_bf16x3_supported": (c_int, [POINTER(ConvDesc)]),
     "mvsn_conv_packed_floats": (c_size_t, [POINTER(ConvDesc)]),
     "mvsn_conv_pack_weights": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p]),
     "mvsn_conv_num_tiles": (c_int, [POINTER(ConvDesc)]),

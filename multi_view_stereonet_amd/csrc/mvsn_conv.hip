@@ -12,6 +12,7 @@
 // LDS tile: [4 ch][HZ][HY][XS], channel stride CST = 16 (mod 32) -> the 16-column x 4-channel
 // fragment read is bank-conflict-free at stride 1.
 #include "mvsn_common.h"
+#include "mvsn_conv_bf16x3.h"
 
 namespace mvsn {
 
@@ -785,13 +786,26 @@ __global__ void mfma_selftest_kernel(int *bad) {
 
 }  // namespace mvsn
 
+extern "C" int mvsn_conv_bf16x3_supported(const mvsn_conv_desc *desc) {
+  mvsn::Bf16x3Geom g;
+  return mvsn::bf16x3_geom(desc, &g) ? 1 : 0;
+}
+
 extern "C" size_t mvsn_conv_packed_floats(const mvsn_conv_desc *desc) {
+  if (desc && desc->precision == MVSN_CONV_BF16X3) {
+    mvsn::Bf16x3Geom bg;
+    return mvsn::bf16x3_geom(desc, &bg) ? (size_t)desc->kd * 9 * 1024 : 0;   // [tap][2][2][64][8] bf16
+  }
   mvsn::ConvGeom g;
   if (!mvsn::make_geom(desc, &g)) return 0;
   return (size_t)g.nchunks * g.wfloats_chunk;
 }
 
 extern "C" int mvsn_conv_num_tiles(const mvsn_conv_desc *desc) {
+  if (desc && desc->precision == MVSN_CONV_BF16X3) {
+    mvsn::Bf16x3Geom bg;
+    return mvsn::bf16x3_geom(desc, &bg) ? bg.tiles : 0;
+  }
   mvsn::ConvGeom g;
   if (!mvsn::make_geom(desc, &g)) return 0;
   return g.tiles;
@@ -799,9 +813,14 @@ extern "C" int mvsn_conv_num_tiles(const mvsn_conv_desc *desc) {
 
 extern "C" int mvsn_conv_pack_weights(const mvsn_conv_desc *desc, const float *weight, float *packed,
                                       mvsn_stream_t stream) {
+  MVSN_REQUIRE(weight && packed, MVSN_E_BADARG, "mvsn_conv_pack_weights: null pointer");
+  if (desc && desc->precision == MVSN_CONV_BF16X3) {
+    mvsn::Bf16x3Geom bg;
+    MVSN_REQUIRE(mvsn::bf16x3_geom(desc, &bg), MVSN_E_BADARG, "mvsn_conv_pack_weights: layer has no bf16x3 form");
+    return mvsn::bf16x3_pack(desc, weight, packed, (hipStream_t)stream);
+  }
   mvsn::ConvGeom g;
   MVSN_REQUIRE(mvsn::make_geom(desc, &g), MVSN_E_BADARG, "mvsn_conv_pack_weights: unsupported descriptor");
-  MVSN_REQUIRE(weight && packed, MVSN_E_BADARG, "mvsn_conv_pack_weights: null pointer");
   const int total = g.nchunks * g.ntaps * 128;
   hipLaunchKernelGGL(mvsn::conv_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, weight,
                      g.cin, g.cout, g.ntaps, g.nchunks, packed);
@@ -813,9 +832,18 @@ extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, co
                                  const float *in_beta, const float *in_residual, float *out_staged, float *out,
                                  float *out_partials, mvsn_stream_t stream) {
   using namespace mvsn;
+  MVSN_REQUIRE(in && weight_packed && out, MVSN_E_BADARG, "mvsn_conv_forward: null pointer");
+  if (desc && desc->precision == MVSN_CONV_BF16X3) {
+    Bf16x3Geom bg;
+    MVSN_REQUIRE(bf16x3_geom(desc, &bg), MVSN_E_BADARG, "mvsn_conv_forward: layer has no bf16x3 form");
+    MVSN_REQUIRE(!in_residual && !out_staged, MVSN_E_BADARG, "mvsn_conv_forward: bf16x3 has no residual folding");
+    MVSN_REQUIRE(!in_stats || (in_gamma && in_beta), MVSN_E_BADARG, "mvsn_conv_forward: input transform needs gamma/beta");
+    MVSN_REQUIRE(bg.n <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_forward: batch too large for one launch");
+    return bf16x3_launch(bg, in, weight_packed, bias, in_stats, in_gamma, in_beta, out, out_partials,
+                         (hipStream_t)stream);
+  }
   ConvGeom g;
   MVSN_REQUIRE(make_geom(desc, &g), MVSN_E_BADARG, "mvsn_conv_forward: unsupported descriptor");
-  MVSN_REQUIRE(in && weight_packed && out, MVSN_E_BADARG, "mvsn_conv_forward: null pointer");
   MVSN_REQUIRE(!in_stats || (in_gamma && in_beta), MVSN_E_BADARG, "mvsn_conv_forward: input transform needs gamma/beta");
   MVSN_REQUIRE(!in_stats || g.cin == 32, MVSN_E_BADARG, "mvsn_conv_forward: input transform needs 32 channels");
   MVSN_REQUIRE(!out_partials || g.cout == 32, MVSN_E_BADARG, "mvsn_conv_forward: partials need 32 output channels");
@@ -940,6 +968,7 @@ extern "C" int mvsn_selftest_mfma(mvsn_stream_t stream) {
   if (e != hipSuccess) return (int)e;
   (void)hipMemsetAsync(dbad, 0, sizeof(int), (hipStream_t)stream);
   hipLaunchKernelGGL(mvsn::mfma_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, dbad);
+  (void)mvsn::bf16_selftest((hipStream_t)stream, dbad);
   int bad = -1;
   (void)hipMemcpyAsync(&bad, dbad, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
   (void)hipStreamSynchronize((hipStream_t)stream);

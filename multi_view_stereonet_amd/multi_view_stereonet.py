@@ -54,10 +54,18 @@ class _Conv:
         w = weight.detach().contiguous().float()
         _native.check(lib.mvsn_conv_pack_weights(ctypes.byref(d), _native.ptr(w), _native.ptr(self.packed),
                                                  _native.stream()), "mvsn_conv_pack_weights")
+        # second packing for the 3 x bf16 split tier, where the layer has one (32 -> 32, 3x3[x3], stride 1)
+        self.packed_bx = None
+        dbx = self.desc(1, 1 if self.dims == 2 else 2, 8, 32, _native.CONV_BF16X3)
+        if lib.mvsn_conv_bf16x3_supported(ctypes.byref(dbx)):
+            nbx = lib.mvsn_conv_packed_floats(ctypes.byref(dbx))
+            self.packed_bx = torch.empty(nbx, dtype=torch.float32, device=weight.device)
+            _native.check(lib.mvsn_conv_pack_weights(ctypes.byref(dbx), _native.ptr(w), _native.ptr(self.packed_bx),
+                                                     _native.stream()), "mvsn_conv_pack_weights(bf16x3)")
 
-    def desc(self, n, depth, rows, cols):
+    def desc(self, n, depth, rows, cols, precision=_native.CONV_FP32):
         return _native.ConvDesc(n, self.cin, self.cout, depth, rows, cols, self.kd, self.kh, self.kw,
-                                self.stride, self.dilation)
+                                self.stride, self.dilation, precision)
 
 
 class _Norm:
@@ -78,6 +86,9 @@ class PlaneSweepEngine:
         # normalise/activate/add pass, 1/3 fewer launches).  Measured on MI355X the folded form is
         # 3 % slower end to end (the doubled staging loads are exposed), so it is off by default.
         self.fold_residual_blocks = False
+        # Arithmetic of the 32 -> 32 channel 3x3 / 3x3x3 layers: "fp32" = exact fp32 MFMA;
+        # "bf16x3" = 3 x bf16 split on the bf16 matrix cores (fp32-equivalent to ~2^-16 per product).
+        self.conv_precision = "fp32"
         fe = net.left_feature_extractor
         self.fe_down = [_Conv(lib, getattr(fe, f"conv{i}").weight, None, stride=2) for i in range(4)]
         self.fe_res = [(_Conv(lib, getattr(fe, f"res{i}").conv1.weight, None), _Norm(getattr(fe, f"res{i}").bn1))
@@ -133,6 +144,11 @@ class PlaneSweepEngine:
         depth = x.shape[2] if c.dims == 3 else 1
         rows, cols = x.shape[-2], x.shape[-1]
         d = c.desc(n, depth, rows, cols)
+        packed = c.packed
+        if self.conv_precision == "bf16x3" and c.packed_bx is not None and in_residual is None and not write_staged:
+            dbx = c.desc(n, depth, rows, cols, _native.CONV_BF16X3)
+            if lib.mvsn_conv_bf16x3_supported(ctypes.byref(dbx)):
+                d, packed = dbx, c.packed_bx
         ro, co = (rows - 1) // c.stride + 1, (cols - 1) // c.stride + 1
         shape = (n, c.cout, depth, ro, co) if c.dims == 3 else (n, c.cout, ro, co)
         out = torch.empty(shape, dtype=torch.float32, device=x.device)
@@ -143,11 +159,12 @@ class PlaneSweepEngine:
             partials = torch.empty((n, tiles, 4, 3), dtype=torch.float32, device=x.device)
         taps = c.kd * c.kh * c.kw
         tag = (f"conv{c.dims}d k{c.kh}" + (f"s{c.stride}" if c.stride > 1 else "") +
-               (f"d{c.dilation}" if c.dilation > 1 else "") + f" {c.cin}->{c.cout}")
+               (f"d{c.dilation}" if c.dilation > 1 else "") + f" {c.cin}->{c.cout}" +
+               (" bf16x3" if d.precision == _native.CONV_BF16X3 else ""))
         nbytes = 4.0 * (x.numel() * (2 if in_residual is not None else 1) + out.numel() +
                         (staged.numel() if staged is not None else 0))
         self._call("mvsn_conv_forward[" + tag + "]", lib.mvsn_conv_forward, ctypes.byref(d), _native.ptr(x),
-                   _native.ptr(c.packed), _native.ptr(c.bias), _native.ptr(in_stats),
+                   _native.ptr(packed), _native.ptr(c.bias), _native.ptr(in_stats),
                    _native.ptr(in_norm.gamma) if in_norm else None, _native.ptr(in_norm.beta) if in_norm else None,
                    _native.ptr(in_residual), _native.ptr(staged), _native.ptr(out), _native.ptr(partials),
                    _native.stream(), flops=2.0 * c.cin * taps * c.cout * out[:, 0].numel(), nbytes=nbytes)

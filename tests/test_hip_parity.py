@@ -222,6 +222,66 @@ def test_conv_to1_vector_path(dims, depth, rows, cols, n):
     assert eng.conv_to1(c, torch.zeros(1, 32, 6, 45, device=DEV)) is None if dims == 2 else True   # ragged width -> MFMA kernel
 
 
+@pytest.mark.parametrize("dims,depth,rows,cols,dil,n", [(2, 1, 16, 32, 1, 2), (2, 1, 37, 70, 1, 1), (2, 1, 24, 40, 2, 1),
+                                                        (2, 1, 64, 96, 4, 1), (3, 8, 16, 32, 1, 2), (3, 5, 9, 35, 1, 1),
+                                                        (3, 64, 16, 32, 1, 1)])
+def test_conv_bf16x3_split(dims, depth, rows, cols, dil, n):
+    """3 x bf16 split tier: fp32-equivalent to ~2^-16 per product (error measured against fp64)."""
+    from multi_view_stereonet_amd.multi_view_stereonet import _Conv, _Norm
+    eng = net_for("gta_sfm_150epochs").engine()
+    g = torch.Generator().manual_seed(rows * 3 + depth)
+    shape = (n, 32, depth, rows, cols) if dims == 3 else (n, 32, rows, cols)
+    x = torch.randn(shape, generator=g) * 1.5 + 0.2
+    w = torch.randn((32, 32) + (3,) * dims, generator=g) * 0.06
+    b = torch.randn(32, generator=g) * 0.1
+    conv = F.conv3d if dims == 3 else F.conv2d
+    ref = conv(x.double(), w.double(), b.double(), padding=dil, dilation=dil)
+    c = _Conv(eng.lib, w.to(DEV), b.to(DEV), dilation=dil)
+    assert c.packed_bx is not None
+    eng.conv_precision = "bf16x3"
+    try:
+        out, stats = eng.conv(c, x.to(DEV), want_stats=True)
+        mean_rel, max_rel = rel_err(out.cpu(), ref)
+        assert mean_rel < 3e-5 and max_rel < 1e-4, (mean_rel, max_rel)
+        rg = ref.reshape(n, 4, -1)
+        close(stats[:, :, 0], rg.mean(2), rtol=1e-4, atol=2e-5)
+        close(stats[:, :, 1], 1.0 / (rg.var(2, unbiased=False) + 1e-5).sqrt(), rtol=1e-4, atol=1e-5)
+        # folded GroupNorm + LeakyReLU on the input
+        gamma, beta = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.1
+
+        class P:
+            weight, bias = gamma.to(DEV), beta.to(DEV)
+        out2, _ = eng.conv(c, out, in_stats=stats, in_norm=_Norm(P))
+        xin = F.leaky_relu(F.group_norm(ref, 4, gamma.double(), beta.double(), 1e-5), 0.2)
+        ref2 = conv(xin, w.double(), b.double(), padding=dil, dilation=dil)
+        mean_rel, max_rel = rel_err(out2.cpu(), ref2)
+        assert mean_rel < 1e-4 and max_rel < 3e-4, (mean_rel, max_rel)
+    finally:
+        eng.conv_precision = "fp32"
+    fp32_out, _ = eng.conv(c, x.to(DEV))
+    m32, _ = rel_err(fp32_out.cpu(), ref)
+    assert m32 < 2e-6          # the default tier is exact fp32
+
+
+@pytest.mark.parametrize("name,wname,smooth", [("g2_gta_512x256_d64_s2.npz", "gta_sfm_150epochs", False),
+                                               ("g2s_gta_512x256_d64_s2.npz", "gta_sfm_150epochs", True),
+                                               ("g3_demon_640x480_d96_s1.npz", "demon_45epochs", False),
+                                               ("g1_gta_128x64_d16_s1.npz", "gta_sfm_150epochs", False)])
+def test_forward_bf16x3_tier_within_contract(name, wname, smooth):
+    """The split tier against the reference's depth maps: inside the 1e-3 contract (reported, not hidden)."""
+    fix = load_golden(name)
+    net = net_for(wname)
+    eng = net.engine()
+    eng.conv_precision = "bf16x3"
+    try:
+        out = _forward(net, fix, smooth=smooth)
+    finally:
+        eng.conv_precision = "fp32"
+    mean_rel, max_rel = rel_err(out["left_idepthmap_pyr"][0].cpu(), fix["idepth_0"])
+    print(f"bf16x3 {name}: mean-rel {mean_rel:.3e} max-rel {max_rel:.3e}")
+    assert mean_rel < 5e-4 and max_rel < 1e-3, (mean_rel, max_rel)
+
+
 def test_cost_volume_filter_and_soft_argmin_golden_unit():
     fix = load_golden("g4_units.npz")
     eng = net_for("gta_sfm_150epochs").engine()
