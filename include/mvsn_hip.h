@@ -112,7 +112,8 @@ int mvsn_incremental_cost_volume(const float *src_image_lvl4, const float *H_lvl
  *   in (N,C_in,[D,]H,W)  weight_packed: mvsn_conv_packed_floats() floats  bias (C_out) or NULL
  *   in_stats (N,4,2) mean,rstd   in_gamma,in_beta (C_in)   in_residual, out_staged (N,C_in,H,W)
  *   out (N,C_out,[D,]Ho,Wo)
- *   out_partials (N, tiles, 4, 3) {count, mean, M2}
+ *   out_partials (N, R, 4, 3) {count, mean, M2}, R = mvsn_conv_num_tiles() partial records per sample
+ *   (one per workgroup tile and wave; written without any workgroup-level synchronisation)
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
   int n;         /* samples */

@@ -291,29 +291,39 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
   float *outn = out + (size_t)n * g.cout * out_chan;
   float s[2] = {0.f, 0.f};
   int cnt = 0;
+  const bool vec_store = (g.Wo & 3) == 0;   // aligned quads of output columns are all inside or all outside
 #pragma unroll
   for (int j = 0; j < NPT; ++j) {
     const bool ok = opos[j] >= 0;
     if (ok) cnt += 1;
 #pragma unroll
-    for (int t = 0; t < CT; ++t)
+    for (int t = 0; t < CT; ++t) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int c = t * 16 + cbase + r;
-        if (c < g.cout) {
-          const float v = acc[j][t][r] + (bias ? bias[c] : 0.0f);
-          acc[j][t][r] = v;
-          if (ok) {
-            outn[(size_t)c * out_chan + opos[j]] = v;
-            s[t] += v;
-          }
+        const float v = acc[j][t][r] + ((bias && c < g.cout) ? bias[c] : 0.0f);
+        acc[j][t][r] = v;
+        if (ok && c < g.cout) s[t] += v;
+      }
+      if (vec_store) {   // 4 couts x 1 pixel -> 1 cout x 4 pixels, one 16-byte store
+        const floatx4 tv = quad_transpose(acc[j][t], lane);
+        const int c = t * 16 + cbase + (lane & 3);
+        if (ok && c < g.cout) *reinterpret_cast<floatx4 *>(outn + (size_t)c * out_chan + (opos[j] - (lane & 3))) = tv;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = t * 16 + cbase + r;
+          if (ok && c < g.cout) outn[(size_t)c * out_chan + opos[j]] = acc[j][t][r];
         }
       }
+    }
   }
   if (out_partials == nullptr) return;  // uniform across the grid
   if (CT != 2) return;                  // partials need all 32 channels (checked on the host)
 
-  // group of channel t*16 + cbase + r is 2t + (lane >> 5): reduce over the 32 lanes of a half-wave
+  // Per-wave GroupNorm partials (count, mean, M2) of the wave's own positions, reduced with shuffles
+  // only -- no LDS, no barrier.  Group of channel t*16 + cbase + r is 2t + (lane >> 5); within a
+  // 32-lane half the lanes with bit 4 clear hold each of the wave's pixels exactly once.
   auto half_wave_sum = [&](float v) {
     v += __shfl_xor(v, 1, 64);
     v += __shfl_xor(v, 2, 64);
@@ -323,32 +333,13 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
     return v;
   };
   const int hi = lane >> 5;
-  int cnt_tile;
-  {
-    float c = (lane < 16) ? (float)cnt : 0.0f;
-    c = half_wave_sum(c);
-    __syncthreads();
-    if (lane == 0) red[wave] = c;
-    __syncthreads();
-    cnt_tile = (int)(red[0] + red[1] + red[2] + red[3]);
-    __syncthreads();
-  }
-  const float npos = (float)cnt_tile * 8.0f;  // elements per group in this tile
+  const float npos = half_wave_sum((lane & 16) == 0 ? (float)cnt : 0.0f) * 8.0f;
   float m[2];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) s[t] = half_wave_sum(s[t]);
-  if ((lane & 31) == 0) {
-    red[wave * 4 + 0 + hi] = s[0];
-    red[wave * 4 + 2 + hi] = s[1];
-  }
-  __syncthreads();
-#pragma unroll
   for (int t = 0; t < 2; ++t) {
-    float tot = 0.f;
-    for (int w = 0; w < CV_WAVES; ++w) tot += red[w * 4 + t * 2 + hi];
-    m[t] = cnt_tile > 0 ? tot / npos : 0.0f;
+    s[t] = half_wave_sum(s[t]);
+    m[t] = npos > 0.0f ? s[t] / npos : 0.0f;
   }
-  __syncthreads();
   float q[2] = {0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < NPT; ++j)
@@ -364,19 +355,12 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
 #pragma unroll
   for (int t = 0; t < 2; ++t) q[t] = half_wave_sum(q[t]);
   if ((lane & 31) == 0) {
-    red[wave * 4 + 0 + hi] = q[0];
-    red[wave * 4 + 2 + hi] = q[1];
-  }
-  __syncthreads();
-  if (wave == 0 && (lane & 31) == 0) {
+    float *rec = out_partials + (((size_t)n * g.tiles + tile_id) * 4 + (tid >> 6)) * 12;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      float tot = 0.f;
-      for (int w = 0; w < CV_WAVES; ++w) tot += red[w * 4 + t * 2 + hi];
-      float *p = out_partials + (((size_t)n * g.tiles + tile_id) * 4 + (t * 2 + hi)) * 3;
-      p[0] = npos;
-      p[1] = m[t];
-      p[2] = tot;
+      rec[(t * 2 + hi) * 3 + 0] = npos;
+      rec[(t * 2 + hi) * 3 + 1] = m[t];
+      rec[(t * 2 + hi) * 3 + 2] = q[t];
     }
   }
 }
@@ -574,27 +558,38 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_dma_kernel(ConvGeom g, con
   float *outn = out + (size_t)n * g.cout * out_chan;
   float s[2] = {0.f, 0.f};
   int cnt = 0;
+  const bool vec_store = (g.Wo & 3) == 0;   // aligned quads of output columns are all inside or all outside
 #pragma unroll
   for (int j = 0; j < NPT; ++j) {
     const bool ok = opos[j] >= 0;
     if (ok) cnt += 1;
 #pragma unroll
-    for (int t = 0; t < CT; ++t)
+    for (int t = 0; t < CT; ++t) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int c = t * 16 + cbase + r;
-        if (c < g.cout) {
-          const float v = acc[j][t][r] + (bias ? bias[c] : 0.0f);
-          acc[j][t][r] = v;
-          if (ok) {
-            outn[(size_t)c * out_chan + opos[j]] = v;
-            s[t] += v;
-          }
+        const float v = acc[j][t][r] + ((bias && c < g.cout) ? bias[c] : 0.0f);
+        acc[j][t][r] = v;
+        if (ok && c < g.cout) s[t] += v;
+      }
+      if (vec_store) {   // 4 couts x 1 pixel -> 1 cout x 4 pixels, one 16-byte store
+        const floatx4 tv = quad_transpose(acc[j][t], lane);
+        const int c = t * 16 + cbase + (lane & 3);
+        if (ok && c < g.cout) *reinterpret_cast<floatx4 *>(outn + (size_t)c * out_chan + (opos[j] - (lane & 3))) = tv;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = t * 16 + cbase + r;
+          if (ok && c < g.cout) outn[(size_t)c * out_chan + opos[j]] = acc[j][t][r];
         }
       }
+    }
   }
   if (out_partials == nullptr) return;
   if (CT != 2) return;
+  // Per-wave GroupNorm partials (count, mean, M2) of the wave's own positions, reduced with shuffles
+  // only -- no LDS, no barrier.  Group of channel t*16 + cbase + r is 2t + (lane >> 5); within a
+  // 32-lane half the lanes with bit 4 clear hold each of the wave's pixels exactly once.
   auto half_wave_sum = [&](float v) {
     v += __shfl_xor(v, 1, 64);
     v += __shfl_xor(v, 2, 64);
@@ -604,33 +599,13 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_dma_kernel(ConvGeom g, con
     return v;
   };
   const int hi = lane >> 5;
-  const int wv = tid >> 6;
-  int cnt_tile;
-  {
-    float c = (lane < 16) ? (float)cnt : 0.0f;
-    c = half_wave_sum(c);
-    __syncthreads();
-    if (lane == 0) red[wv] = c;
-    __syncthreads();
-    cnt_tile = (int)(red[0] + red[1] + red[2] + red[3]);
-    __syncthreads();
-  }
-  const float npos = (float)cnt_tile * 8.0f;
+  const float npos = half_wave_sum((lane & 16) == 0 ? (float)cnt : 0.0f) * 8.0f;
   float m[2];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) s[t] = half_wave_sum(s[t]);
-  if ((lane & 31) == 0) {
-    red[wv * 4 + 0 + hi] = s[0];
-    red[wv * 4 + 2 + hi] = s[1];
-  }
-  __syncthreads();
-#pragma unroll
   for (int t = 0; t < 2; ++t) {
-    float tot = 0.f;
-    for (int w = 0; w < CV_WAVES; ++w) tot += red[w * 4 + t * 2 + hi];
-    m[t] = cnt_tile > 0 ? tot / npos : 0.0f;
+    s[t] = half_wave_sum(s[t]);
+    m[t] = npos > 0.0f ? s[t] / npos : 0.0f;
   }
-  __syncthreads();
   float q[2] = {0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < NPT; ++j)
@@ -646,19 +621,12 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_dma_kernel(ConvGeom g, con
 #pragma unroll
   for (int t = 0; t < 2; ++t) q[t] = half_wave_sum(q[t]);
   if ((lane & 31) == 0) {
-    red[wv * 4 + 0 + hi] = q[0];
-    red[wv * 4 + 2 + hi] = q[1];
-  }
-  __syncthreads();
-  if (wv == 0 && (lane & 31) == 0) {
+    float *rec = out_partials + (((size_t)n * g.tiles + tile_id) * 4 + (tid >> 6)) * 12;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      float tot = 0.f;
-      for (int w = 0; w < CV_WAVES; ++w) tot += red[w * 4 + t * 2 + hi];
-      float *p = out_partials + (((size_t)n * g.tiles + tile_id) * 4 + (t * 2 + hi)) * 3;
-      p[0] = npos;
-      p[1] = m[t];
-      p[2] = tot;
+      rec[(t * 2 + hi) * 3 + 0] = npos;
+      rec[(t * 2 + hi) * 3 + 1] = m[t];
+      rec[(t * 2 + hi) * 3 + 2] = q[t];
     }
   }
 }
@@ -802,13 +770,14 @@ extern "C" size_t mvsn_conv_packed_floats(const mvsn_conv_desc *desc) {
 }
 
 extern "C" int mvsn_conv_num_tiles(const mvsn_conv_desc *desc) {
+  // number of GroupNorm partial records per sample: one per (tile, wave), 4 waves per workgroup tile
   if (desc && desc->precision == MVSN_CONV_BF16X3) {
     mvsn::Bf16x3Geom bg;
-    return mvsn::bf16x3_geom(desc, &bg) ? bg.tiles : 0;
+    return mvsn::bf16x3_geom(desc, &bg) ? bg.tiles * 4 : 0;
   }
   mvsn::ConvGeom g;
   if (!mvsn::make_geom(desc, &g)) return 0;
-  return g.tiles;
+  return g.tiles * 4;
 }
 
 extern "C" int mvsn_conv_pack_weights(const mvsn_conv_desc *desc, const float *weight, float *packed,

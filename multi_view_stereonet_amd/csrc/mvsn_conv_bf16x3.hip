@@ -7,12 +7,14 @@
 // the regulariser and refiner layers.
 //
 // Plane streaming: a workgroup owns TZO x TY x 32 outputs x 32 couts and walks the TZO+KD-1 input
-// planes it needs once; the haloed plane tile sits in LDS channel-minor, one 144-byte record per
-// position = [32 x bf16 hi | 32 x bf16 lo | 16 pad] (record stride 36 dwords: the sixteen 16-byte
+// planes it needs once; the haloed plane tile sits in LDS channel-minor, one 160-byte record per
+// position = [32 x bf16 hi | 32 x bf16 lo | 32 pad] (record stride 40 dwords: the sixteen 16-byte
 // B-fragment reads of a lane group land on distinct banks).  Lane l of an MFMA supplies
 // A[i = l&15][k = 8*(l>>4) + 0..7] (weights, read as two 16-byte global loads per part, L1/L2 resident)
 // and B[k][j = l&15] (one 16-byte LDS read per part).  Input planes that fall outside the volume are
 // skipped (their taps contribute zeros), so edge tiles do less work.
+#include <stdlib.h>
+
 #include "mvsn_common.h"
 #include "mvsn_conv_bf16x3.h"
 
@@ -22,7 +24,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
 
 constexpr int BX_THREADS = 256;
-constexpr int BX_REC = 36;  // dwords per position record
+constexpr int BX_REC = 40;  // dwords per position record: 160 B = 10 sixteen-byte slots -> the ds_read_b128 lane groups are conflict-free
 
 __device__ __forceinline__ unsigned int pack_bf16_pair(float a, float b) {
   // two RNE conversions in one v_cvt_pk_bf16_f32
@@ -51,7 +53,15 @@ __global__ void conv_bf16x3_pack_kernel(const float *__restrict__ w, int ntaps, 
   out[base + 512] = (unsigned short)lo;
 }
 
-template <int KD, int TZO, int TY, int MODE>
+// KD   1 (2-D) or 3 (3-D);  TZO output planes, TY output rows (x 32 columns) per tile
+// TPW  consecutive tiles per workgroup (2-D only; a 3-D workgroup walks TZO+2 input planes instead)
+// NIT  staging items per thread per stage = ceil(HY*HX*4 / 256); an item = 8 channels of one position
+//
+// Stages (one haloed input plane tile each) are software-pipelined: the raw fp32 values of stage s+1
+// are fetched into registers while the MFMAs of stage s run, then converted to hi/lo bf16 records and
+// written to the single LDS plane between two barriers.
+// DIL  dilation as a compile-time constant: the tap offsets become ds_read immediates (no address VALU)
+template <int KD, int TZO, int TY, int TPW, int NIT, int MODE, int DIL>
 __global__ __launch_bounds__(BX_THREADS, 2) void conv_bf16x3_kernel(Bf16x3Geom g, const float *__restrict__ in,
                                                                     const uintx4 *__restrict__ wpk,
                                                                     const float *__restrict__ bias,
@@ -59,24 +69,31 @@ __global__ __launch_bounds__(BX_THREADS, 2) void conv_bf16x3_kernel(Bf16x3Geom g
                                                                     const float *__restrict__ in_gamma,
                                                                     const float *__restrict__ in_beta,
                                                                     float *__restrict__ out,
-                                                                    float *__restrict__ out_partials) {
+                                                                    float *__restrict__ out_partials,
+                                                                    unsigned long long *dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned int plane[];  // HY*HX records of BX_REC dwords
-  constexpr int NPT = TY / 2;  // pixel tiles (16 columns) per wave per output plane
-  const int npos = g.HY * g.HX;
+  int dbg_i = 0;
+#define BX_STAMP()                                                                                     \
+  do {                                                                                                 \
+    if (dbg && blockIdx.x == 3 && blockIdx.y == 0 && threadIdx.x == 0 && dbg_i < 60) dbg[dbg_i++] = __builtin_readcyclecounter(); \
+  } while (0)
+  // Wave w owns cout tile (w & 1) and half (w >> 1) of the tile's pixel tiles: a weight fragment is
+  // then reused for TY pixel tiles x 3 products, which halves the L1 traffic of the weight stream (the
+  // first bottleneck of this kernel) at the price of more B-fragment reads from LDS, where there is room.
+  constexpr int NPT = TY;  // pixel tiles (16 columns) per wave per output plane
+  constexpr int NSTAGE = KD == 3 ? TZO + 2 : TPW;
+  constexpr int HX = 32 + 2 * DIL, HY = TY + 2 * DIL;   // == g.HX, g.HY
+  constexpr int npos = HY * HX;
   float *scsh = reinterpret_cast<float *>(plane + (size_t)npos * BX_REC);  // 64
   float *red = scsh + 64;                                                  // 16
 
+  BX_STAMP();   // kernel entry
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tw = wave & 1, half = wave >> 1;
   const int n = blockIdx.y;
-  int tix = blockIdx.x;
-  const int txi = tix % g.ntx;
-  tix /= g.ntx;
-  const int tyi = tix % g.nty;
-  const int tzi = tix / g.nty;
-  const int z0 = tzi * TZO, y0 = tyi * TY, x0 = txi * 32;
-  const int gy0 = y0 - g.dil, gx0 = x0 - g.dil;
   const size_t in_plane = (size_t)g.H * g.W, in_chan = (size_t)g.D * in_plane;
   const float *inn = in + (size_t)n * 32 * in_chan;
+  float *outn = out + (size_t)n * 32 * in_chan;
 
   if (MODE == 1 && tid < 32) {
     const int grp = tid >> 3;
@@ -87,40 +104,73 @@ __global__ __launch_bounds__(BX_THREADS, 2) void conv_bf16x3_kernel(Bf16x3Geom g
     scsh[32 + tid] = in_beta[tid] - mean * sc;
   }
 
+  // stage s -> (tile, input plane): 3-D: one tile, planes z0-1 .. z0+TZO; 2-D: TPW tiles, plane 0
+  auto tile_of = [&](int s) { return KD == 3 ? (int)blockIdx.x : (int)blockIdx.x * TPW + s; };
+  auto origin = [&](int tile, int &z0, int &y0, int &x0) {
+    const int txi = tile % g.ntx;
+    const int rest = tile / g.ntx;
+    const int tyi = rest % g.nty;
+    z0 = (rest / g.nty) * TZO, y0 = tyi * TY, x0 = txi * 32;
+  };
+  auto stage_valid = [&](int s) {
+    if (KD == 3) {
+      int z0, y0, x0;
+      origin(tile_of(s), z0, y0, x0);
+      const int gz = z0 - 1 + s;
+      return gz >= 0 && gz < g.D;
+    }
+    return tile_of(s) < g.tiles;
+  };
+
   // this lane's pixels (column j = lane & 15 of each of the wave's pixel tiles) as record offsets
   int prec[NPT];
 #pragma unroll
   for (int j = 0; j < NPT; ++j) {
-    const int pt = wave * NPT + j;  // 0 .. TY*2-1
+    const int pt = half * NPT + j;
     const int yy = pt >> 1, xx = (pt & 1) * 16 + (lane & 15);
-    prec[j] = (yy * g.HX + xx) * BX_REC + (lane >> 4) * 4;  // + k-group: 8 bf16 = 4 dwords
+    prec[j] = (yy * HX + xx) * BX_REC + (lane >> 4) * 4;
+  }
+  // staging items of this thread: position and channel group are the same for every stage
+  int ipos[NIT];
+  short iy[NIT], ix[NIT], igrp[NIT];
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int it = tid + k * BX_THREADS;
+    const int grp = it / npos, p = it - grp * npos;
+    ipos[k] = it < npos * 4 ? p : -1;
+    iy[k] = (short)(p / HX);
+    ix[k] = (short)(p - (p / HX) * HX);
+    igrp[k] = (short)grp;
   }
 
-  floatx4 acc[TZO][NPT][2];
+  float raw[NIT][8];
+  unsigned okmask = 0;
+  auto fetch = [&](int s) {
+    int z0, y0, x0;
+    origin(tile_of(s), z0, y0, x0);
+    const int gz = KD == 3 ? z0 - 1 + s : 0;
+    okmask = 0;
 #pragma unroll
-  for (int zo = 0; zo < TZO; ++zo)
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) acc[zo][j][0] = acc[zo][j][1] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-  const int items = npos * 4;  // (position, channel group of 8)
-  for (int zi = 0; zi < TZO + KD - 1; ++zi) {
-    const int gz = z0 - (KD / 2) + zi;
-    if (gz < 0 || gz >= g.D) continue;  // uniform: a plane of zeros contributes nothing
-    __syncthreads();                    // previous plane fully consumed (and scsh visible)
-    // ---- stage the haloed plane tile: fp32 HBM -> (transform) -> hi/lo bf16 records ----------------
-    for (int it = tid; it < items; it += BX_THREADS) {
-      const int grp = it / npos, p = it - grp * npos;
-      const int y = p / g.HX, x = p - y * g.HX;
-      const int gy = gy0 + y, gx = gx0 + x;
-      const bool ok = gy >= 0 && gy < g.H && gx >= 0 && gx < g.W;
-      const float *src = inn + (size_t)(grp * 8) * in_chan + (size_t)gz * in_plane + (size_t)(ok ? gy : 0) * g.W +
+    for (int k = 0; k < NIT; ++k) {
+      const int gy = y0 - DIL + iy[k], gx = x0 - DIL + ix[k];
+      const bool ok = ipos[k] >= 0 && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W;
+      if (ok) okmask |= 1u << k;
+      const float *src = inn + (size_t)(igrp[k] * 8) * in_chan + (size_t)gz * in_plane + (size_t)(ok ? gy : 0) * g.W +
                          (ok ? gx : 0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) raw[k][e] = ok ? src[(size_t)e * in_chan] : 0.0f;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      if (ipos[k] < 0) continue;
       float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = ok ? src[(size_t)e * in_chan] : 0.0f;
-      if (MODE == 1 && ok) {
+      for (int e = 0; e < 8; ++e) v[e] = raw[k][e];
+      if (MODE == 1 && ((okmask >> k) & 1u)) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = lrelu02(v[e] * scsh[grp * 8 + e] + scsh[32 + grp * 8 + e]);
+        for (int e = 0; e < 8; ++e) v[e] = lrelu02(v[e] * scsh[igrp[k] * 8 + e] + scsh[32 + igrp[k] * 8 + e]);
       }
       uintx4 hi, lo;
 #pragma unroll
@@ -129,142 +179,192 @@ __global__ __launch_bounds__(BX_THREADS, 2) void conv_bf16x3_kernel(Bf16x3Geom g
         hi[e] = h;
         lo[e] = pack_bf16_pair(v[2 * e] - bf16_lo_to_float(h), v[2 * e + 1] - bf16_hi_to_float(h));
       }
-      unsigned int *rec = plane + (size_t)p * BX_REC + grp * 4;
+      unsigned int *rec = plane + (size_t)ipos[k] * BX_REC + igrp[k] * 4;
       *reinterpret_cast<uintx4 *>(rec) = hi;
       *reinterpret_cast<uintx4 *>(rec + 16) = lo;
     }
-    __syncthreads();
-    // ---- every output plane that sees this input plane through some z-tap ----------------------------
-#pragma unroll
-    for (int zo = 0; zo < TZO; ++zo) {
-      const int tz = zi - zo;              // z-tap through which output plane zo sees this input plane
-      if (tz < 0 || tz >= KD) continue;    // uniform
-#pragma unroll
-      for (int ty = 0; ty < 3; ++ty)
-#pragma unroll
-        for (int tx = 0; tx < 3; ++tx) {
-          const int tap = (tz * 3 + ty) * 3 + tx;
-          const uintx4 *wt = wpk + (size_t)tap * 256 + lane;  // [t][part][lane]
-          const bf16x8 a0h = __builtin_bit_cast(bf16x8, wt[0]);
-          const bf16x8 a0l = __builtin_bit_cast(bf16x8, wt[64]);
-          const bf16x8 a1h = __builtin_bit_cast(bf16x8, wt[128]);
-          const bf16x8 a1l = __builtin_bit_cast(bf16x8, wt[192]);
-          const int toff = (ty * g.dil * g.HX + tx * g.dil) * BX_REC;
-#pragma unroll
-          for (int j = 0; j < NPT; ++j) {
-            const unsigned int *rec = plane + prec[j] + toff;
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uintx4 *>(rec));
-            const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uintx4 *>(rec + 16));
-            acc[zo][j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0l, bh, acc[zo][j][0], 0, 0, 0);
-            acc[zo][j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, bl, acc[zo][j][0], 0, 0, 0);
-            acc[zo][j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, bh, acc[zo][j][0], 0, 0, 0);
-            acc[zo][j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1l, bh, acc[zo][j][1], 0, 0, 0);
-            acc[zo][j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, bl, acc[zo][j][1], 0, 0, 0);
-            acc[zo][j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, bh, acc[zo][j][1], 0, 0, 0);
-          }
-        }
-    }
-  }
+  };
 
-  // ---- epilogue: bias, store, GroupNorm partials (same contract as the fp32 kernels) ------------------
-  const int cbase = (lane >> 4) * 4;
-  const size_t out_plane = (size_t)g.H * g.W, out_chan = (size_t)g.D * out_plane;
-  float *outn = out + (size_t)n * 32 * out_chan;
-  float s[2] = {0.f, 0.f};
-  int cnt = 0;
+  floatx4 acc[TZO][NPT];
+  auto clear_acc = [&]() {
 #pragma unroll
-  for (int zo = 0; zo < TZO; ++zo)
+    for (int zo = 0; zo < TZO; ++zo)
 #pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-      const int pt = wave * NPT + j;
-      const int oz = z0 + zo, oy = y0 + (pt >> 1), ox = x0 + (pt & 1) * 16 + (lane & 15);
-      const bool ok = oz < g.D && oy < g.H && ox < g.W;
-      if (ok) cnt += 1;
-      const size_t pos = (size_t)oz * out_plane + (size_t)oy * g.W + ox;
+      for (int j = 0; j < NPT; ++j) acc[zo][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+  };
+
+  // Bias of this lane's four channels, read once: a global load inside the per-tile epilogue would make
+  // its s_waitcnt (vmcnt retires in order) wait for the next stage's prefetch and the previous tile's stores.
+  float bias4[4];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+  for (int r = 0; r < 4; ++r) bias4[r] = bias ? bias[tw * 16 + (lane >> 4) * 4 + r] : 0.0f;
+
+  // bias, store, GroupNorm partials of one finished tile.  This wave holds channels tw*16 + cbase + r,
+  // i.e. GroupNorm groups 2*tw + (lane >> 5); the tile's positions are split over the two `half` waves.
+  auto epilogue = [&](int tile) {
+    int z0, y0, x0;
+    origin(tile, z0, y0, x0);
+    const int cbase = (lane >> 4) * 4;
+    float s = 0.f;
+    int cnt = 0;
+#pragma unroll
+    for (int zo = 0; zo < TZO; ++zo)
+#pragma unroll
+      for (int j = 0; j < NPT; ++j) {
+        const int pt = half * NPT + j;
+        const int oz = z0 + zo, oy = y0 + (pt >> 1), ox = x0 + (pt & 1) * 16 + (lane & 15);
+        const bool ok = oz < g.D && oy < g.H && ox < g.W;
+        if (ok) cnt += 1;
+        const size_t pos = (size_t)oz * in_plane + (size_t)oy * g.W + ox;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int c = t * 16 + cbase + r;
-          const float v = acc[zo][j][t][r] + (bias ? bias[c] : 0.0f);
-          acc[zo][j][t][r] = ok ? v : 0.0f;
-          if (ok) {
-            outn[(size_t)c * out_chan + pos] = v;
-            s[t] += v;
-          }
+          const float v = acc[zo][j][r] + bias4[r];
+          acc[zo][j][r] = ok ? v : 0.0f;
+          if (ok) s += v;
         }
-    }
-  if (out_partials == nullptr) return;
-  auto half_wave_sum = [&](float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
-    v += __shfl_xor(v, 16, 64);
-    return v;
-  };
-  const int hi = lane >> 5;
-  int cnt_tile;
-  {
-    float c = (lane < 16) ? (float)cnt : 0.0f;
-    c = half_wave_sum(c);
-    __syncthreads();
-    if (lane == 0) red[wave] = c;
-    __syncthreads();
-    cnt_tile = (int)(red[0] + red[1] + red[2] + red[3]);
-    __syncthreads();
-  }
-  const float npos_out = (float)cnt_tile * 8.0f;
-  float m[2];
+        if ((g.W & 3) == 0) {   // 4 couts x 1 pixel -> 1 cout x 4 pixels, one 16-byte store
+          const floatx4 tv = quad_transpose(acc[zo][j], lane);
+          const int c = tw * 16 + cbase + (lane & 3);
+          if (ok) *reinterpret_cast<floatx4 *>(outn + (size_t)c * in_chan + (pos - (lane & 3))) = tv;
+        } else {
 #pragma unroll
-  for (int t = 0; t < 2; ++t) s[t] = half_wave_sum(s[t]);
-  if ((lane & 31) == 0) {
-    red[wave * 4 + 0 + hi] = s[0];
-    red[wave * 4 + 2 + hi] = s[1];
-  }
-  __syncthreads();
+          for (int r = 0; r < 4; ++r)
+            if (ok) outn[(size_t)(tw * 16 + cbase + r) * in_chan + pos] = acc[zo][j][r];
+        }
+      }
+    if (out_partials == nullptr) return;
+    // Per-wave GroupNorm partials (count, mean, M2), reduced with shuffles only -- no LDS, no barrier.
+    // Record (tile, wave) holds this wave's two groups; the other two are written with count 0.
+    auto half_wave_sum = [&](float v) {
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      return v;
+    };
+    const int hi = lane >> 5;
+    const float npos_out = half_wave_sum((lane & 16) == 0 ? (float)cnt : 0.0f) * 8.0f;
+    s = half_wave_sum(s);
+    const float m = npos_out > 0.0f ? s / npos_out : 0.0f;
+    float q = 0.f;
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    float tot = 0.f;
-    for (int w = 0; w < 4; ++w) tot += red[w * 4 + t * 2 + hi];
-    m[t] = cnt_tile > 0 ? tot / npos_out : 0.0f;
-  }
-  __syncthreads();
-  float q[2] = {0.f, 0.f};
+    for (int zo = 0; zo < TZO; ++zo)
 #pragma unroll
-  for (int zo = 0; zo < TZO; ++zo)
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-      const int pt = wave * NPT + j;
-      const bool ok = z0 + zo < g.D && y0 + (pt >> 1) < g.H && x0 + (pt & 1) * 16 + (lane & 15) < g.W;
-      if (ok) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
+      for (int j = 0; j < NPT; ++j) {
+        const int pt = half * NPT + j;
+        const bool ok = z0 + zo < g.D && y0 + (pt >> 1) < g.H && x0 + (pt & 1) * 16 + (lane & 15) < g.W;
+        if (ok) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float dv = acc[zo][j][t][r] - m[t];
-            q[t] += dv * dv;
+            const float dv = acc[zo][j][r] - m;
+            q += dv * dv;
           }
+        }
+      }
+    q = half_wave_sum(q);
+    if ((lane & 31) == 0) {
+      float *rec = out_partials + (((size_t)n * g.tiles + tile) * 4 + wave) * 12;
+      float *mine = rec + (tw * 2 + hi) * 3, *other = rec + ((1 - tw) * 2 + hi) * 3;
+      mine[0] = npos_out, mine[1] = m, mine[2] = q;
+      other[0] = 0.0f, other[1] = 0.0f, other[2] = 0.0f;
+    }
+  };
+
+  bf16x8 wh[9], wl[9];
+  int slab_tz = -1;
+  auto load_slab = [&](int tz) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const uintx4 *wt = wpk + (size_t)(tz * 9 + k) * 256 + tw * 128 + lane;  // [tap][t][part][lane]
+      wh[k] = __builtin_bit_cast(bf16x8, wt[0]);
+      wl[k] = __builtin_bit_cast(bf16x8, wt[64]);
+    }
+    slab_tz = tz;
+  };
+  if (KD == 1) load_slab(0);
+
+  clear_acc();
+  int next = 0;
+  while (next < NSTAGE && !stage_valid(next)) ++next;  // uniform
+  if (next < NSTAGE) fetch(next);
+#pragma nounroll
+  while (next < NSTAGE) {
+    const int s = next;
+    BX_STAMP();
+    __syncthreads();  // the previous stage's MFMAs are done with the LDS plane (and scsh is visible)
+    BX_STAMP();
+    commit();
+    BX_STAMP();
+    __syncthreads();
+    BX_STAMP();
+    ++next;
+    while (next < NSTAGE && !stage_valid(next)) ++next;
+    bool prefetched = false;
+    if (KD == 1) {
+      if (next < NSTAGE) fetch(next);  // in flight behind this stage's MFMAs
+      prefetched = true;
+    }
+
+    // One z-tap slab of weight fragments (9 taps x hi/lo of this wave's cout tile = 72 VGPRs) is read
+    // ahead of the MFMAs that use it.  vmcnt retires in order, so a weight load issued after the
+    // prefetch of the next stage would wait for that prefetch: the 2-D slab is therefore loaded once
+    // per workgroup (before any prefetch), and the first 3-D slab of a stage before the stage's prefetch.
+#pragma unroll
+    for (int zo = 0; zo < TZO; ++zo) {
+      const int tz = KD == 3 ? s - zo : 0;  // z-tap through which output plane zo sees this input plane
+      if (tz < 0 || tz >= KD) continue;     // uniform
+      if (KD == 3) {
+        if (tz != slab_tz) load_slab(tz);
+        if (!prefetched) {
+          if (next < NSTAGE) fetch(next);    // in flight behind this stage's MFMAs
+          prefetched = true;
+        }
+      }
+      // 9 taps x NPT pixel tiles, flattened and taken two steps at a time: the three split products of a
+      // step accumulate into the same registers (a dependent MFMA chain), so the products of two steps
+      // are interleaved, and the B fragments (hi, lo: two 16-byte LDS reads per step) of the next pair
+      // are already in flight -- three 16-cycle MFMAs do not cover an LDS round trip.
+      constexpr int NPAIR = 9 * NPT / 2;
+      uintx4 fh[2][2], fl[2][2];
+      auto frag = [&](int step, uintx4 &h, uintx4 &l) {
+        const int tap = step / NPT, j = step - tap * NPT;
+        const int toff = ((tap / 3) * DIL * HX + (tap % 3) * DIL) * BX_REC;   // compile-time: a ds_read immediate
+        const unsigned int *rec = plane + prec[j] + toff;
+        h = *reinterpret_cast<const uintx4 *>(rec);
+        l = *reinterpret_cast<const uintx4 *>(rec + 16);
+      };
+      frag(0, fh[0][0], fl[0][0]);
+      frag(1, fh[0][1], fl[0][1]);
+#pragma unroll
+      for (int pr = 0; pr < NPAIR; ++pr) {
+        const int cur = pr & 1;
+        if (pr + 1 < NPAIR) {
+          frag(2 * pr + 2, fh[cur ^ 1][0], fl[cur ^ 1][0]);
+          frag(2 * pr + 3, fh[cur ^ 1][1], fl[cur ^ 1][1]);
+        }
+        const int tap = (2 * pr) / NPT, j0 = 2 * pr - tap * NPT, j1 = j0 + 1;   // NPT is even: same tap
+        const bf16x8 ah = wh[tap], al = wl[tap];
+        const bf16x8 bh0 = __builtin_bit_cast(bf16x8, fh[cur][0]), bl0 = __builtin_bit_cast(bf16x8, fl[cur][0]);
+        const bf16x8 bh1 = __builtin_bit_cast(bf16x8, fh[cur][1]), bl1 = __builtin_bit_cast(bf16x8, fl[cur][1]);
+        acc[zo][j0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh0, acc[zo][j0], 0, 0, 0);
+        acc[zo][j1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh1, acc[zo][j1], 0, 0, 0);
+        acc[zo][j0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl0, acc[zo][j0], 0, 0, 0);
+        acc[zo][j1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl1, acc[zo][j1], 0, 0, 0);
+        acc[zo][j0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh0, acc[zo][j0], 0, 0, 0);
+        acc[zo][j1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh1, acc[zo][j1], 0, 0, 0);
       }
     }
-#pragma unroll
-  for (int t = 0; t < 2; ++t) q[t] = half_wave_sum(q[t]);
-  if ((lane & 31) == 0) {
-    red[wave * 4 + 0 + hi] = q[0];
-    red[wave * 4 + 2 + hi] = q[1];
-  }
-  __syncthreads();
-  if (wave == 0 && (lane & 31) == 0) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      float tot = 0.f;
-      for (int w = 0; w < 4; ++w) tot += red[w * 4 + t * 2 + hi];
-      float *p = out_partials + (((size_t)n * g.tiles + blockIdx.x) * 4 + (t * 2 + hi)) * 3;
-      p[0] = npos_out;
-      p[1] = m[t];
-      p[2] = tot;
+    if (KD == 3 && !prefetched && next < NSTAGE) fetch(next);
+    BX_STAMP();
+    if (KD == 1) {  // every 2-D stage is a finished tile
+      epilogue(tile_of(s));
+      clear_acc();
     }
   }
+  BX_STAMP();   // before the (3-D) epilogue
+  if (KD == 3) epilogue(tile_of(0));
+  BX_STAMP();   // kernel exit
 }
 
 // ---- device self-test of the bf16 fragment mapping -----------------------------------------------------
@@ -294,7 +394,7 @@ bool bf16x3_geom(const mvsn_conv_desc *d, Bf16x3Geom *g) {
   if (!(d->kd == 1 || d->kd == 3) || (d->kd == 1 && d->depth != 1) || d->dilation < 1) return false;
   g->n = d->n, g->D = d->depth, g->H = d->rows, g->W = d->cols, g->dil = d->dilation, g->kd = d->kd;
   g->tzo = d->kd == 3 ? 4 : 1;
-  g->ty = 8;
+  g->ty = 4;
   g->HY = g->ty + 2 * g->dil;
   g->HX = 32 + 2 * g->dil;
   g->ntz = (g->D + g->tzo - 1) / g->tzo;
@@ -302,6 +402,7 @@ bool bf16x3_geom(const mvsn_conv_desc *d, Bf16x3Geom *g) {
   g->ntx = (g->W + 31) / 32;
   g->tiles = g->ntz * g->nty * g->ntx;
   g->lds_bytes = ((size_t)g->HY * g->HX * BX_REC + 64 + 16) * 4;
+  if (d->dilation > 2) return false;   // (measured) dilation 4 needs 92 KB of LDS per workgroup and loses to fp32 MFMA
   return g->lds_bytes <= 160 * 1024 && (d->kd == 1 || d->dilation == 1);
 }
 
@@ -315,7 +416,6 @@ int bf16x3_pack(const mvsn_conv_desc *d, const float *weight, void *packed, hipS
 
 int bf16x3_launch(const Bf16x3Geom &g, const float *in, const void *wpk, const float *bias, const float *in_stats,
                   const float *in_gamma, const float *in_beta, float *out, float *out_partials, hipStream_t stream) {
-  dim3 grid(g.tiles, g.n);
 #define MVSN_BX_LAUNCH(...)                                                                                       \
   do {                                                                                                            \
     auto kern = conv_bf16x3_kernel<__VA_ARGS__>;                                                                  \
@@ -331,13 +431,18 @@ int bf16x3_launch(const Bf16x3Geom &g, const float *in, const void *wpk, const f
       opted = g.lds_bytes;                                                                                        \
     }                                                                                                             \
     hipLaunchKernelGGL(kern, grid, dim3(BX_THREADS), g.lds_bytes, stream, g, in, (const uintx4 *)wpk, bias, in_stats, \
-                       in_gamma, in_beta, out, out_partials);                                                     \
+                       in_gamma, in_beta, out, out_partials, dbgp);                                               \
   } while (0)
   const bool xf = in_stats != nullptr;
-  if (g.kd == 3) {
-    if (xf) MVSN_BX_LAUNCH(3, 4, 8, 1); else MVSN_BX_LAUNCH(3, 4, 8, 0);
-  } else {
-    if (xf) MVSN_BX_LAUNCH(1, 1, 8, 1); else MVSN_BX_LAUNCH(1, 1, 8, 0);
+  static unsigned long long *dbgp = getenv("MVSN_BX_DEBUG_PTR") ? (unsigned long long *)strtoull(getenv("MVSN_BX_DEBUG_PTR"), nullptr, 0) : nullptr;
+  constexpr int TPW2D = 8;
+  const dim3 grid(g.kd == 3 ? g.tiles : (g.tiles + TPW2D - 1) / TPW2D, g.n);
+  if (g.kd == 3) {          // TZO 4, TY 4: 6 x 34 positions -> 816 items -> 4 per thread
+    if (xf) MVSN_BX_LAUNCH(3, 4, 4, 1, 4, 1, 1); else MVSN_BX_LAUNCH(3, 4, 4, 1, 4, 0, 1);
+  } else if (g.dil == 1) {  // TY 4: 6 x 34 -> 816 items -> 4 per thread
+    if (xf) MVSN_BX_LAUNCH(1, 1, 4, TPW2D, 4, 1, 1); else MVSN_BX_LAUNCH(1, 1, 4, TPW2D, 4, 0, 1);
+  } else {                  // dilation 2: 8 x 36 -> 1152 items -> 5 per thread
+    if (xf) MVSN_BX_LAUNCH(1, 1, 4, TPW2D, 5, 1, 2); else MVSN_BX_LAUNCH(1, 1, 4, TPW2D, 5, 0, 2);
   }
 #undef MVSN_BX_LAUNCH
   return check_launch("mvsn_conv_forward(bf16x3)");
