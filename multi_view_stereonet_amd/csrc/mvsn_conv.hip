@@ -265,24 +265,29 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
     stage_store(chunk);
     __syncthreads();
     if (chunk + 1 < g.nchunks) stage_load(chunk + 1);
+    // taps software-pipelined by hand: the next tap's weight and activation fragments are read from LDS
+    // before the current tap's MFMAs are issued (the compiler otherwise waits lgkmcnt(0) per fragment)
     const float *wt = wl + lane;
+    float fw[2][2], fb[2][NPT];
+    auto read_tap = [&](int tap, int buf) {
+      const int tz = tap / (KH * KW), ty = (tap / KW) % KH, tx = tap % KW;
+      const float *bp = tile + (tz * g.HY + ty * g.dil) * g.XS + tx * g.dil;
+      fw[buf][0] = wt[tap * 128];
+      fw[buf][1] = CT == 2 ? wt[tap * 128 + 64] : 0.0f;
 #pragma unroll
-    for (int tz = 0; tz < KD; ++tz)
+      for (int j = 0; j < NPT; ++j) fb[buf][j] = bp[lpos[j]];
+    };
+    read_tap(0, 0);
 #pragma unroll
-      for (int ty = 0; ty < KH; ++ty)
+    for (int tap = 0; tap < NTAPS; ++tap) {
+      const int cur = tap & 1;
+      if (tap + 1 < NTAPS) read_tap(tap + 1, cur ^ 1);
 #pragma unroll
-        for (int tx = 0; tx < KW; ++tx) {
-          const int tap = (tz * KH + ty) * KW + tx;
-          const float *bp = tile + (tz * g.HY + ty * g.dil) * g.XS + tx * g.dil;
-          const float w0 = wt[tap * 128];
-          const float w1 = CT == 2 ? wt[tap * 128 + 64] : 0.0f;
-#pragma unroll
-          for (int j = 0; j < NPT; ++j) {
-            const float b = bp[lpos[j]];
-            acc[j][0] = mfma16x16x4(w0, b, acc[j][0]);
-            if (CT == 2) acc[j][CT - 1] = mfma16x16x4(w1, b, acc[j][CT - 1]);
-          }
-        }
+      for (int j = 0; j < NPT; ++j) {
+        acc[j][0] = mfma16x16x4(fw[cur][0], fb[cur][j], acc[j][0]);
+        if (CT == 2) acc[j][CT - 1] = mfma16x16x4(fw[cur][1], fb[cur][j], acc[j][CT - 1]);
+      }
+    }
   }
 
   // ---- epilogue: bias, store, GroupNorm partials ---------------------------------------------
@@ -533,23 +538,26 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_dma_kernel(ConvGeom g, con
 
     const float *tile = st;
     const float *wt = st + tile_floats * (MODE == 2 ? 2 : 1) + lane;
+    float fw[2][2], fb[2][NPT];
+    auto read_tap = [&](int tap, int buf) {
+      const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
+      const float *bp = tile + (tz * g.HY + ty * g.dil) * g.XS + tx * g.dil;
+      fw[buf][0] = wt[tap * 128];
+      fw[buf][1] = CT == 2 ? wt[tap * 128 + 64] : 0.0f;
 #pragma unroll
-    for (int tz = 0; tz < KD; ++tz)
+      for (int j = 0; j < NPT; ++j) fb[buf][j] = bp[lpos[j]];
+    };
+    read_tap(0, 0);
 #pragma unroll
-      for (int ty = 0; ty < 3; ++ty)
+    for (int tap = 0; tap < NTAPS; ++tap) {   // next tap's fragments in flight behind this tap's MFMAs
+      const int cur = tap & 1;
+      if (tap + 1 < NTAPS) read_tap(tap + 1, cur ^ 1);
 #pragma unroll
-        for (int tx = 0; tx < 3; ++tx) {
-          const int tap = (tz * 3 + ty) * 3 + tx;
-          const float *bp = tile + (tz * g.HY + ty * g.dil) * g.XS + tx * g.dil;
-          const float w0 = wt[tap * 128];
-          const float w1 = CT == 2 ? wt[tap * 128 + 64] : 0.0f;
-#pragma unroll
-          for (int j = 0; j < NPT; ++j) {
-            const float b = bp[lpos[j]];
-            acc[j][0] = mfma16x16x4(w0, b, acc[j][0]);
-            if (CT == 2) acc[j][CT - 1] = mfma16x16x4(w1, b, acc[j][CT - 1]);
-          }
-        }
+      for (int j = 0; j < NPT; ++j) {
+        acc[j][0] = mfma16x16x4(fw[cur][0], fb[cur][j], acc[j][0]);
+        if (CT == 2) acc[j][CT - 1] = mfma16x16x4(fw[cur][1], fb[cur][j], acc[j][CT - 1]);
+      }
+    }
   }
 
   // ---- epilogue (same as the register-staged kernel) -----------------------------------------
@@ -690,28 +698,28 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
   const long stride = (long)gridDim.x * blockDim.x * 4;
   const bool vec_ok = (spatial & 3) == 0;
   if (vec_ok) {
-    // streaming pass: non-temporal 16-byte accesses, two independent iterations in flight per thread
+    // streaming pass: non-temporal 16-byte accesses, four independent iterations in flight per thread
     long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    for (; i + stride < spatial; i += 2 * stride) {
-      const floatx4 v0 = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(xp + i));
-      const floatx4 v1 = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(xp + i + stride));
-      floatx4 o0, o1;
+    for (; i + 3 * stride < spatial; i += 4 * stride) {
+      floatx4 v[4], o[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        o0[k] = lrelu02(v0[k] * sc + sh);
-        o1[k] = lrelu02(v1[k] * sc + sh);
-      }
+      for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(xp + i + u * stride));
       if (rp) {
-        const floatx4 r0 = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(rp + i));
-        const floatx4 r1 = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(rp + i + stride));
+        floatx4 rv[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          o0[k] += r0[k];
-          o1[k] += r1[k];
-        }
+        for (int u = 0; u < 4; ++u) rv[u] = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(rp + i + u * stride));
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[u][k] = lrelu02(v[u][k] * sc + sh) + rv[u][k];
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[u][k] = lrelu02(v[u][k] * sc + sh);
       }
-      *reinterpret_cast<floatx4 *>(op + i) = o0;
-      *reinterpret_cast<floatx4 *>(op + i + stride) = o1;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) __builtin_nontemporal_store(o[u], reinterpret_cast<floatx4 *>(op + i + u * stride));
     }
     for (; i < spatial; i += stride) {
       floatx4 v = *reinterpret_cast<const floatx4 *>(xp + i);
@@ -924,8 +932,8 @@ extern "C" int mvsn_groupnorm_lrelu_apply(const float *x, const float *stats, co
   MVSN_REQUIRE(x && stats && gamma && beta && out && n > 0 && spatial > 0, MVSN_E_BADARG,
                "mvsn_groupnorm_lrelu_apply: bad argument");
   MVSN_REQUIRE((long)n * 32 <= 65535, MVSN_E_TOOLARGE, "mvsn_groupnorm_lrelu_apply: batch too large for one launch");
-  long per = (spatial + 2047) / 2048;
-  int gx = (int)(per < 1 ? 1 : (per > 16 ? 16 : per));
+  long per = (spatial + 4095) / 4096;   // 4 float4 per thread per pass
+  int gx = (int)(per < 1 ? 1 : (per > 32 ? 32 : per));
   hipLaunchKernelGGL(mvsn::gn_apply_kernel, dim3(gx, n * 32), dim3(256), 0, (hipStream_t)stream, x, stats, gamma,
                      beta, residual, spatial, out);
   return mvsn::check_launch("mvsn_groupnorm_lrelu_apply");
