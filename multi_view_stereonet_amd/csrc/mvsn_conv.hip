@@ -109,6 +109,90 @@ __device__ __forceinline__ int xcd_tile_index(int bid, int tiles) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+// Shared epilogue of the fp32 kernels: bias, 16-byte stores after a quad transpose (4 couts x 1 pixel ->
+// 1 cout x 4 pixels), and per-wave GroupNorm partials (count, mean, M2) reduced with shuffles only -- no
+// LDS, no barrier.  Lane l holds couts t*16 + (l>>4)*4 + r of pixel column l&15 of each of its NPT pixel
+// tiles; the group of such a channel is 2t + (l>>5), and within a 32-lane half the lanes with bit 4 clear
+// hold each of the wave's pixels exactly once.
+template <int NPT, int CT>
+__device__ __forceinline__ void conv_epilogue(const ConvGeom &g, floatx4 (&acc)[NPT][CT], const int (&opos)[NPT],
+                                              int tid, int n, int tile_id, const float *__restrict__ bias,
+                                              float *__restrict__ out, float *__restrict__ out_partials) {
+  const int lane = tid & 63;
+  const int cbase = (lane >> 4) * 4;
+  const size_t out_chan = (size_t)g.Do * g.Ho * g.Wo;
+  float *outn = out + (size_t)n * g.cout * out_chan;
+  float s[2] = {0.f, 0.f};
+  int cnt = 0;
+  const bool vec_store = (g.Wo & 3) == 0;   // aligned quads of output columns are all inside or all outside
+#pragma unroll
+  for (int j = 0; j < NPT; ++j) {
+    const bool ok = opos[j] >= 0;
+    if (ok) cnt += 1;
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = t * 16 + cbase + r;
+        const float v = acc[j][t][r] + ((bias && c < g.cout) ? bias[c] : 0.0f);
+        acc[j][t][r] = v;
+        if (ok && c < g.cout) s[t] += v;
+      }
+      if (vec_store) {
+        const floatx4 tv = quad_transpose(acc[j][t], lane);
+        const int c = t * 16 + cbase + (lane & 3);
+        if (ok && c < g.cout) *reinterpret_cast<floatx4 *>(outn + (size_t)c * out_chan + (opos[j] - (lane & 3))) = tv;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = t * 16 + cbase + r;
+          if (ok && c < g.cout) outn[(size_t)c * out_chan + opos[j]] = acc[j][t][r];
+        }
+      }
+    }
+  }
+  if (out_partials == nullptr || CT != 2) return;  // uniform; partials need all 32 channels (host-checked)
+  auto half_wave_sum = [&](float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    return v;
+  };
+  const int hi = lane >> 5;
+  const float npos = half_wave_sum((lane & 16) == 0 ? (float)cnt : 0.0f) * 8.0f;
+  float m[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    s[t] = half_wave_sum(s[t]);
+    m[t] = npos > 0.0f ? s[t] / npos : 0.0f;
+  }
+  float q[2] = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < NPT; ++j)
+    if (opos[j] >= 0) {
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float dv = acc[j][t][r] - m[t];
+          q[t] += dv * dv;
+        }
+    }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) q[t] = half_wave_sum(q[t]);
+  if ((lane & 31) == 0) {
+    float *rec = out_partials + (((size_t)n * g.tiles + tile_id) * 4 + (tid >> 6)) * 12;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      rec[(t * 2 + hi) * 3 + 0] = npos;
+      rec[(t * 2 + hi) * 3 + 1] = m[t];
+      rec[(t * 2 + hi) * 3 + 2] = q[t];
+    }
+  }
+}
+
 // NPT   pixel tiles (16 output columns each) per wave = TZ*TY*2/4
 // KD/KH/KW/STRIDE compile-time so the tap loops unroll completely and LDS reads run ahead of the MFMAs
 // SE    staged input elements per thread per channel (upper bound, ceil(HZ*HY*HX/256))
@@ -139,7 +223,6 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
   float *tile = smem;                               // CV_CK * CST
   float *wl = tile + (size_t)CV_CK * g.CST;         // WFL
   float *scsh = wl + WFL;                           // 32 scale + 32 shift of the input transform
-  float *red = scsh + 64;                           // 4 waves x 4 groups
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = blockIdx.y;
@@ -290,84 +373,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
     }
   }
 
-  // ---- epilogue: bias, store, GroupNorm partials ---------------------------------------------
-  const int cbase = (lane >> 4) * 4;
-  const size_t out_chan = (size_t)g.Do * g.Ho * g.Wo;
-  float *outn = out + (size_t)n * g.cout * out_chan;
-  float s[2] = {0.f, 0.f};
-  int cnt = 0;
-  const bool vec_store = (g.Wo & 3) == 0;   // aligned quads of output columns are all inside or all outside
-#pragma unroll
-  for (int j = 0; j < NPT; ++j) {
-    const bool ok = opos[j] >= 0;
-    if (ok) cnt += 1;
-#pragma unroll
-    for (int t = 0; t < CT; ++t) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = t * 16 + cbase + r;
-        const float v = acc[j][t][r] + ((bias && c < g.cout) ? bias[c] : 0.0f);
-        acc[j][t][r] = v;
-        if (ok && c < g.cout) s[t] += v;
-      }
-      if (vec_store) {   // 4 couts x 1 pixel -> 1 cout x 4 pixels, one 16-byte store
-        const floatx4 tv = quad_transpose(acc[j][t], lane);
-        const int c = t * 16 + cbase + (lane & 3);
-        if (ok && c < g.cout) *reinterpret_cast<floatx4 *>(outn + (size_t)c * out_chan + (opos[j] - (lane & 3))) = tv;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int c = t * 16 + cbase + r;
-          if (ok && c < g.cout) outn[(size_t)c * out_chan + opos[j]] = acc[j][t][r];
-        }
-      }
-    }
-  }
-  if (out_partials == nullptr) return;  // uniform across the grid
-  if (CT != 2) return;                  // partials need all 32 channels (checked on the host)
-
-  // Per-wave GroupNorm partials (count, mean, M2) of the wave's own positions, reduced with shuffles
-  // only -- no LDS, no barrier.  Group of channel t*16 + cbase + r is 2t + (lane >> 5); within a
-  // 32-lane half the lanes with bit 4 clear hold each of the wave's pixels exactly once.
-  auto half_wave_sum = [&](float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
-    v += __shfl_xor(v, 16, 64);
-    return v;
-  };
-  const int hi = lane >> 5;
-  const float npos = half_wave_sum((lane & 16) == 0 ? (float)cnt : 0.0f) * 8.0f;
-  float m[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    s[t] = half_wave_sum(s[t]);
-    m[t] = npos > 0.0f ? s[t] / npos : 0.0f;
-  }
-  float q[2] = {0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < NPT; ++j)
-    if (opos[j] >= 0) {
-#pragma unroll
-      for (int t = 0; t < CT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float dv = acc[j][t][r] - m[t];
-          q[t] += dv * dv;
-        }
-    }
-#pragma unroll
-  for (int t = 0; t < 2; ++t) q[t] = half_wave_sum(q[t]);
-  if ((lane & 31) == 0) {
-    float *rec = out_partials + (((size_t)n * g.tiles + tile_id) * 4 + (tid >> 6)) * 12;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      rec[(t * 2 + hi) * 3 + 0] = npos;
-      rec[(t * 2 + hi) * 3 + 1] = m[t];
-      rec[(t * 2 + hi) * 3 + 2] = q[t];
-    }
-  }
+  conv_epilogue<NPT, CT>(g, acc, opos, tid, n, tile_id, bias, out, out_partials);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -404,7 +410,6 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_dma_kernel(ConvGeom g, con
   const int tile_floats = CV_CK * g.CST;
   const int stage_floats = tile_floats * (MODE == 2 ? 2 : 1) + WSLOT;
   float *scsh = smem + 2 * stage_floats;        // 64
-  float *red = scsh + 64;                       // 16
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -560,83 +565,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_dma_kernel(ConvGeom g, con
     }
   }
 
-  // ---- epilogue (same as the register-staged kernel) -----------------------------------------
-  const int cbase = (lane >> 4) * 4;
-  const size_t out_chan = (size_t)g.Do * g.Ho * g.Wo;
-  float *outn = out + (size_t)n * g.cout * out_chan;
-  float s[2] = {0.f, 0.f};
-  int cnt = 0;
-  const bool vec_store = (g.Wo & 3) == 0;   // aligned quads of output columns are all inside or all outside
-#pragma unroll
-  for (int j = 0; j < NPT; ++j) {
-    const bool ok = opos[j] >= 0;
-    if (ok) cnt += 1;
-#pragma unroll
-    for (int t = 0; t < CT; ++t) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = t * 16 + cbase + r;
-        const float v = acc[j][t][r] + ((bias && c < g.cout) ? bias[c] : 0.0f);
-        acc[j][t][r] = v;
-        if (ok && c < g.cout) s[t] += v;
-      }
-      if (vec_store) {   // 4 couts x 1 pixel -> 1 cout x 4 pixels, one 16-byte store
-        const floatx4 tv = quad_transpose(acc[j][t], lane);
-        const int c = t * 16 + cbase + (lane & 3);
-        if (ok && c < g.cout) *reinterpret_cast<floatx4 *>(outn + (size_t)c * out_chan + (opos[j] - (lane & 3))) = tv;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int c = t * 16 + cbase + r;
-          if (ok && c < g.cout) outn[(size_t)c * out_chan + opos[j]] = acc[j][t][r];
-        }
-      }
-    }
-  }
-  if (out_partials == nullptr) return;
-  if (CT != 2) return;
-  // Per-wave GroupNorm partials (count, mean, M2) of the wave's own positions, reduced with shuffles
-  // only -- no LDS, no barrier.  Group of channel t*16 + cbase + r is 2t + (lane >> 5); within a
-  // 32-lane half the lanes with bit 4 clear hold each of the wave's pixels exactly once.
-  auto half_wave_sum = [&](float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
-    v += __shfl_xor(v, 16, 64);
-    return v;
-  };
-  const int hi = lane >> 5;
-  const float npos = half_wave_sum((lane & 16) == 0 ? (float)cnt : 0.0f) * 8.0f;
-  float m[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    s[t] = half_wave_sum(s[t]);
-    m[t] = npos > 0.0f ? s[t] / npos : 0.0f;
-  }
-  float q[2] = {0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < NPT; ++j)
-    if (opos[j] >= 0) {
-#pragma unroll
-      for (int t = 0; t < CT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float dv = acc[j][t][r] - m[t];
-          q[t] += dv * dv;
-        }
-    }
-#pragma unroll
-  for (int t = 0; t < 2; ++t) q[t] = half_wave_sum(q[t]);
-  if ((lane & 31) == 0) {
-    float *rec = out_partials + (((size_t)n * g.tiles + tile_id) * 4 + (tid >> 6)) * 12;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      rec[(t * 2 + hi) * 3 + 0] = npos;
-      rec[(t * 2 + hi) * 3 + 1] = m[t];
-      rec[(t * 2 + hi) * 3 + 2] = q[t];
-    }
-  }
+  conv_epilogue<NPT, CT>(g, acc, opos, tid, n, tile_id, bias, out, out_partials);
 }
 
 // Chan et al. combination of per-tile (count, mean, M2) in double; one workgroup per (n, group).
