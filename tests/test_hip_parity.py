@@ -456,6 +456,31 @@ def test_unpack_batch_on_device_matches_host():
     close(dev["T_right_in_left"][1], host["T_right_in_left"][1], rtol=1e-6, atol=1e-7)
 
 
+def test_forward_properties_at_headline_size():
+    """Size-independent properties at 512x256 / D=64 / S=2 (no oracle needed):
+    * the order of the source views does not matter (the fusion is a mean);
+    * scaling every translation by k scales the level-4 idepth (raw and refined) by exactly 1/k: each source
+      is renormalised to unit baseline inside the forward and divided by its baseline afterwards
+      (:566-571, :615-619).  The finer levels refine in those units and are not scale-equivariant, which is
+      why multi_view_unpack_batch normalises the poses first."""
+    net = net_for("gta_sfm_150epochs")
+    batch = synthetic.make_batch(256, 512, 2, batch=2, seed=77, pose_jitter=0.15, smooth=True)
+    inp = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
+    lp, kp, ts, rp = to_dev(inp)
+    base = net(lp, kp, ts, rp, 64, True, [True] * 5)
+    swapped = net(lp, kp, ts[::-1], rp[::-1], 64, True, [True] * 5)
+    close(swapped["left_idepthmap_pyr"][0], base["left_idepthmap_pyr"][0].cpu(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(swapped["left_idepthmap_mask_pyr"][0], base["left_idepthmap_mask_pyr"][0])
+    k = 2.5
+    ts_k = [t_.clone() for t_ in ts]
+    for t_ in ts_k:
+        t_[:, :3, 3] *= k
+    scaled = net(lp, kp, ts_k, rp, 64, True, [True] * 5)
+    close(scaled["left_idepthmap_pyr"][4] * k, base["left_idepthmap_pyr"][4].cpu(), rtol=2e-5, atol=2e-6)
+    close(scaled["left_idepthmap_raw_pyr"][4] * k, base["left_idepthmap_raw_pyr"][4].cpu(), rtol=2e-5, atol=2e-6)
+    assert torch.equal(scaled["left_idepthmap_mask_pyr"][4], base["left_idepthmap_mask_pyr"][4])
+
+
 def test_forward_batch_independence_and_determinism():
     """Images are independent units: a batch of 3 equals three batches of 1, bit for
     bit except GroupNorm partial-combination order (none here: same tiles), and reruns agree."""
