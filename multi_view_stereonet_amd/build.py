@@ -36,6 +36,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(o)
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, s), "-o", o]
+        cmd += os.environ.get("MVSN_HIPCC_FLAGS", "").split()   # experiments: -D switches for A/B builds
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for cmd, p in procs:
         out, _ = p.communicate()
