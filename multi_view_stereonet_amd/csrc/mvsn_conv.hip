@@ -22,7 +22,25 @@ constexpr int CV_TX = 32;   // output columns per tile
 constexpr int CV_CK = 4;    // input channels per staged chunk = one MFMA k-step
 constexpr float CV_EPS = 1e-5f;
 
+// Division by a launch-invariant divisor: q = (mulhi(n, mul) + n) >> shift, exact for 0 <= n < 2^31.
+// The kernels' prologues decompose tile and staging indices with ~30 divisions; as generic integer
+// divisions (~40 instructions each, issued next to three MFMA-bound waves per SIMD) they made the
+// prologue a quarter of a workgroup's lifetime.
+struct FastDiv {
+  unsigned mul, shift;
+};
+static FastDiv make_fastdiv(unsigned d) {
+  unsigned s = 0;
+  while ((1u << s) < d) ++s;
+  const unsigned long long m = ((1ull << 32) * ((1ull << s) - d)) / d + 1;
+  return FastDiv{(unsigned)m, s};
+}
+__device__ __forceinline__ int fdiv(int n, FastDiv f) {
+  return (int)((__umulhi((unsigned)n, f.mul) + (unsigned)n) >> f.shift);
+}
+
 struct ConvGeom {
+  FastDiv fd_hx, fd_hy, fd_ntx, fd_nty, fd_ty;
   int n, cin, cout, D, H, W, Do, Ho, Wo;
   int kd, kh, kw, stride, dil, pd, ph, pw;
   int TZ, TY;           // output tile (TX = 32)
@@ -34,7 +52,12 @@ struct ConvGeom {
   int wfloats_chunk;    // ntaps * 2 cout-tiles * 64
   size_t lds_bytes;
   int se;               // staged elements per thread per channel
-  int dma_stage_floats; // LDS-DMA kernel: floats per pipeline stage without the residual tile
+  // LDS-DMA kernel: rows are staged as whole 16-byte pieces from the aligned column x0 - 4 (40 floats per
+  // row for any halo <= 4), so one DMA instruction moves 1 KB instead of 256 B
+  int dma_ok;           // cols % 4 == 0, stride 1, halo <= 4
+  int dXS, dCST, dipc;  // row stride (40), channel stride, 16-byte-piece instructions per channel
+  int dma_stage_floats; // floats per pipeline stage without the residual tile
+  FastDiv fd_10;
 };
 
 static bool make_geom(const mvsn_conv_desc *d, ConvGeom *g) {
@@ -69,6 +92,9 @@ static bool make_geom(const mvsn_conv_desc *d, ConvGeom *g) {
   g->nty = (g->Ho + g->TY - 1) / g->TY;
   g->ntx = (g->Wo + CV_TX - 1) / CV_TX;
   g->tiles = g->ntz * g->nty * g->ntx;
+  g->fd_hx = make_fastdiv((unsigned)g->HX), g->fd_hy = make_fastdiv((unsigned)g->HY);
+  g->fd_ntx = make_fastdiv((unsigned)g->ntx), g->fd_nty = make_fastdiv((unsigned)g->nty);
+  g->fd_ty = make_fastdiv((unsigned)g->TY);
   g->ntaps = d->kd * d->kh * d->kw;
   g->nchunks = (d->c_in + CV_CK - 1) / CV_CK;
   g->wfloats_chunk = g->ntaps * 2 * 64;
@@ -76,7 +102,12 @@ static bool make_geom(const mvsn_conv_desc *d, ConvGeom *g) {
   g->se = (g->HZ * g->HY * g->HX + CV_THREADS - 1) / CV_THREADS;
   {
     const int wslot = ((g->ntaps * 128 + 255) / 256) * 256;
-    g->dma_stage_floats = CV_CK * g->CST + wslot;   // + CV_CK * CST more when a residual tile is staged
+    g->dma_ok = (d->cols % 4 == 0 && d->stride == 1 && g->pw <= 4 && d->kw == 3) ? 1 : 0;
+    g->dXS = 40;
+    g->dipc = (g->HZ * g->HY * 10 + 63) / 64;
+    g->dCST = g->dipc * 256 + 16;                     // = 16 (mod 32): conflict-free 16-column x 4-channel reads
+    g->dma_stage_floats = CV_CK * g->dCST + wslot;    // + CV_CK * dCST more when a residual tile is staged
+    g->fd_10 = make_fastdiv(10u);
   }
   if (g->se > 6) return false;
   const bool k333 = d->kd == 3 && d->kh == 3 && d->kw == 3 && d->stride == 1;
@@ -109,80 +140,102 @@ __device__ __forceinline__ int xcd_tile_index(int bid, int tiles) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-// Shared epilogue of the fp32 kernels: bias, 16-byte stores after a quad transpose (4 couts x 1 pixel ->
-// 1 cout x 4 pixels), and per-wave GroupNorm partials (count, mean, M2) reduced with shuffles only -- no
-// LDS, no barrier.  Lane l holds couts t*16 + (l>>4)*4 + r of pixel column l&15 of each of its NPT pixel
-// tiles; the group of such a channel is 2t + (l>>5), and within a 32-lane half the lanes with bit 4 clear
-// hold each of the wave's pixels exactly once.
+// Shared epilogue of the fp32 kernels.  The MFMAs run with A = activations (16 pixels x 4 cins) and
+// B = weights (4 cins x 16 couts), so D = pixels x couts: lane l holds, for cout t*16 + (l & 15), the four
+// CONSECUTIVE pixels 4*(l>>4) + r of each of its NPT pixel tiles -- one 16-byte store per accumulator, no
+// transpose.  The output offset of the first of those four pixels and how many of them are inside the
+// image (0..4) are formed here from the tile origin (wave-uniform row arithmetic + one lane term), so no
+// per-tile position registers stay live across the MFMA loop.  Per-wave GroupNorm partials (count, mean, M2) are reduced
+// with shuffles only -- no LDS, no barrier: the group of a lane's channel is 2t + ((l>>3)&1).
 template <int NPT, int CT>
-__device__ __forceinline__ void conv_epilogue(const ConvGeom &g, floatx4 (&acc)[NPT][CT], const int (&opos)[NPT],
+__device__ __forceinline__ void conv_epilogue(const ConvGeom &g, floatx4 (&acc)[NPT][CT], int z0, int y0, int x0,
                                               int tid, int n, int tile_id, const float *__restrict__ bias,
                                               float *__restrict__ out, float *__restrict__ out_partials) {
   const int lane = tid & 63;
-  const int cbase = (lane >> 4) * 4;
+  const int cl = lane & 15;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int opos[NPT], ovalid[NPT];
+#pragma unroll
+  for (int j = 0; j < NPT; ++j) {
+    const int pt = wave_u * NPT + j;   // NPT is even: pixel tile j covers columns (j & 1) * 16 .. + 15
+    const int zz = fdiv(pt >> 1, g.fd_ty), yy = (pt >> 1) - zz * g.TY;
+    const int oz = z0 + zz, oy = y0 + yy, ox4 = x0 + (j & 1) * 16 + (lane >> 4) * 4;
+    const bool ok = oz < g.Do && oy < g.Ho && ox4 < g.Wo;
+    opos[j] = (oz * g.Ho + oy) * g.Wo + ox4;
+    ovalid[j] = ok ? min(4, g.Wo - ox4) : 0;
+  }
   const size_t out_chan = (size_t)g.Do * g.Ho * g.Wo;
   float *outn = out + (size_t)n * g.cout * out_chan;
   float s[2] = {0.f, 0.f};
   int cnt = 0;
-  const bool vec_store = (g.Wo & 3) == 0;   // aligned quads of output columns are all inside or all outside
+  float bv[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) bv[t] = (bias && t * 16 + cl < g.cout) ? bias[t * 16 + cl] : 0.0f;
 #pragma unroll
   for (int j = 0; j < NPT; ++j) {
-    const bool ok = opos[j] >= 0;
-    if (ok) cnt += 1;
+    cnt += ovalid[j];
 #pragma unroll
-    for (int t = 0; t < CT; ++t) {
+    for (int t = 0; t < CT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int c = t * 16 + cbase + r;
-        const float v = acc[j][t][r] + ((bias && c < g.cout) ? bias[c] : 0.0f);
+        const float v = acc[j][t][r] + bv[t];
         acc[j][t][r] = v;
-        if (ok && c < g.cout) s[t] += v;
+        if (r < ovalid[j]) s[t] += v;
       }
-      if (vec_store) {
-        const floatx4 tv = quad_transpose(acc[j][t], lane);
-        const int c = t * 16 + cbase + (lane & 3);
-        if (ok && c < g.cout) *reinterpret_cast<floatx4 *>(outn + (size_t)c * out_chan + (opos[j] - (lane & 3))) = tv;
-      } else {
+  }
+  if ((g.Wo & 3) == 0) {   // uniform: the four pixels are all inside or all outside, and 16-byte aligned
+#pragma unroll
+    for (int j = 0; j < NPT; ++j)
+#pragma unroll
+      for (int t = 0; t < CT; ++t) {
+        const int c = t * 16 + cl;
+        if (ovalid[j] == 4 && c < g.cout) *reinterpret_cast<floatx4 *>(outn + (size_t)c * out_chan + opos[j]) = acc[j][t];
+      }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NPT; ++j)
+#pragma unroll
+      for (int t = 0; t < CT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int c = t * 16 + cbase + r;
-          if (ok && c < g.cout) outn[(size_t)c * out_chan + opos[j]] = acc[j][t][r];
+          const int c = t * 16 + cl;
+          if (r < ovalid[j] && c < g.cout) outn[(size_t)c * out_chan + opos[j] + r] = acc[j][t][r];
         }
-      }
-    }
   }
   if (out_partials == nullptr || CT != 2) return;  // uniform; partials need all 32 channels (host-checked)
-  auto half_wave_sum = [&](float v) {
+  auto pixel_sum = [&](float v) {   // over the lanes holding the same cout: bits 4, 5
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+  };
+  auto group_sum = [&](float v) {   // over the 8 couts of a group (bits 0-2) and all pixels (bits 4, 5)
     v += __shfl_xor(v, 1, 64);
     v += __shfl_xor(v, 2, 64);
     v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
-    v += __shfl_xor(v, 16, 64);
-    return v;
+    return pixel_sum(v);
   };
-  const int hi = lane >> 5;
-  const float npos = half_wave_sum((lane & 16) == 0 ? (float)cnt : 0.0f) * 8.0f;
+  const int hi = (lane >> 3) & 1;
+  const float npos = pixel_sum((float)cnt) * 8.0f;
   float m[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    s[t] = half_wave_sum(s[t]);
+    s[t] = group_sum(s[t]);
     m[t] = npos > 0.0f ? s[t] / npos : 0.0f;
   }
   float q[2] = {0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < NPT; ++j)
-    if (opos[j] >= 0) {
 #pragma unroll
-      for (int t = 0; t < CT; ++t)
+    for (int t = 0; t < CT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < 4; ++r)
+        if (r < ovalid[j]) {
           const float dv = acc[j][t][r] - m[t];
           q[t] += dv * dv;
         }
-    }
 #pragma unroll
-  for (int t = 0; t < 2; ++t) q[t] = half_wave_sum(q[t]);
-  if ((lane & 31) == 0) {
+  for (int t = 0; t < 2; ++t) q[t] = group_sum(q[t]);
+  if ((lane & 0x37) == 0) {   // lanes 0 and 8
     float *rec = out_partials + (((size_t)n * g.tiles + tile_id) * 4 + (tid >> 6)) * 12;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -224,30 +277,24 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
   float *wl = tile + (size_t)CV_CK * g.CST;         // WFL
   float *scsh = wl + WFL;                           // 32 scale + 32 shift of the input transform
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = blockIdx.y;
   const int tile_id = xcd_tile_index(blockIdx.x, g.tiles);
-  int tix = tile_id;
-  const int txi = tix % g.ntx;
-  tix /= g.ntx;
-  const int tyi = tix % g.nty;
-  const int tzi = tix / g.nty;
+  const int trow = fdiv(tile_id, g.fd_ntx), txi = tile_id - trow * g.ntx;
+  const int tzi = fdiv(trow, g.fd_nty), tyi = trow - tzi * g.nty;
   const int z0 = tzi * g.TZ, y0 = tyi * g.TY, x0 = txi * CV_TX;  // output-space origin
   const int gz0 = z0 - g.pd, gy0 = y0 * STRIDE - g.ph, gx0 = x0 * STRIDE - g.pw;  // input-space origin
   const size_t in_plane = (size_t)g.H * g.W, in_chan = (size_t)g.D * in_plane;
   const float *inn = in + (size_t)n * g.cin * in_chan;
 
   // this lane's output positions
-  int lpos[NPT];      // offset of (z, y, x) in the staged tile (tap (0,0,0))
-  int opos[NPT];      // offset in the output plane, -1 when outside
+  int lpos[NPT];      // fragment read: offset of (z, y, x = column lane&15) in the staged tile (tap (0,0,0))
 #pragma unroll
   for (int j = 0; j < NPT; ++j) {
     const int pt = wave * NPT + j;
-    const int xt = pt & 1, yy = (pt >> 1) % g.TY, zz = (pt >> 1) / g.TY;
+    const int xt = pt & 1, zz = fdiv(pt >> 1, g.fd_ty), yy = (pt >> 1) - zz * g.TY;
     const int xx = xt * 16 + (lane & 15);
-    const int oz = z0 + zz, oy = y0 + yy, ox = x0 + xx;
-    const bool ok = oz < g.Do && oy < g.Ho && ox < g.Wo;
-    opos[j] = ok ? (oz * g.Ho + oy) * g.Wo + ox : -1;
     lpos[j] = (zz * g.HY + yy * STRIDE) * g.XS + xx * STRIDE + (lane >> 4) * g.CST;
   }
 
@@ -260,8 +307,8 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
     const int e = tid + k * CV_THREADS;
     int off = -2;  // -2: beyond the tile, -1: zero padding
     if (e < tile_elems) {
-      const int row = e / g.HX, x = e - row * g.HX;
-      const int z = row / g.HY, y = row - z * g.HY;
+      const int row = fdiv(e, g.fd_hx), x = e - row * g.HX;
+      const int z = fdiv(row, g.fd_hy), y = row - z * g.HY;
       const int gz = gz0 + z, gy = gy0 + y, gx = gx0 + x;
       off = (gz >= 0 && gz < g.D && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) ? (gz * g.H + gy) * g.W + gx : -1;
       if (RES && off >= 0 && z >= g.pd && z < g.pd + g.TZ && y >= g.ph && y < g.ph + g.TY && x >= g.pw &&
@@ -367,20 +414,29 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
       if (tap + 1 < NTAPS) read_tap(tap + 1, cur ^ 1);
 #pragma unroll
       for (int j = 0; j < NPT; ++j) {
-        acc[j][0] = mfma16x16x4(fw[cur][0], fb[cur][j], acc[j][0]);
-        if (CT == 2) acc[j][CT - 1] = mfma16x16x4(fw[cur][1], fb[cur][j], acc[j][CT - 1]);
+        acc[j][0] = mfma16x16x4(fb[cur][j], fw[cur][0], acc[j][0]);   // D = pixels x couts
+        if (CT == 2) acc[j][CT - 1] = mfma16x16x4(fb[cur][j], fw[cur][1], acc[j][CT - 1]);
       }
     }
   }
 
-  conv_epilogue<NPT, CT>(g, acc, opos, tid, n, tile_id, bias, out, out_partials);
+  conv_epilogue<NPT, CT>(g, acc, z0, y0, x0, tid, n, tile_id, bias, out, out_partials);
 }
 
 // ---------------------------------------------------------------------------------------------
+#ifdef MVSN_DMA_STAMPS   // tuning aid (tools/dma_phases.py): s_memtime stamps of one mid-launch wave
+__device__ unsigned long long *g_dma_stamps = nullptr;
+#define DMA_STAMP() do { if (dbg && dbg_i < 60) dbg[dbg_i++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DMA_STAMP() do { } while (0)
+#endif
+
 // LDS-DMA variant (3x3 / 3x3x3, stride 1): the same implicit GEMM, but the haloed chunk tiles and the
 // weight fragments go HBM -> LDS with global_load_lds (no VGPR round trip, no LDS store pass) into a
 // two-stage ring, one barrier per chunk.  Wave w owns channel w of every 4-channel chunk: it issues
-// that channel's 64-element runs (per-lane source address, out-of-image lanes read a zero word), and
+// that channel's rows as 16-byte pieces, 1 KB per instruction (per-lane source address from the aligned
+// column x0 - 4; pieces outside the image read a zero word; requires cols % 4 == 0, otherwise the
+// register-staged kernel runs), and
 // once its own loads have landed it applies the fused input transform IN LDS on exactly those
 // elements -- LeakyReLU(GN(.)), optionally + residual (a whole SimpleBasicBlock folded into the next
 // layer's load) -- and writes the block output for its own output positions as a by-product.
@@ -392,7 +448,7 @@ __device__ floatx4 g_zero16 = {0.f, 0.f, 0.f, 0.f};
 #define MVSN_LPTR(p) ((__attribute__((address_space(3))) void *)(p))
 
 template <int NPT, int KD, int IPC, int CT, int MODE>
-__global__ __launch_bounds__(CV_THREADS, 2) void conv_dma_kernel(ConvGeom g, const float *__restrict__ in,
+__global__ __launch_bounds__(CV_THREADS, MODE <= 1 ? 4 : 2) void conv_dma_kernel(ConvGeom g, const float *__restrict__ in,
                                                                  const float *__restrict__ wpk,
                                                                  const float *__restrict__ bias,
                                                                  const float *__restrict__ in_stats,
@@ -407,19 +463,24 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_dma_kernel(ConvGeom g, con
   constexpr int WFL = NTAPS * 128;
   constexpr int WSLOT = ((WFL + 255) / 256) * 256;
   constexpr int WRUNS = WSLOT / 256;            // 16-byte DMA runs (256 floats each) per chunk
-  const int tile_floats = CV_CK * g.CST;
+  const int tile_floats = CV_CK * g.dCST;
   const int stage_floats = tile_floats * (MODE == 2 ? 2 : 1) + WSLOT;
   float *scsh = smem + 2 * stage_floats;        // 64
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = blockIdx.y;
+#ifdef MVSN_DMA_STAMPS
+  unsigned long long *dbg = (blockIdx.x == gridDim.x / 3 && blockIdx.y == gridDim.y / 2 && tid == 0) ? g_dma_stamps : nullptr;
+  int dbg_i = 0;
+#endif
+  DMA_STAMP();   // entry
+#ifdef MVSN_DMA_STAMPS
+  if (dbg) dbg[62] = wall_clock64();   // 100 MHz reference: (s_memtime span) / (this span) = shader clock
+#endif
   const int tile_id = xcd_tile_index(blockIdx.x, g.tiles);
-  int tix = tile_id;
-  const int txi = tix % g.ntx;
-  tix /= g.ntx;
-  const int tyi = tix % g.nty;
-  const int tzi = tix / g.nty;
+  const int trow = fdiv(tile_id, g.fd_ntx), txi = tile_id - trow * g.ntx;
+  const int tzi = fdiv(trow, g.fd_nty), tyi = trow - tzi * g.nty;
   const int z0 = tzi * g.TZ, y0 = tyi * g.TY, x0 = txi * CV_TX;
   const int gz0 = z0 - g.pd, gy0 = y0 - g.ph, gx0 = x0 - g.pw;
   const size_t in_plane = (size_t)g.H * g.W, in_chan = (size_t)g.D * in_plane;
@@ -427,35 +488,33 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_dma_kernel(ConvGeom g, con
   const float *resn = (MODE == 2 && in_residual) ? in_residual + (size_t)n * g.cin * in_chan : nullptr;
   float *stgn = (MODE == 2 && out_staged) ? out_staged + (size_t)n * g.cin * in_chan : nullptr;
 
-  int lpos[NPT], opos[NPT];
+  int lpos[NPT];   // see conv_mfma_kernel
 #pragma unroll
   for (int j = 0; j < NPT; ++j) {
-    const int pt = (tid >> 6) * NPT + j;
-    const int xt = pt & 1, yy = (pt >> 1) % g.TY, zz = (pt >> 1) / g.TY;
+    const int pt = wave * NPT + j;
+    const int xt = pt & 1, zz = fdiv(pt >> 1, g.fd_ty), yy = (pt >> 1) - zz * g.TY;
     const int xx = xt * 16 + (lane & 15);
-    const int oz = z0 + zz, oy = y0 + yy, ox = x0 + xx;
-    const bool ok = oz < g.Do && oy < g.Ho && ox < g.Wo;
-    opos[j] = ok ? (oz * g.Ho + oy) * g.Wo + ox : -1;
-    lpos[j] = (zz * g.HY + yy) * g.XS + xx + (lane >> 4) * g.CST;
+    lpos[j] = (zz * g.HY + yy) * g.dXS + xx + (4 - g.pw) + (lane >> 4) * g.dCST;
   }
 
-  // DMA plan of this lane: run i covers tile elements i*64 .. i*64+63 of the wave's channel
+  // DMA plan of this lane: piece i covers the 16-byte groups i*64 .. i*64+63 of the wave's channel, group
+  // e = row * 10 + q holding columns x0 - 4 + 4q .. + 3 of tile row `row` (aligned in global memory and in LDS;
+  // cols % 4 == 0, so a group is entirely inside or entirely outside the image)
   int goff[IPC];
   unsigned inimg = 0, interior = 0;
-  const int tile_elems = g.HZ * g.HY * g.HX;
+  const int tile_groups = g.HZ * g.HY * 10;
 #pragma unroll
   for (int i = 0; i < IPC; ++i) {
     const int e = i * 64 + lane;
     int off = -1;
-    if (i < g.ipc && e < tile_elems) {
-      const int row = e / g.HX, x = e - row * g.HX;
-      const int z = row / g.HY, y = row - z * g.HY;
-      const int gz = gz0 + z, gy = gy0 + y, gx = gx0 + x;
+    if (i < g.dipc && e < tile_groups) {
+      const int row = fdiv(e, g.fd_10), q = e - row * 10;
+      const int z = fdiv(row, g.fd_hy), y = row - z * g.HY;
+      const int gz = gz0 + z, gy = gy0 + y, gx = x0 - 4 + 4 * q;
       if (gz >= 0 && gz < g.D && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) {
         off = (gz * g.H + gy) * g.W + gx;
         inimg |= 1u << i;
-        if (z >= g.pd && z < g.pd + g.TZ && y >= g.ph && y < g.ph + g.TY && x >= g.pw && x < g.pw + CV_TX)
-          interior |= 1u << i;
+        if (z >= g.pd && z < g.pd + g.TZ && y >= g.ph && y < g.ph + g.TY && q >= 1 && q <= 8) interior |= 1u << i;
       }
     }
     goff[i] = off;
@@ -476,22 +535,22 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_dma_kernel(ConvGeom g, con
     const int c = chunk * CV_CK + wave;                      // this wave's channel
     const bool cok = c < g.cin;
     const float *src = inn + (size_t)(cok ? c : 0) * in_chan;
-    float *dst = st + wave * g.CST;
+    float *dst = st + wave * g.dCST;
 #pragma unroll
     for (int i = 0; i < IPC; ++i) {
-      if (i < g.ipc) {  // IPC is a compile-time upper bound; runs past g.ipc would leave the slot
+      if (i < g.dipc) {  // IPC is a compile-time upper bound; pieces past g.dipc would leave the slot
         const float *p = (cok && goff[i] >= 0) ? src + goff[i] : zero;
-        __builtin_amdgcn_global_load_lds(MVSN_GPTR(p), MVSN_LPTR(dst + i * 64), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(MVSN_GPTR(p), MVSN_LPTR(dst + i * 256), 16, 0, 0);
       }
     }
     if constexpr (MODE == 2) {
       const float *rsrc = resn ? resn + (size_t)(cok ? c : 0) * in_chan : nullptr;
-      float *rdst = st + tile_floats + wave * g.CST;
+      float *rdst = st + tile_floats + wave * g.dCST;
 #pragma unroll
       for (int i = 0; i < IPC; ++i) {
-        if (i < g.ipc) {
+        if (i < g.dipc) {
           const float *p = (rsrc && cok && goff[i] >= 0) ? rsrc + goff[i] : zero;
-          __builtin_amdgcn_global_load_lds(MVSN_GPTR(p), MVSN_LPTR(rdst + i * 64), 4, 0, 0);
+          __builtin_amdgcn_global_load_lds(MVSN_GPTR(p), MVSN_LPTR(rdst + i * 256), 16, 0, 0);
         }
       }
     }
@@ -515,38 +574,48 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_dma_kernel(ConvGeom g, con
     for (int t = 0; t < CT; ++t) acc[j][t] = floatx4{0.f, 0.f, 0.f, 0.f};
 
   issue(0, 0);
+  DMA_STAMP();   // prologue done, first chunk issued
   for (int chunk = 0; chunk < g.nchunks; ++chunk) {
     const int stage = chunk & 1;
     float *st = smem + stage * stage_floats;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA runs for `chunk` have landed
+    DMA_STAMP();   // landed
     if constexpr (MODE >= 1) {
       // fused input transform on the elements this wave loaded (its channel of the chunk)
       if (chunk == 0) __syncthreads();   // scsh visible
       const int c = chunk * CV_CK + wave;
       if (c < g.cin) {
         const float sc = scsh[c], sh = scsh[32 + c];
-        float *tl = st + wave * g.CST + lane;
+        float *tl = st + wave * g.dCST + lane * 4;
         float *stg = stgn ? stgn + (size_t)c * in_chan : nullptr;
 #pragma unroll
         for (int i = 0; i < IPC; ++i) {
           if ((inimg >> i) & 1u) {
-            float v = lrelu02(tl[i * 64] * sc + sh);
-            if constexpr (MODE == 2) v += tl[tile_floats + i * 64];
-            tl[i * 64] = v;
-            if (MODE == 2 && stg && ((interior >> i) & 1u)) stg[goff[i]] = v;
+            floatx4 v = *reinterpret_cast<floatx4 *>(tl + i * 256);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = lrelu02(v[r] * sc + sh);
+            if constexpr (MODE == 2) {
+              const floatx4 rv = *reinterpret_cast<const floatx4 *>(tl + tile_floats + i * 256);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += rv[r];
+            }
+            *reinterpret_cast<floatx4 *>(tl + i * 256) = v;
+            if (MODE == 2 && stg && ((interior >> i) & 1u)) *reinterpret_cast<floatx4 *>(stg + goff[i]) = v;
           }
         }
       }
     }
     __syncthreads();  // every wave's channel is in place; everyone is done with the other stage
+    DMA_STAMP();   // barrier passed
     if (chunk + 1 < g.nchunks) issue(chunk + 1, stage ^ 1);
+    DMA_STAMP();   // next chunk issued
 
     const float *tile = st;
     const float *wt = st + tile_floats * (MODE == 2 ? 2 : 1) + lane;
     float fw[2][2], fb[2][NPT];
     auto read_tap = [&](int tap, int buf) {
       const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
-      const float *bp = tile + (tz * g.HY + ty * g.dil) * g.XS + tx * g.dil;
+      const float *bp = tile + (tz * g.HY + ty * g.dil) * g.dXS + tx * g.dil;
       fw[buf][0] = wt[tap * 128];
       fw[buf][1] = CT == 2 ? wt[tap * 128 + 64] : 0.0f;
 #pragma unroll
@@ -559,13 +628,18 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_dma_kernel(ConvGeom g, con
       if (tap + 1 < NTAPS) read_tap(tap + 1, cur ^ 1);
 #pragma unroll
       for (int j = 0; j < NPT; ++j) {
-        acc[j][0] = mfma16x16x4(fw[cur][0], fb[cur][j], acc[j][0]);
-        if (CT == 2) acc[j][CT - 1] = mfma16x16x4(fw[cur][1], fb[cur][j], acc[j][CT - 1]);
+        acc[j][0] = mfma16x16x4(fb[cur][j], fw[cur][0], acc[j][0]);   // D = pixels x couts
+        if (CT == 2) acc[j][CT - 1] = mfma16x16x4(fb[cur][j], fw[cur][1], acc[j][CT - 1]);
       }
     }
+    DMA_STAMP();   // MFMAs issued
   }
 
-  conv_epilogue<NPT, CT>(g, acc, opos, tid, n, tile_id, bias, out, out_partials);
+  conv_epilogue<NPT, CT>(g, acc, z0, y0, x0, tid, n, tile_id, bias, out, out_partials);
+  DMA_STAMP();   // epilogue issued
+#ifdef MVSN_DMA_STAMPS
+  if (dbg) dbg[63] = wall_clock64();
+#endif
 }
 
 // Chan et al. combination of per-tile (count, mean, M2) in double; one workgroup per (n, group).
@@ -762,9 +836,9 @@ extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, co
   // ---- LDS-DMA pipeline for the 2-D 3x3 stride-1 layers with dilation <= 4 ---------------------
   // (measured on MI355X, B=128: 2-5 % faster than register staging there, 7 % slower on the 3-D
   // layers where the in-LDS transform pass is exposed, and 8 % slower at dilation 8)
-  if (g.kd == 1 && g.kh == 3 && g.stride == 1 && g.dil <= 4) {
+  if (g.kd == 1 && g.kh == 3 && g.stride == 1 && g.dil <= 4 && g.dma_ok) {
     const int mode = (in_residual || out_staged) ? 2 : (in_stats ? 1 : 0);
-    const size_t stage = (size_t)g.dma_stage_floats + (mode == 2 ? (size_t)CV_CK * g.CST : 0);
+    const size_t stage = (size_t)g.dma_stage_floats + (mode == 2 ? (size_t)CV_CK * g.dCST : 0);
     const size_t lds = (2 * stage + 64 + 16) * sizeof(float);
     const bool one = g.cout <= 16;
 #define MVSN_DMA_LAUNCH(...)                                                                                      \
@@ -795,13 +869,9 @@ extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, co
       else MVSN_DMA_LAUNCH(NPTV, KDV, IPCV, 2, 2);                                               \
     }                                                                                            \
   } while (0)
-    if (lds <= 160 * 1024) {
-      if (g.TY == 16) {
-        if (g.ipc <= 12) MVSN_DMA_MODES(8, 1, 12);
-      } else {
-        if (g.ipc <= 12) MVSN_DMA_MODES(4, 1, 12);
-        else if (g.ipc <= 18) MVSN_DMA_MODES(4, 1, 18);
-      }
+    if (lds <= 160 * 1024 && g.dipc <= 4) {
+      if (g.TY == 16) MVSN_DMA_MODES(8, 1, 4);
+      else MVSN_DMA_MODES(4, 1, 4);
     }
 #undef MVSN_DMA_MODES
 #undef MVSN_DMA_LAUNCH
@@ -848,6 +918,12 @@ extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, co
 #undef MVSN_CONV_LAUNCH
   return check_launch("mvsn_conv_forward");
 }
+
+#ifdef MVSN_DMA_STAMPS
+extern "C" int mvsn_debug_set_dma_stamps(void *buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(mvsn::g_dma_stamps), &buf, sizeof(buf));
+}
+#endif
 
 extern "C" int mvsn_groupnorm_finalize(const float *partials, int n, int tiles, float *stats, mvsn_stream_t stream) {
   MVSN_REQUIRE(partials && stats && n > 0 && tiles > 0, MVSN_E_BADARG, "mvsn_groupnorm_finalize: bad argument");
