@@ -26,6 +26,13 @@ constexpr float CV_EPS = 1e-5f;
 // The kernels' prologues decompose tile and staging indices with ~30 divisions; as generic integer
 // divisions (~40 instructions each, issued next to three MFMA-bound waves per SIMD) they made the
 // prologue a quarter of a workgroup's lifetime.
+#ifndef MVSN_TALL_TILE_MAX_DIL
+#define MVSN_TALL_TILE_MAX_DIL 8   // 2-D 3x3 layers up to this dilation use 16-row tiles (measured: 2/4/8 within 1.5 %)
+#endif
+#ifndef MVSN_DMA_MAX_DIL
+#define MVSN_DMA_MAX_DIL 8         // 2-D 3x3 layers up to this dilation run on the LDS-DMA kernel (cols % 4 == 0)
+#endif
+
 struct FastDiv {
   unsigned mul, shift;
 };
@@ -52,12 +59,13 @@ struct ConvGeom {
   int wfloats_chunk;    // ntaps * 2 cout-tiles * 64
   size_t lds_bytes;
   int se;               // staged elements per thread per channel
-  // LDS-DMA kernel: rows are staged as whole 16-byte pieces from the aligned column x0 - 4 (40 floats per
-  // row for any halo <= 4), so one DMA instruction moves 1 KB instead of 256 B
-  int dma_ok;           // cols % 4 == 0, stride 1, halo <= 4
-  int dXS, dCST, dipc;  // row stride (40), channel stride, 16-byte-piece instructions per channel
+  // LDS-DMA kernel: rows are staged as whole 16-byte pieces from the aligned column x0 - dpa (dpa = halo
+  // rounded up to 4: 40 floats per row for a halo <= 4, 48 for 8), so one DMA instruction moves 1 KB
+  int dma_ok;           // cols % 4 == 0, stride 1, halo <= 8
+  int dpa, dq;          // aligned halo, 16-byte pieces per row
+  int dXS, dCST, dipc;  // row stride (4 * dq), channel stride, piece instructions per channel
   int dma_stage_floats; // floats per pipeline stage without the residual tile
-  FastDiv fd_10;
+  FastDiv fd_dq;
 };
 
 static bool make_geom(const mvsn_conv_desc *d, ConvGeom *g) {
@@ -76,10 +84,15 @@ static bool make_geom(const mvsn_conv_desc *d, ConvGeom *g) {
   g->Wo = (d->cols - 1) / d->stride + 1;
   const bool is3d = d->depth > 1 || d->kd > 1;
   g->TZ = is3d ? 2 : 1;
-  // 2-D 3x3 layers on tall images use 16-row tiles (less halo per output, more MFMAs per staging)
-  // (measured on MI355X, B=128: dilation 4/8 layers are 10-17 % faster with 8-row tiles -- the 16-row
-  // halo no longer fits two workgroups' worth of staging registers -- dilation 1/2 layers are equal)
-  g->TY = (!is3d && d->kh == 3 && d->stride == 1 && d->dilation <= 2 && (d->rows - 1) / d->stride + 1 > 8) ? 16 : 8;
+  // 2-D 3x3 layers on tall images use 16-row tiles (less halo per output, more MFMAs per staging).  On the
+  // LDS-DMA kernel (cols % 4 == 0) that holds for every dilation (measured on MI355X, B=128: 8/16 rows within
+  // 1.5 % at dilation 4/8); the register-staged kernel keeps 8-row tiles above dilation 2, where the 16-row
+  // halo no longer fits two workgroups' worth of staging registers (10-17 % slower).
+  {
+    const bool dma = d->cols % 4 == 0 && d->dilation <= MVSN_DMA_MAX_DIL;
+    const int tall_dil = dma ? MVSN_TALL_TILE_MAX_DIL : 2;
+    g->TY = (!is3d && d->kh == 3 && d->stride == 1 && d->dilation <= tall_dil && (d->rows - 1) / d->stride + 1 > 8) ? 16 : 8;
+  }
   g->HZ = g->TZ + d->kd - 1;
   g->HY = (g->TY - 1) * d->stride + d->dilation * (d->kh - 1) + 1;
   g->HX = (CV_TX - 1) * d->stride + d->dilation * (d->kw - 1) + 1;
@@ -102,12 +115,14 @@ static bool make_geom(const mvsn_conv_desc *d, ConvGeom *g) {
   g->se = (g->HZ * g->HY * g->HX + CV_THREADS - 1) / CV_THREADS;
   {
     const int wslot = ((g->ntaps * 128 + 255) / 256) * 256;
-    g->dma_ok = (d->cols % 4 == 0 && d->stride == 1 && g->pw <= 4 && d->kw == 3) ? 1 : 0;
-    g->dXS = 40;
-    g->dipc = (g->HZ * g->HY * 10 + 63) / 64;
+    g->dma_ok = (d->cols % 4 == 0 && d->stride == 1 && g->pw <= 8 && d->kw == 3) ? 1 : 0;
+    g->dpa = (g->pw + 3) / 4 * 4;
+    g->dq = (CV_TX + 2 * g->dpa) / 4;
+    g->dXS = 4 * g->dq;
+    g->dipc = (g->HZ * g->HY * g->dq + 63) / 64;
     g->dCST = g->dipc * 256 + 16;                     // = 16 (mod 32): conflict-free 16-column x 4-channel reads
     g->dma_stage_floats = CV_CK * g->dCST + wslot;    // + CV_CK * dCST more when a residual tile is staged
-    g->fd_10 = make_fastdiv(10u);
+    g->fd_dq = make_fastdiv((unsigned)g->dq);
   }
   if (g->se > 6) return false;
   const bool k333 = d->kd == 3 && d->kh == 3 && d->kw == 3 && d->stride == 1;
@@ -435,7 +450,7 @@ __device__ unsigned long long *g_dma_stamps = nullptr;
 // weight fragments go HBM -> LDS with global_load_lds (no VGPR round trip, no LDS store pass) into a
 // two-stage ring, one barrier per chunk.  Wave w owns channel w of every 4-channel chunk: it issues
 // that channel's rows as 16-byte pieces, 1 KB per instruction (per-lane source address from the aligned
-// column x0 - 4; pieces outside the image read a zero word; requires cols % 4 == 0, otherwise the
+// column x0 - halo (rounded up to 4); pieces outside the image read a zero word; requires cols % 4 == 0, otherwise the
 // register-staged kernel runs), and
 // once its own loads have landed it applies the fused input transform IN LDS on exactly those
 // elements -- LeakyReLU(GN(.)), optionally + residual (a whole SimpleBasicBlock folded into the next
@@ -494,27 +509,27 @@ __global__ __launch_bounds__(CV_THREADS, MODE <= 1 ? 4 : 2) void conv_dma_kernel
     const int pt = wave * NPT + j;
     const int xt = pt & 1, zz = fdiv(pt >> 1, g.fd_ty), yy = (pt >> 1) - zz * g.TY;
     const int xx = xt * 16 + (lane & 15);
-    lpos[j] = (zz * g.HY + yy) * g.dXS + xx + (4 - g.pw) + (lane >> 4) * g.dCST;
+    lpos[j] = (zz * g.HY + yy) * g.dXS + xx + (g.dpa - g.pw) + (lane >> 4) * g.dCST;
   }
 
   // DMA plan of this lane: piece i covers the 16-byte groups i*64 .. i*64+63 of the wave's channel, group
-  // e = row * 10 + q holding columns x0 - 4 + 4q .. + 3 of tile row `row` (aligned in global memory and in LDS;
+  // e = row * dq + q holding columns x0 - dpa + 4q .. + 3 of tile row `row` (aligned in global memory and in LDS;
   // cols % 4 == 0, so a group is entirely inside or entirely outside the image)
   int goff[IPC];
   unsigned inimg = 0, interior = 0;
-  const int tile_groups = g.HZ * g.HY * 10;
+  const int tile_groups = g.HZ * g.HY * g.dq;
 #pragma unroll
   for (int i = 0; i < IPC; ++i) {
     const int e = i * 64 + lane;
     int off = -1;
     if (i < g.dipc && e < tile_groups) {
-      const int row = fdiv(e, g.fd_10), q = e - row * 10;
+      const int row = fdiv(e, g.fd_dq), q = e - row * g.dq;
       const int z = fdiv(row, g.fd_hy), y = row - z * g.HY;
-      const int gz = gz0 + z, gy = gy0 + y, gx = x0 - 4 + 4 * q;
+      const int gz = gz0 + z, gy = gy0 + y, gx = x0 - g.dpa + 4 * q;
       if (gz >= 0 && gz < g.D && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) {
         off = (gz * g.H + gy) * g.W + gx;
         inimg |= 1u << i;
-        if (z >= g.pd && z < g.pd + g.TZ && y >= g.ph && y < g.ph + g.TY && q >= 1 && q <= 8) interior |= 1u << i;
+        if (z >= g.pd && z < g.pd + g.TZ && y >= g.ph && y < g.ph + g.TY && 4 * q >= g.dpa && 4 * q < g.dpa + CV_TX) interior |= 1u << i;
       }
     }
     goff[i] = off;
@@ -836,7 +851,7 @@ extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, co
   // ---- LDS-DMA pipeline for the 2-D 3x3 stride-1 layers with dilation <= 4 ---------------------
   // (measured on MI355X, B=128: 2-5 % faster than register staging there, 7 % slower on the 3-D
   // layers where the in-LDS transform pass is exposed, and 8 % slower at dilation 8)
-  if (g.kd == 1 && g.kh == 3 && g.stride == 1 && g.dil <= 4 && g.dma_ok) {
+  if (g.kd == 1 && g.kh == 3 && g.stride == 1 && g.dil <= MVSN_DMA_MAX_DIL && g.dma_ok) {
     const int mode = (in_residual || out_staged) ? 2 : (in_stats ? 1 : 0);
     const size_t stage = (size_t)g.dma_stage_floats + (mode == 2 ? (size_t)CV_CK * g.dCST : 0);
     const size_t lds = (2 * stage + 64 + 16) * sizeof(float);
@@ -869,9 +884,14 @@ extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, co
       else MVSN_DMA_LAUNCH(NPTV, KDV, IPCV, 2, 2);                                               \
     }                                                                                            \
   } while (0)
-    if (lds <= 160 * 1024 && g.dipc <= 4) {
-      if (g.TY == 16) MVSN_DMA_MODES(8, 1, 4);
-      else MVSN_DMA_MODES(4, 1, 4);
+    if (lds <= 160 * 1024 && g.dipc <= 6) {
+      if (g.TY == 16) {
+        if (g.dipc <= 4) MVSN_DMA_MODES(8, 1, 4);
+        else MVSN_DMA_MODES(8, 1, 6);
+      } else {
+        if (g.dipc <= 4) MVSN_DMA_MODES(4, 1, 4);
+        else MVSN_DMA_MODES(4, 1, 6);
+      }
     }
 #undef MVSN_DMA_MODES
 #undef MVSN_DMA_LAUNCH
