@@ -155,7 +155,9 @@ int mvsn_groupnorm_lrelu_apply(const float *x, const float *stats, const float *
 /* ---------------------------------------------------------------------------------------------
  * 32 -> 1 channel 3x3 (kd = 1) or 3x3x3 (kd = 3) convolution, 'same' padding, dilation 1: the last
  * layer of CostVolumeFilter (conv4, :337,:351) and of every IDepthmapRefiner (conv_final, :464,:480).
- * HBM-bound, so it runs on the vector ALUs with float4 rows and wave shuffles instead of MFMA.
+ * HBM-bound (128 input bytes per output).  2-D: vector ALUs, float4 rows, halo columns by wave shuffle.
+ * 3-D: a tap GEMM P[27 taps][voxel] = W[27 x 32] * in[32 x voxel] on the fp32 matrix cores (every input
+ * element is loaded once), then a 27-term shift-and-add out of LDS.
  * With prior != NULL it also applies the refiner's epilogue (:482 and the gain trick :607-611):
  *     out = relu(prior * fx[n] + conv + bias) / fx[n]
  *   in (N,32,[D,]H,W)  weight (1,32,[3,]3,3) UNPACKED  bias (1) or NULL  prior (N,1,H,W)  fx (N)

@@ -277,9 +277,10 @@ extern "C" int mvsn_fuse_sources(const float *raw, const float *refined, const f
 // ---------------------------------------------------------------------------------------------
 // 32 -> 1 channel 3x3 / 3x3x3 convolution (the last layer of every refiner and of the regulariser)
 // ---------------------------------------------------------------------------------------------
-// One output channel has no cout dimension to put on MFMA (15/16 of a 16x16x4 tile would be wasted),
-// and at 128 input bytes per output the layer is HBM-bound: each thread owns 4 consecutive output
-// columns of one row, reads the three (or nine) neighbouring input rows of every channel as aligned
+// At 128 input bytes per output the layer is HBM-bound.  One output channel has no cout dimension to put
+// on MFMA directly; the 3-D layer (27 taps) instead puts the TAPS on it (tap GEMM, further down), the 2-D
+// layer (9 taps) runs on the vector ALUs: each thread owns 4 consecutive output
+// columns of one row, reads the three neighbouring input rows of every channel as aligned
 // float4 and takes the two halo columns from its lane neighbours with wave shuffles (a 16-lane group
 // spans 64 columns; only the group's edge lanes touch memory for the halo).  Weights are wave-uniform
 // (scalar loads).  Optional refiner epilogue: relu(prior*fx + conv + bias) / fx
@@ -300,11 +301,9 @@ __device__ __forceinline__ void load_row6(const float *__restrict__ row, bool ok
   r[0] = left, r[1] = v[0], r[2] = v[1], r[3] = v[2], r[4] = v[3], r[5] = right;
 }
 
-// Each thread owns 4 columns x RY rows (2-D) or 4 columns x 1 row x ZC planes (3-D) and walks the
-// input rows / planes once per channel with a rolling window, so a row is loaded once per RY (ZC)
-// outputs instead of three times.
+// 2-D: each thread owns 4 columns x RY rows and walks the input rows once per channel with a rolling
+// window, so a row is loaded once per RY outputs instead of three times.
 constexpr int TO1_RY = 4;   // 2-D: output rows per thread
-constexpr int TO1_ZC = 8;   // 3-D: output planes per thread
 
 __global__ __launch_bounds__(256) void conv_to1_2d_kernel(const float *__restrict__ in, const float *__restrict__ w,
                                                           const float *__restrict__ bias,
@@ -367,72 +366,127 @@ __global__ __launch_bounds__(256) void conv_to1_2d_kernel(const float *__restric
   }
 }
 
-// GW lanes (GW*4 columns) per row group; the thread-row index runs over (plane chunk, image row)
-// jointly so that narrow coarse-level planes (e.g. 16x32) still fill the workgroup.
-template <int GW>
-__global__ __launch_bounds__(256) void conv_to1_3d_kernel(const float *__restrict__ in, const float *__restrict__ w,
-                                                          const float *__restrict__ bias, int D, int H, int W,
-                                                          float *__restrict__ out) {
-  const int lane16 = threadIdx.x % GW;
-  const int x4 = (blockIdx.x * GW + lane16) * 4;
-  const int zchunks = (D + TO1_ZC - 1) / TO1_ZC;
-  const int rowid = blockIdx.y * (256 / GW) + threadIdx.x / GW;   // over zchunks * H
-  const bool row_ok = rowid < zchunks * H;
-  const int z0 = (row_ok ? rowid / H : 0) * TO1_ZC;
-  const int y = row_ok ? rowid % H : 0;
+// ---- 32 -> 1 channel 3x3x3 as a tap GEMM ------------------------------------------------------------------
+// out[z][y][x] = sum_tap P[tap][z + dz - 1][y + dy - 1][x + dx - 1],  P[tap][v] = sum_c w[c][tap] in[c][v].
+// P is a (27 x 32) by (32 x voxels) product: it runs on the fp32 matrix cores, every input element is read
+// from HBM exactly once (one 16-byte load feeds four MFMAs), and the 27-tap shift-and-add reads P back from
+// LDS.  A workgroup owns a 16 x 32 pixel tile and a slab of planes and streams through the slab: per input
+// plane it forms P over the haloed tile (18 rows x 40 columns from the aligned column x0 - 4 = 720 slots),
+// then every thread adds the plane's contribution to the three output planes it touches for its two pixels
+// (rolling accumulators) and writes the plane that just became complete.
+//   A = taps (16 per MFMA, 2 tiles) x 4 cins, held in registers for the whole kernel
+//   B = 4 cins x 16 slots: lane (k, i) loads slots 64g + 4i .. + 3 of channel 4 ks + k with one dwordx4;
+//       register p of that load is the B fragment of "slot tile p" = slots {64g + 4i + p}, so the four
+//       accumulators of a lane are four CONSECUTIVE slots of one tap row -> one 16-byte LDS write.
+constexpr int T3_TY = 16, T3_TX = 32;
+constexpr int T3_HY = T3_TY + 2, T3_XS = 40;          // haloed rows, row stride in slots
+constexpr int T3_SLOTS = T3_HY * T3_XS;               // 720
+constexpr int T3_GROUPS = (T3_SLOTS + 63) / 64;       // 12 groups of 64 slots, 3 per wave
+constexpr int T3_LDS_FLOATS = 27 * T3_SLOTS;          // 77,760 bytes: two workgroups per CU
+
+__global__ __launch_bounds__(256, 2) void conv_to1_3d_mfma_kernel(const float *__restrict__ in, const float *__restrict__ w,
+                                                                  const float *__restrict__ bias, int D, int H, int W,
+                                                                  int ntx, int zslab, float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float P[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = blockIdx.z;
+  const int tyi = blockIdx.x / ntx, txi = blockIdx.x - tyi * ntx;
+  const int y0 = tyi * T3_TY, x0 = txi * T3_TX;
+  const int zb = blockIdx.y * zslab, ze = min(D, zb + zslab);   // output planes [zb, ze)
   const size_t plane = (size_t)H * W, chan = (size_t)D * plane;
-  const float *inn = in + (size_t)n * 32 * chan;
-  float acc[TO1_ZC][4];
+  const float *inn = in + (size_t)n * 32 * chan + (size_t)(lane >> 4) * chan;   // this lane's k (cin within a k-step)
+
+  // tap weights as A fragments: a[t][ks] = w[cin = 4 ks + (lane>>4)][tap = 16 t + (lane&15)]
+  float a[2][8];
 #pragma unroll
-  for (int r = 0; r < TO1_ZC; ++r)
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[r][k] = 0.f;
-  for (int c = 0; c < 32; ++c) {
-    const float *ic = inn + (size_t)c * chan;
-    const float *wc = w + (size_t)c * 27;
+    for (int ks = 0; ks < 8; ++ks) {
+      const int tap = t * 16 + (lane & 15), c = ks * 4 + (lane >> 4);
+      a[t][ks] = tap < 27 ? w[c * 27 + tap] : 0.0f;
+    }
+
+  // this lane's slots: group g = wave + 4 u, slots 64 g + 4 (lane&15) .. + 3
+  constexpr int GPW = T3_GROUPS / 4;   // 3
+  int goff[GPW];
 #pragma unroll
-    for (int rz = 0; rz < TO1_ZC + 2; ++rz) {   // input plane z0 - 1 + rz feeds output planes rz-2 .. rz
-      const int zz = z0 - 1 + rz;
-      const bool zok = zz >= 0 && zz < D;
-      float s[3][4];                           // this plane's 3x3 row-convolved sums, one per dz weight slab
+  for (int u = 0; u < GPW; ++u) {
+    const int s0 = (wave + 4 * u) * 64 + 4 * (lane & 15);
+    const int row = s0 / T3_XS, col = s0 - row * T3_XS;
+    const int gy = y0 - 1 + row, gx = x0 - 4 + col;
+    goff[u] = (s0 < T3_SLOTS && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
+  }
+
+  // gather side: this thread's two output pixels (xx even)
+  const int oy = tid >> 4, ox = (tid & 15) * 2;
+  const bool o_ok = y0 + oy < H && x0 + ox < W;          // W % 4 == 0: both pixels or neither
+  const float *pg = P + oy * T3_XS + ox + 3;             // tap (dy, dx) adds dy * T3_XS + dx
+  float acc[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};   // output planes z-1, z, z+1 of the current input plane z
+  const float b = bias ? bias[0] : 0.0f;
+  float *outn = out + (size_t)n * chan + (size_t)(y0 + oy) * W + x0 + ox;
+
+  for (int z = zb - 1; z <= ze; ++z) {
+    if (z >= 0 && z < D) {   // uniform: planes outside the volume contribute nothing
+      // ---- P = taps x slots for plane z
+      floatx4 bfr[2][8];
+      auto load_group = [&](int u, floatx4 (&dst)[8]) {
+        const float *src = inn + (size_t)z * plane + (goff[u] >= 0 ? goff[u] : 0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+          dst[ks] = goff[u] >= 0 ? *reinterpret_cast<const floatx4 *>(src + (size_t)ks * 4 * chan) : floatx4{0.f, 0.f, 0.f, 0.f};
+      };
+      load_group(0, bfr[0]);
+#pragma unroll
+      for (int u = 0; u < GPW; ++u) {
+        if (u + 1 < GPW) load_group(u + 1, bfr[(u + 1) & 1]);
+        floatx4 d[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int p = 0; p < 4; ++p) d[t][p] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+          for (int p = 0; p < 4; ++p) {
+            d[0][p] = mfma16x16x4(a[0][ks], bfr[u & 1][ks][p], d[0][p]);
+            d[1][p] = mfma16x16x4(a[1][ks], bfr[u & 1][ks][p], d[1][p]);
+          }
+        // lane holds taps 16 t + 4 (lane>>4) + r of slots s0 .. s0 + 3
+        const int s0 = (wave + 4 * u) * 64 + 4 * (lane & 15);
+        if (s0 < T3_SLOTS) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int tap = t * 16 + (lane >> 4) * 4 + r;
+              if (tap < 27)
+                *reinterpret_cast<floatx4 *>(P + tap * T3_SLOTS + s0) = floatx4{d[t][0][r], d[t][1][r], d[t][2][r], d[t][3][r]};
+            }
+        }
+      }
+      __syncthreads();
+      // ---- shift-and-add: input plane z feeds output planes z + 1 (dz = 0), z (dz = 1), z - 1 (dz = 2)
 #pragma unroll
       for (int dz = 0; dz < 3; ++dz)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s[dz][k] = 0.f;
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const int yy = y + dy - 1;
-        const bool ok = row_ok && zok && yy >= 0 && yy < H && x4 < W;
-        float r6[6];
-        load_row6<GW>(ic + (size_t)(ok ? zz : 0) * plane + (size_t)(ok ? yy : 0) * W, ok, x4, W, lane16, r6);
-#pragma unroll
-        for (int dz = 0; dz < 3; ++dz) {
-          const float w0 = wc[dz * 9 + dy * 3], w1 = wc[dz * 9 + dy * 3 + 1], w2 = wc[dz * 9 + dy * 3 + 2];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) s[dz][k] += w0 * r6[k] + w1 * r6[k + 1] + w2 * r6[k + 2];
-        }
-      }
-#pragma unroll
-      for (int dz = 0; dz < 3; ++dz) {
-        const int oz = rz - dz;
-        if (oz >= 0 && oz < TO1_ZC) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) acc[oz][k] += s[dz][k];
-        }
-      }
+          for (int dx = 0; dx < 3; ++dx) {
+            const float *q = pg + (dz * 9 + dy * 3 + dx) * T3_SLOTS + dy * T3_XS + dx;
+            acc[2 - dz][0] += q[0];
+            acc[2 - dz][1] += q[1];
+          }
     }
-  }
-  if (x4 >= W || !row_ok) return;
-  const float b = bias ? bias[0] : 0.0f;
-#pragma unroll
-  for (int r = 0; r < TO1_ZC; ++r) {
-    const int z = z0 + r;
-    if (z >= D) break;
-    floatx4 res;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) res[k] = acc[r][k] + b;
-    *reinterpret_cast<floatx4 *>(out + ((size_t)n * D + z) * plane + (size_t)y * W + x4) = res;
+    // output plane z - 1 is complete
+    if (z - 1 >= zb && z - 1 < ze && o_ok) {
+      float2 v = make_float2(acc[0][0] + b, acc[0][1] + b);
+      *reinterpret_cast<float2 *>(outn + (size_t)(z - 1) * plane) = v;
+    }
+    acc[0][0] = acc[1][0], acc[0][1] = acc[1][1];
+    acc[1][0] = acc[2][0], acc[1][1] = acc[2][1];
+    acc[2][0] = 0.f, acc[2][1] = 0.f;
+    __syncthreads();   // everyone is done reading P before the next plane overwrites it
   }
 }
 
@@ -449,18 +503,27 @@ extern "C" int mvsn_conv_to1(const float *in, const float *weight, const float *
   MVSN_REQUIRE(cols % 4 == 0, MVSN_E_BADARG, "mvsn_conv_to1: cols must be a multiple of 4 (use mvsn_conv_forward)");
   MVSN_REQUIRE(!prior || (fx && depth == 1), MVSN_E_BADARG, "mvsn_conv_to1: refiner epilogue needs fx and 2-D input");
   if (kd == 3) {
-    const int zchunks = (depth + mvsn::TO1_ZC - 1) / mvsn::TO1_ZC;
-    const int gw = cols <= 32 ? 8 : 16;
-    const int rows_per_block = 256 / gw;
-    const int row_blocks = (zchunks * rows + rows_per_block - 1) / rows_per_block;
-    MVSN_REQUIRE(n <= 65535 && row_blocks <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_to1: grid");
-    dim3 grid((cols + gw * 4 - 1) / (gw * 4), row_blocks, n);
-    if (gw == 8)
-      hipLaunchKernelGGL(mvsn::conv_to1_3d_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, in, weight, bias, depth,
-                         rows, cols, out);
-    else
-      hipLaunchKernelGGL(mvsn::conv_to1_3d_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, in, weight, bias,
-                         depth, rows, cols, out);
+    using namespace mvsn;
+    // tap GEMM on the matrix cores; slabs of planes so that even one chain fills the chip
+    const int nty = (rows + T3_TY - 1) / T3_TY, ntx = (cols + T3_TX - 1) / T3_TX;
+    int nslab = 1;
+    while (nslab < 8 && (long)n * nty * ntx * nslab < 1024 && depth / (nslab * 2) >= 8) nslab *= 2;
+    const int zslab = (depth + nslab - 1) / nslab;
+    const int nz = (depth + zslab - 1) / zslab;
+    MVSN_REQUIRE(n <= 65535 && nz <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_to1: grid");
+    const size_t lds = (size_t)T3_LDS_FLOATS * sizeof(float);
+    static bool opted = false;
+    if (!opted) {
+      hipError_t e = hipFuncSetAttribute((const void *)conv_to1_3d_mfma_kernel,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) {
+        set_error("mvsn_conv_to1: LDS opt-in of %zu bytes failed: %s", lds, hipGetErrorString(e));
+        return (int)e;
+      }
+      opted = true;
+    }
+    hipLaunchKernelGGL(conv_to1_3d_mfma_kernel, dim3(nty * ntx, nz, n), dim3(256), lds, (hipStream_t)stream, in, weight,
+                       bias, depth, rows, cols, ntx, zslab, out);
   } else {
     MVSN_REQUIRE(depth == 1, MVSN_E_BADARG, "mvsn_conv_to1: kd = 1 needs depth = 1");
     const int ry = 16 * mvsn::TO1_RY;

@@ -199,7 +199,9 @@ def test_conv_with_folded_residual_block(rows, cols, dil, cout):
 
 
 @pytest.mark.parametrize("dims,depth,rows,cols,n", [(2, 1, 16, 32, 2), (2, 1, 37, 68, 1), (2, 1, 256, 512, 1), (2, 1, 5, 4, 3),
-                                                    (3, 8, 4, 8, 2), (3, 12, 16, 32, 1), (3, 5, 30, 40, 1)])
+                                                    (3, 8, 4, 8, 2), (3, 12, 16, 32, 1), (3, 5, 30, 40, 1),
+                                                    (3, 64, 16, 32, 2), (3, 96, 30, 40, 1), (3, 7, 32, 64, 1), (3, 1, 16, 32, 1),
+                                                    (3, 33, 17, 36, 1)])
 def test_conv_to1_vector_path(dims, depth, rows, cols, n):
     from multi_view_stereonet_amd.multi_view_stereonet import _Conv
     eng = net_for("gta_sfm_150epochs").engine()
