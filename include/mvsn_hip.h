@@ -151,13 +151,19 @@ int mvsn_groupnorm_finalize(const float *partials, int n, int tiles, float *stat
 /* out = [residual +] LeakyReLU_0.2(GroupNorm(x)) on (N,32,spatial); residual may be NULL; out may alias x */
 int mvsn_groupnorm_lrelu_apply(const float *x, const float *stats, const float *gamma, const float *beta,
                                const float *residual, int n, long spatial, float *out, mvsn_stream_t stream);
+/* out = LeakyReLU(GroupNorm(x)) + LeakyReLU(GroupNorm_r(r)): the first residual block of a refiner
+ * (:472-474) when the head's activation x0 = LReLU(GN(conv0)) is never materialised -- conv0's raw output r
+ * feeds block 1's convolution through mvsn_conv_forward's in_stats transform and this call as the residual. */
+int mvsn_groupnorm_lrelu_add2(const float *x, const float *stats, const float *gamma, const float *beta,
+                              const float *r, const float *r_stats, const float *r_gamma, const float *r_beta, int n,
+                              long spatial, float *out, mvsn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 32 -> 1 channel 3x3 (kd = 1) or 3x3x3 (kd = 3) convolution, 'same' padding, dilation 1: the last
  * layer of CostVolumeFilter (conv4, :337,:351) and of every IDepthmapRefiner (conv_final, :464,:480).
- * HBM-bound (128 input bytes per output).  2-D: vector ALUs, float4 rows, halo columns by wave shuffle.
- * 3-D: a tap GEMM P[27 taps][voxel] = W[27 x 32] * in[32 x voxel] on the fp32 matrix cores (every input
- * element is loaded once), then a 27-term shift-and-add out of LDS.
+ * HBM-bound (128 input bytes per output): a tap GEMM P[taps][position] = W[taps x 32] * in[32 x position]
+ * on the fp32 matrix cores (every input element is loaded once, 9 or 27 taps on the MFMA row dimension),
+ * then a shift-and-add of the tap planes out of LDS.
  * With prior != NULL it also applies the refiner's epilogue (:482 and the gain trick :607-611):
  *     out = relu(prior * fx[n] + conv + bias) / fx[n]
  *   in (N,32,[D,]H,W)  weight (1,32,[3,]3,3) UNPACKED  bias (1) or NULL  prior (N,1,H,W)  fx (N)
@@ -166,6 +172,13 @@ int mvsn_groupnorm_lrelu_apply(const float *x, const float *stats, const float *
 int mvsn_conv_to1_supported(int rows, int cols);
 int mvsn_conv_to1(const float *in, const float *weight, const float *bias, const float *prior, const float *fx,
                   int n, int depth, int rows, int cols, int kd, float *out, mvsn_stream_t stream);
+/* The same 2-D layer with the tower's LAST residual block folded into its load: the input
+ * in_residual + LeakyReLU(GroupNorm(in_raw)) (SimpleBasicBlock, multi_view_stereonet.py:21-38) is formed in
+ * registers from the raw output of the block's convolution and the block's input, never written.
+ *   in_raw, in_residual (N,32,H,W)  in_stats (N,4,2)  in_gamma, in_beta (32)  in_residual may be NULL */
+int mvsn_conv_to1_block(const float *in_raw, const float *in_stats, const float *in_gamma, const float *in_beta,
+                        const float *in_residual, const float *weight, const float *bias, const float *prior,
+                        const float *fx, int n, int rows, int cols, float *out, mvsn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Soft-argmin over the hypothesis axis: out = sum_d softmax(-cost)_d * idepth_d.

@@ -699,10 +699,16 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
 }
 
 // out = [residual +] LeakyReLU(GroupNorm(x)), (N,32,spatial), float4 per thread.
+// RRAW: the residual is itself a raw conv output whose LeakyReLU(GroupNorm(.)) was never materialised
+// (the head of a refiner): out = LReLU(GN(x)) + LReLU(GN_r(residual)).
+template <bool RRAW>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, const float *__restrict__ stats,
                                                        const float *__restrict__ gamma,
                                                        const float *__restrict__ beta,
-                                                       const float *__restrict__ residual, long spatial,
+                                                       const float *__restrict__ residual,
+                                                       const float *__restrict__ r_stats,
+                                                       const float *__restrict__ r_gamma,
+                                                       const float *__restrict__ r_beta, long spatial,
                                                        float *__restrict__ out) {
   const int plane = blockIdx.y;  // n*32 + c
   const int n = plane >> 5, c = plane & 31;
@@ -710,6 +716,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
   const float rstd = stats[((size_t)n * 4 + (c >> 3)) * 2 + 1];
   const float sc = rstd * gamma[c];
   const float sh = beta[c] - mean * sc;
+  float rsc = 1.0f, rsh = 0.0f;
+  if constexpr (RRAW) {
+    const float rm = r_stats[((size_t)n * 4 + (c >> 3)) * 2 + 0];
+    rsc = r_stats[((size_t)n * 4 + (c >> 3)) * 2 + 1] * r_gamma[c];
+    rsh = r_beta[c] - rm * rsc;
+  }
+  auto res = [&](float v) { return RRAW ? lrelu02(v * rsc + rsh) : v; };
   const float *xp = x + (size_t)plane * spatial;
   const float *rp = residual ? residual + (size_t)plane * spatial : nullptr;
   float *op = out + (size_t)plane * spatial;
@@ -729,7 +742,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int k = 0; k < 4; ++k) o[u][k] = lrelu02(v[u][k] * sc + sh) + rv[u][k];
+          for (int k = 0; k < 4; ++k) o[u][k] = lrelu02(v[u][k] * sc + sh) + res(rv[u][k]);
       } else {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -747,14 +760,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
       if (rp) {
         floatx4 rv = *reinterpret_cast<const floatx4 *>(rp + i);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] += rv[k];
+        for (int k = 0; k < 4; ++k) o[k] += res(rv[k]);
       }
       *reinterpret_cast<floatx4 *>(op + i) = o;
     }
   } else {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < spatial; i += (long)gridDim.x * blockDim.x) {
       float o = lrelu02(xp[i] * sc + sh);
-      if (rp) o += rp[i];
+      if (rp) o += res(rp[i]);
       op[i] = o;
     }
   }
@@ -959,9 +972,23 @@ extern "C" int mvsn_groupnorm_lrelu_apply(const float *x, const float *stats, co
   MVSN_REQUIRE((long)n * 32 <= 65535, MVSN_E_TOOLARGE, "mvsn_groupnorm_lrelu_apply: batch too large for one launch");
   long per = (spatial + 4095) / 4096;   // 4 float4 per thread per pass
   int gx = (int)(per < 1 ? 1 : (per > 32 ? 32 : per));
-  hipLaunchKernelGGL(mvsn::gn_apply_kernel, dim3(gx, n * 32), dim3(256), 0, (hipStream_t)stream, x, stats, gamma,
-                     beta, residual, spatial, out);
+  hipLaunchKernelGGL(mvsn::gn_apply_kernel<false>, dim3(gx, n * 32), dim3(256), 0, (hipStream_t)stream, x, stats, gamma,
+                     beta, residual, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, spatial,
+                     out);
   return mvsn::check_launch("mvsn_groupnorm_lrelu_apply");
+}
+
+extern "C" int mvsn_groupnorm_lrelu_add2(const float *x, const float *stats, const float *gamma, const float *beta,
+                                         const float *r, const float *r_stats, const float *r_gamma,
+                                         const float *r_beta, int n, long spatial, float *out, mvsn_stream_t stream) {
+  MVSN_REQUIRE(x && stats && gamma && beta && r && r_stats && r_gamma && r_beta && out && n > 0 && spatial > 0,
+               MVSN_E_BADARG, "mvsn_groupnorm_lrelu_add2: bad argument");
+  MVSN_REQUIRE((long)n * 32 <= 65535, MVSN_E_TOOLARGE, "mvsn_groupnorm_lrelu_add2: batch too large for one launch");
+  long per = (spatial + 4095) / 4096;
+  int gx = (int)(per < 1 ? 1 : (per > 32 ? 32 : per));
+  hipLaunchKernelGGL(mvsn::gn_apply_kernel<true>, dim3(gx, n * 32), dim3(256), 0, (hipStream_t)stream, x, stats, gamma,
+                     beta, r, r_stats, r_gamma, r_beta, spatial, out);
+  return mvsn::check_launch("mvsn_groupnorm_lrelu_add2");
 }
 
 extern "C" int mvsn_selftest_mfma(mvsn_stream_t stream) {

@@ -287,85 +287,6 @@ extern "C" int mvsn_fuse_sources(const float *raw, const float *refined, const f
 // (multi_view_stereonet.py:482 with the gain trick of :607-611).
 namespace mvsn {
 
-// Load one input row segment (4 columns of this thread + the two halo columns).
-template <int GW = 16>
-__device__ __forceinline__ void load_row6(const float *__restrict__ row, bool ok, int x4, int W, int lane16,
-                                          float (&r)[6]) {
-  floatx4 v = {0.f, 0.f, 0.f, 0.f};
-  if (ok) v = *reinterpret_cast<const floatx4 *>(row + x4);
-  float left = __shfl_up(v[3], 1, GW);
-  float right = __shfl_down(v[0], 1, GW);
-  if (lane16 == 0) left = (ok && x4 > 0) ? row[x4 - 1] : 0.0f;
-  if (lane16 == GW - 1) right = (ok && x4 + 4 < W) ? row[x4 + 4] : 0.0f;
-  if (x4 + 4 >= W) right = 0.0f;  // last column group of a narrow image
-  r[0] = left, r[1] = v[0], r[2] = v[1], r[3] = v[2], r[4] = v[3], r[5] = right;
-}
-
-// 2-D: each thread owns 4 columns x RY rows and walks the input rows once per channel with a rolling
-// window, so a row is loaded once per RY outputs instead of three times.
-constexpr int TO1_RY = 4;   // 2-D: output rows per thread
-
-__global__ __launch_bounds__(256) void conv_to1_2d_kernel(const float *__restrict__ in, const float *__restrict__ w,
-                                                          const float *__restrict__ bias,
-                                                          const float *__restrict__ prior, const float *__restrict__ fx,
-                                                          int H, int W, float *__restrict__ out) {
-  const int lane16 = threadIdx.x & 15;
-  const int x4 = (blockIdx.x * 16 + lane16) * 4;
-  const int y0 = (blockIdx.y * 16 + (threadIdx.x >> 4)) * TO1_RY;
-  const int n = blockIdx.z;
-  const size_t plane = (size_t)H * W;
-  const float *inn = in + (size_t)n * 32 * plane;
-  float acc[TO1_RY][4];
-#pragma unroll
-  for (int r = 0; r < TO1_RY; ++r)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) acc[r][k] = 0.f;
-  for (int c = 0; c < 32; ++c) {
-    const float *ic = inn + (size_t)c * plane;
-    float wt[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) wt[i] = w[c * 9 + i];
-#pragma unroll
-    for (int ry = 0; ry < TO1_RY + 2; ++ry) {   // input row y0 - 1 + ry feeds output rows ry-2 .. ry
-      const int yy = y0 - 1 + ry;
-      const bool ok = yy >= 0 && yy < H && x4 < W;
-      float r6[6];
-      load_row6(ic + (size_t)(ok ? yy : 0) * W, ok, x4, W, lane16, r6);
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const int orow = ry - dy;  // output row (relative) that sees this input row through tap dy
-        if (orow >= 0 && orow < TO1_RY) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            acc[orow][k] += wt[dy * 3 + 0] * r6[k] + wt[dy * 3 + 1] * r6[k + 1] + wt[dy * 3 + 2] * r6[k + 2];
-        }
-      }
-    }
-  }
-  if (x4 >= W) return;
-  const float b = bias ? bias[0] : 0.0f;
-  const float g = prior ? fx[n] : 1.0f;
-#pragma unroll
-  for (int r = 0; r < TO1_RY; ++r) {
-    const int y = y0 + r;
-    if (y >= H) break;
-    const size_t o = (size_t)n * plane + (size_t)y * W + x4;
-    floatx4 res;
-    if (prior) {
-      const floatx4 p = *reinterpret_cast<const floatx4 *>(prior + o);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float sv = p[k] * g + (acc[r][k] + b);
-        res[k] = (sv > 0.0f ? sv : 0.0f) / g;
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; ++k) res[k] = acc[r][k] + b;
-    }
-    *reinterpret_cast<floatx4 *>(out + o) = res;
-  }
-}
-
 // ---- 32 -> 1 channel 3x3x3 as a tap GEMM ------------------------------------------------------------------
 // out[z][y][x] = sum_tap P[tap][z + dz - 1][y + dy - 1][x + dx - 1],  P[tap][v] = sum_c w[c][tap] in[c][v].
 // P is a (27 x 32) by (32 x voxels) product: it runs on the fp32 matrix cores, every input element is read
@@ -490,6 +411,109 @@ __global__ __launch_bounds__(256, 2) void conv_to1_3d_mfma_kernel(const float *_
   }
 }
 
+// ---- 32 -> 1 channel 3x3 (2-D) the same way: 9 taps = one MFMA row tile ------------------------------------
+// One workgroup per 16 x 32 tile.  XFORM: the input is not materialised -- the kernel reads the raw
+// output r of the tower's last conv and the block input x and forms x + LeakyReLU(GN(r)) on the B
+// fragments in registers (zero outside the image, as the padding of the materialised tensor would be),
+// i.e. the last residual block's normalise/activate/add pass is folded into this layer's load.
+// Epilogue (optional): the refiner's relu(prior * fx + conv + bias) / fx.
+constexpr int T2_LDS_FLOATS = 9 * T3_SLOTS;   // 25,920 bytes
+
+template <bool XFORM>
+__global__ __launch_bounds__(256) void conv_to1_2d_mfma_kernel(const float *__restrict__ in, const float *__restrict__ w,
+                                                               const float *__restrict__ bias,
+                                                               const float *__restrict__ in_stats,
+                                                               const float *__restrict__ in_gamma,
+                                                               const float *__restrict__ in_beta,
+                                                               const float *__restrict__ in_residual,
+                                                               const float *__restrict__ prior, const float *__restrict__ fx,
+                                                               int H, int W, int ntx, float *__restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float P[T2_LDS_FLOATS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = blockIdx.y;
+  const int tyi = blockIdx.x / ntx, txi = blockIdx.x - tyi * ntx;
+  const int y0 = tyi * T3_TY, x0 = txi * T3_TX;
+  const size_t plane = (size_t)H * W;
+  const int kc = lane >> 4;   // this lane's cin within a k-step
+  const float *inn = in + ((size_t)n * 32 + kc) * plane;
+  const float *resn = (XFORM && in_residual) ? in_residual + ((size_t)n * 32 + kc) * plane : nullptr;
+
+  float a[8];   // A fragments: w[cin = 4 ks + kc][tap = lane & 15]
+  float sc[8], sh[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const int tap = lane & 15, c = ks * 4 + kc;
+    a[ks] = tap < 9 ? w[c * 9 + tap] : 0.0f;
+    if constexpr (XFORM) {
+      const float mean = in_stats[((size_t)n * 4 + (c >> 3)) * 2 + 0];
+      const float rstd = in_stats[((size_t)n * 4 + (c >> 3)) * 2 + 1];
+      sc[ks] = rstd * in_gamma[c];
+      sh[ks] = in_beta[c] - mean * sc[ks];
+    }
+  }
+
+  constexpr int GPW = T3_GROUPS / 4;   // 3 groups of 64 slots per wave
+#pragma unroll
+  for (int u = 0; u < GPW; ++u) {
+    const int s0 = (wave + 4 * u) * 64 + 4 * (lane & 15);
+    const int row = s0 / T3_XS, col = s0 - row * T3_XS;
+    const int gy = y0 - 1 + row, gx = x0 - 4 + col;
+    const bool ok = s0 < T3_SLOTS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const size_t off = ok ? (size_t)gy * W + gx : 0;
+    floatx4 bfr[8], rfr[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      bfr[ks] = ok ? *reinterpret_cast<const floatx4 *>(inn + (size_t)ks * 4 * plane + off) : floatx4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (XFORM)
+        rfr[ks] = (ok && resn) ? *reinterpret_cast<const floatx4 *>(resn + (size_t)ks * 4 * plane + off)
+                               : floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    floatx4 d[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) d[p] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if constexpr (XFORM) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) bfr[ks][p] = ok ? rfr[ks][p] + lrelu02(bfr[ks][p] * sc[ks] + sh[ks]) : 0.0f;
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p) d[p] = mfma16x16x4(a[ks], bfr[ks][p], d[p]);
+    }
+    if (s0 < T3_SLOTS) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tap = kc * 4 + r;
+        if (tap < 9) *reinterpret_cast<floatx4 *>(P + tap * T3_SLOTS + s0) = floatx4{d[0][r], d[1][r], d[2][r], d[3][r]};
+      }
+    }
+  }
+  __syncthreads();
+  const int oy = tid >> 4, ox = (tid & 15) * 2;
+  if (y0 + oy >= H || x0 + ox >= W) return;
+  const float *pg = P + oy * T3_XS + ox + 3;
+  float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const float *q = pg + (dy * 3 + dx) * T3_SLOTS + dy * T3_XS + dx;
+      acc0 += q[0];
+      acc1 += q[1];
+    }
+  const float b = bias ? bias[0] : 0.0f;
+  const size_t o = (size_t)n * plane + (size_t)(y0 + oy) * W + x0 + ox;
+  float2 res = make_float2(acc0 + b, acc1 + b);
+  if (prior) {
+    const float g = fx[n];
+    const float2 pv = *reinterpret_cast<const float2 *>(prior + o);
+    const float s0v = pv.x * g + res.x, s1v = pv.y * g + res.y;
+    res = make_float2((s0v > 0.0f ? s0v : 0.0f) / g, (s1v > 0.0f ? s1v : 0.0f) / g);
+  }
+  *reinterpret_cast<float2 *>(out + o) = res;
+}
+
 }  // namespace mvsn
 
 extern "C" int mvsn_conv_to1_supported(int rows, int cols) { return (cols % 4 == 0 && rows > 0) ? 1 : 0; }
@@ -526,11 +550,27 @@ extern "C" int mvsn_conv_to1(const float *in, const float *weight, const float *
                        bias, depth, rows, cols, ntx, zslab, out);
   } else {
     MVSN_REQUIRE(depth == 1, MVSN_E_BADARG, "mvsn_conv_to1: kd = 1 needs depth = 1");
-    const int ry = 16 * mvsn::TO1_RY;
-    MVSN_REQUIRE(n <= 65535 && (rows + ry - 1) / ry <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_to1: grid");
-    dim3 grid((cols + 63) / 64, (rows + ry - 1) / ry, n);
-    hipLaunchKernelGGL(mvsn::conv_to1_2d_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, weight, bias, prior, fx,
-                       rows, cols, out);
+    const int nty = (rows + mvsn::T3_TY - 1) / mvsn::T3_TY, ntx = (cols + mvsn::T3_TX - 1) / mvsn::T3_TX;
+    MVSN_REQUIRE(n <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_to1: grid");
+    hipLaunchKernelGGL(mvsn::conv_to1_2d_mfma_kernel<false>, dim3(nty * ntx, n), dim3(256), 0, (hipStream_t)stream, in,
+                       weight, bias, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
+                       (const float *)nullptr, prior, fx, rows, cols, ntx, out);
   }
   return mvsn::check_launch("mvsn_conv_to1");
+}
+
+extern "C" int mvsn_conv_to1_block(const float *in_raw, const float *in_stats, const float *in_gamma,
+                                   const float *in_beta, const float *in_residual, const float *weight,
+                                   const float *bias, const float *prior, const float *fx, int n, int rows, int cols,
+                                   float *out, mvsn_stream_t stream) {
+  MVSN_REQUIRE(in_raw && in_stats && in_gamma && in_beta && weight && out, MVSN_E_BADARG,
+               "mvsn_conv_to1_block: null pointer");
+  MVSN_REQUIRE(n > 0 && rows > 0 && cols > 0, MVSN_E_BADARG, "mvsn_conv_to1_block: bad sizes");
+  MVSN_REQUIRE(cols % 4 == 0, MVSN_E_BADARG, "mvsn_conv_to1_block: cols must be a multiple of 4");
+  MVSN_REQUIRE(!prior || fx, MVSN_E_BADARG, "mvsn_conv_to1_block: refiner epilogue needs fx");
+  MVSN_REQUIRE(n <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_to1_block: grid");
+  const int nty = (rows + mvsn::T3_TY - 1) / mvsn::T3_TY, ntx = (cols + mvsn::T3_TX - 1) / mvsn::T3_TX;
+  hipLaunchKernelGGL(mvsn::conv_to1_2d_mfma_kernel<true>, dim3(nty * ntx, n), dim3(256), 0, (hipStream_t)stream, in_raw,
+                     weight, bias, in_stats, in_gamma, in_beta, in_residual, prior, fx, rows, cols, ntx, out);
+  return mvsn::check_launch("mvsn_conv_to1_block");
 }

@@ -89,6 +89,9 @@ class PlaneSweepEngine:
         # Arithmetic of the 32 -> 32 channel 3x3 / 3x3x3 layers: "fp32" = exact fp32 MFMA;
         # "bf16x3" = 3 x bf16 split on the bf16 matrix cores (fp32-equivalent to ~2^-16 per product).
         self.conv_precision = "fp32"
+        # Skip the stand-alone normalise/activate pass at both ends of a refiner tower (see
+        # residual_tower_unfused); False keeps one pass per block (tests compare the two).
+        self.trim_tower_ends = True
         fe = net.left_feature_extractor
         self.fe_down = [_Conv(lib, getattr(fe, f"conv{i}").weight, None, stride=2) for i in range(4)]
         self.fe_res = [(_Conv(lib, getattr(fe, f"res{i}").conv1.weight, None), _Norm(getattr(fe, f"res{i}").bn1))
@@ -196,19 +199,58 @@ class PlaneSweepEngine:
         return out
 
     def residual_tower_unfused(self, x, first, blocks, final: _Conv, prior=None, fx=None):
-        """Same tower with the normalise/activate/add as a stand-alone float4 pass per block."""
+        """first? -> [x + LReLU(GN(conv(x)))]* -> final conv, one stand-alone float4 normalise/activate/add
+        pass per block -- except at the two ends of a refiner, where that pass would only feed one consumer:
+        the head's activation is never written (block 1 reads conv0's raw output through the conv's input
+        transform and as a transformed residual), and the last block is folded into the 32 -> 1 layer's load."""
+        blocks = list(blocks)
+        pend = None                      # (raw, stats, norm): LReLU(GN(raw)) not materialised
         if first is not None:
-            r, st = self.conv(first[0], x, want_stats=True)
-            x = self.gn_lrelu(r, st, first[1], out=r)
-        for conv, norm in blocks:
-            r, st = self.conv(conv, x, want_stats=True)
-            x = self.gn_lrelu(r, st, norm, residual=x, out=r)
+            r0, st0 = self.conv(first[0], x, want_stats=True)
+            if blocks and self.trim_tower_ends:
+                pend = (r0, st0, first[1])
+            else:
+                x = self.gn_lrelu(r0, st0, first[1], out=r0)
+        to1_ok = (final.cout == 1 and final.cin == 32 and final.dilation == 1 and final.stride == 1 and
+                  final.dims == 2 and self.lib.mvsn_conv_to1_supported(x.shape[-2], x.shape[-1]))
+        for i, (conv, norm) in enumerate(blocks):
+            if pend is not None:
+                r0, st0, n0 = pend
+                r, st = self.conv(conv, r0, in_stats=st0, in_norm=n0, want_stats=True)
+            else:
+                r, st = self.conv(conv, x, want_stats=True)
+            if i == len(blocks) - 1 and to1_ok and self.trim_tower_ends and pend is None:
+                return self.conv_to1_block(final, r, st, norm, x, prior, fx), prior is not None
+            if pend is not None:
+                x = self.gn_lrelu_add2(r, st, norm, *pend, out=r)
+                pend = None
+            else:
+                x = self.gn_lrelu(r, st, norm, residual=x, out=r)
         if final.cout == 1:
             out = self.conv_to1(final, x, prior, fx)
             if out is not None:
                 return out, prior is not None
         out, _ = self.conv(final, x)
         return out, False
+
+    def gn_lrelu_add2(self, r, st, norm: _Norm, r0, st0, norm0: _Norm, out=None):
+        n, spatial = r.shape[0], r[0, 0].numel()
+        out = torch.empty_like(r) if out is None else out
+        self._call("mvsn_groupnorm_lrelu_add2", self.lib.mvsn_groupnorm_lrelu_add2, _native.ptr(r), _native.ptr(st),
+                   _native.ptr(norm.gamma), _native.ptr(norm.beta), _native.ptr(r0), _native.ptr(st0),
+                   _native.ptr(norm0.gamma), _native.ptr(norm0.beta), n, spatial, _native.ptr(out), _native.stream(),
+                   nbytes=4.0 * r.numel() * 3)
+        return out
+
+    def conv_to1_block(self, c: _Conv, r, st, norm: _Norm, x, prior=None, fx=None):
+        """conv_to1 on x + LReLU(GN(r)) without materialising it."""
+        n, rows, cols = r.shape[0], r.shape[-2], r.shape[-1]
+        out = torch.empty((n, 1, rows, cols), dtype=torch.float32, device=r.device)
+        self._call("mvsn_conv_to1_block", self.lib.mvsn_conv_to1_block, _native.ptr(r), _native.ptr(st),
+                   _native.ptr(norm.gamma), _native.ptr(norm.beta), _native.ptr(x), _native.ptr(c.weight),
+                   _native.ptr(c.bias), _native.ptr(prior), _native.ptr(fx), n, rows, cols, _native.ptr(out),
+                   _native.stream(), flops=2.0 * 32 * 9 * out.numel(), nbytes=4.0 * (2 * r.numel() + out.numel()))
+        return out
 
     def residual_tower(self, x, first, blocks, final: _Conv):
         """first? -> [x + LReLU(GN(conv(x)))]* -> final conv, with every normalise/activate/add folded
@@ -271,11 +313,13 @@ class PlaneSweepEngine:
         out, _ = self.conv(last, x, in_stats=st, in_norm=self.vf_norms[3])
         return out[:, 0]
 
-    def idepth_refiner(self, level: int, guide: torch.Tensor, prior: torch.Tensor, fx: torch.Tensor) -> torch.Tensor:
+    def idepth_refiner(self, level: int, guide, prior: torch.Tensor, fx: torch.Tensor) -> torch.Tensor:
+        """`guide` is a tensor or a list of channel blocks (image, features): the refiner input
+        [guide..., prior * fx] is assembled with ONE concatenation."""
         p = self.refiners[level]
         scale = fx.view(-1, 1, 1, 1)
         scaled = prior * scale
-        x_in = torch.cat([guide, scaled], 1)
+        x_in = torch.cat((list(guide) if isinstance(guide, (list, tuple)) else [guide]) + [scaled], 1)
         if self.fold_residual_blocks:
             delta, done = self.residual_tower(x_in, (p["conv0"], p["bn0"]), p["res"], p["final"]), False
         else:
@@ -417,8 +461,8 @@ class PlaneSweepEngine:
             masks[lvl] = self.upsample_mask(masks[lvl + 1], size)
             if do_refiners[lvl]:
                 img = left_image_pyr[lvl].float()
-                guide = img if lvl == 0 else torch.cat([img, left_feats[lvl]], 1)
-                idepth[lvl] = self.idepth_refiner(lvl, guide.contiguous(), prior[lvl], K_pyr[lvl][:, 0, 0].float())
+                guide = [img] if lvl == 0 else [img, left_feats[lvl]]
+                idepth[lvl] = self.idepth_refiner(lvl, guide, prior[lvl], K_pyr[lvl][:, 0, 0].float())
             else:
                 idepth[lvl] = prior[lvl]
         return {"left_idepthmap_pyr": idepth, "left_idepthmap_raw_pyr": prior, "left_idepthmap_mask_pyr": masks}

@@ -202,7 +202,7 @@ def test_conv_with_folded_residual_block(rows, cols, dil, cout):
                                                     (3, 8, 4, 8, 2), (3, 12, 16, 32, 1), (3, 5, 30, 40, 1),
                                                     (3, 64, 16, 32, 2), (3, 96, 30, 40, 1), (3, 7, 32, 64, 1), (3, 1, 16, 32, 1),
                                                     (3, 33, 17, 36, 1)])
-def test_conv_to1_vector_path(dims, depth, rows, cols, n):
+def test_conv_to1_tap_gemm(dims, depth, rows, cols, n):
     from multi_view_stereonet_amd.multi_view_stereonet import _Conv
     eng = net_for("gta_sfm_150epochs").engine()
     g = torch.Generator().manual_seed(rows * 7 + depth)
@@ -222,6 +222,58 @@ def test_conv_to1_vector_path(dims, depth, rows, cols, n):
         s = fx.view(-1, 1, 1, 1)
         close(got, torch.relu(prior * s + ref) / s, rtol=1e-4, atol=1e-5)
     assert eng.conv_to1(c, torch.zeros(1, 32, 6, 45, device=DEV)) is None if dims == 2 else True   # ragged width -> MFMA kernel
+
+
+@pytest.mark.parametrize("rows,cols,n,with_res,with_prior", [(16, 32, 2, True, True), (37, 68, 1, True, False),
+                                                             (256, 512, 1, True, True), (5, 4, 3, False, True),
+                                                             (30, 40, 2, True, True)])
+def test_conv_to1_block_folds_last_residual_block(rows, cols, n, with_res, with_prior):
+    """32 -> 1 layer reading x + LReLU(GN(r)) formed in registers (mvsn_conv_to1_block) against ATen."""
+    from multi_view_stereonet_amd.multi_view_stereonet import _Conv, _Norm
+    eng = net_for("gta_sfm_150epochs").engine()
+    g = torch.Generator().manual_seed(rows * 3 + cols)
+    r = torch.randn(n, 32, rows, cols, generator=g) * 1.5 + 0.3
+    x = torch.randn(n, 32, rows, cols, generator=g) if with_res else None
+    gamma, beta = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.1
+    w = torch.randn(1, 32, 3, 3, generator=g) * 0.05
+    b = torch.randn(1, generator=g) * 0.1
+
+    class P:
+        weight, bias = gamma.to(DEV), beta.to(DEV)
+    rg = r.reshape(n, 4, -1).double()
+    stats = torch.stack([rg.mean(2), 1.0 / (rg.var(2, unbiased=False) + 1e-5).sqrt()], 2).float().contiguous()
+    y = F.leaky_relu(F.group_norm(r, 4, gamma, beta, 1e-5), 0.2)
+    if with_res:
+        y = y + x
+    ref = F.conv2d(y, w, b, padding=1)
+    prior = fx = None
+    if with_prior:
+        prior = torch.rand(n, 1, rows, cols, generator=g) * 3.0
+        fx = torch.rand(n, generator=g) * 50 + 10
+        sc = fx.view(-1, 1, 1, 1)
+        ref = torch.relu(prior * sc + ref) / sc
+    c = _Conv(eng.lib, w.to(DEV), b.to(DEV))
+    got = eng.conv_to1_block(c, r.to(DEV), stats.to(DEV), _Norm(P), x.to(DEV) if with_res else None,
+                             prior.to(DEV) if with_prior else None, fx.to(DEV) if with_prior else None)
+    close(got, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_refiner_tower_end_trimming_is_equivalent():
+    """The tower with the head activation and the last block never materialised (gn_lrelu_add2 +
+    conv_to1_block) against the one-pass-per-block form, on every refiner of the pretrained weights."""
+    eng = net_for("gta_sfm_150epochs").engine()
+    g = torch.Generator().manual_seed(11)
+    for lvl, (rows, cols) in zip((4, 2, 0), ((16, 32), (64, 128), (256, 512))):
+        cin = eng.refiners[lvl]["conv0"].cin
+        guide = torch.rand(2, cin - 1, rows, cols, generator=g).to(DEV)
+        prior = (torch.rand(2, 1, rows, cols, generator=g) * 0.5).to(DEV)
+        fx = torch.tensor([300.0 / 2 ** lvl, 260.0 / 2 ** lvl], device=DEV)
+        eng.trim_tower_ends = True
+        a = eng.idepth_refiner(lvl, guide, prior, fx)
+        eng.trim_tower_ends = False
+        b = eng.idepth_refiner(lvl, guide, prior, fx)
+        eng.trim_tower_ends = True
+        close(a, b.cpu(), rtol=2e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize("dims,depth,rows,cols,dil,n", [(2, 1, 16, 32, 1, 2), (2, 1, 37, 70, 1, 1), (2, 1, 24, 40, 2, 1),
