@@ -61,6 +61,15 @@ __device__ __forceinline__ floatx4 quad_transpose(floatx4 v, int lane) {
   return v;
 }
 
+// Workgroup b is observed to run on XCD b % 8, each XCD with its own L2.  Neighbouring tiles share halo
+// rows, so hand each XCD a contiguous range of tiles instead of every 8th one (bijective for any tile
+// count; placement only affects speed, never results).
+__device__ __forceinline__ int xcd_tile_index(int bid, int tiles) {
+  const int q = tiles >> 3, r = tiles & 7;
+  const int xcd = bid & 7, k = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 // Source-pixel coordinate of a homography warp, evaluated with the same fp32 expression order
 // as the reference (stereo/image_predictor.py:493-516) followed by grid_sample's
 // un-normalisation, so that the |n|>1 predicate flips on the same pixels.

@@ -146,15 +146,6 @@ __global__ void conv_pack_kernel(const float *__restrict__ w, int cin, int cout,
   out[i] = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * ntaps + tap] : 0.0f;
 }
 
-// Workgroup b is observed to run on XCD b % 8, each XCD with its own L2.  Neighbouring tiles share halo
-// rows, so hand each XCD a contiguous range of tiles instead of every 8th one (bijective for any tile
-// count; placement only affects speed, never results).
-__device__ __forceinline__ int xcd_tile_index(int bid, int tiles) {
-  const int q = tiles >> 3, r = tiles & 7;
-  const int xcd = bid & 7, k = bid >> 3;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-}
-
 // Shared epilogue of the fp32 kernels.  The MFMAs run with A = activations (16 pixels x 4 cins) and
 // B = weights (4 cins x 16 couts), so D = pixels x couts: lane l holds, for cout t*16 + (l & 15), the four
 // CONSECUTIVE pixels 4*(l>>4) + r of each of its NPT pixel tiles -- one 16-byte store per accumulator, no

@@ -312,7 +312,8 @@ __global__ __launch_bounds__(256, 2) void conv_to1_3d_mfma_kernel(const float *_
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = blockIdx.z;
-  const int tyi = blockIdx.x / ntx, txi = blockIdx.x - tyi * ntx;
+  const int tile = xcd_tile_index(blockIdx.x, gridDim.x);
+  const int tyi = tile / ntx, txi = tile - tyi * ntx;
   const int y0 = tyi * T3_TY, x0 = txi * T3_TX;
   const int zb = blockIdx.y * zslab, ze = min(D, zb + zslab);   // output planes [zb, ze)
   const size_t plane = (size_t)H * W, chan = (size_t)D * plane;
@@ -432,7 +433,8 @@ __global__ __launch_bounds__(256) void conv_to1_2d_mfma_kernel(const float *__re
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = blockIdx.y;
-  const int tyi = blockIdx.x / ntx, txi = blockIdx.x - tyi * ntx;
+  const int tile = xcd_tile_index(blockIdx.x, gridDim.x);   // neighbouring tiles (shared halo lines) on one XCD's L2
+  const int tyi = tile / ntx, txi = tile - tyi * ntx;
   const int y0 = tyi * T3_TY, x0 = txi * T3_TX;
   const size_t plane = (size_t)H * W;
   const int kc = lane >> 4;   // this lane's cin within a k-step
