@@ -124,7 +124,7 @@ typedef struct {
   int kd, kh, kw;/* kernel extent; kd = 1 for 2-D */
   int stride;    /* 1 or 2 (rows/cols only) */
   int dilation;  /* rows/cols only */
-  int precision; /* MVSN_CONV_FP32 (exact fp32 MFMA) or MVSN_CONV_BF16X3 (3 x bf16 split, see below) */
+  int precision; /* MVSN_CONV_FP32, MVSN_CONV_FP32_WINO or MVSN_CONV_BF16X3: arithmetic / algorithm, see below */
 } mvsn_conv_desc;
 
 /* Arithmetic of mvsn_conv_forward.
@@ -133,10 +133,17 @@ typedef struct {
  *                     v_mfma_f32_16x16x32_bf16 with fp32 accumulation (~2^-16 relative per product;
  *                     "3 x bf16 split", the fp32-equivalent tier BASELINE.md section 2 allows).  Only the
  *                     32 -> 32 channel 3x3 / 3x3x3 stride-1 layers (mvsn_conv_bf16x3_supported); weights are
- *                     packed per precision, in_residual / out_staged are not available. */
+ *                     packed per precision, in_residual / out_staged are not available.
+ *   MVSN_CONV_FP32_WINO  the same fp32 MFMA arithmetic on the Winograd F(2x2,3x3) form of the layer: 16
+ *                     products per 2x2 outputs and (cin, cout) pair instead of 36; every operand and
+ *                     accumulation is fp32, the result differs from MVSN_CONV_FP32 by rounding only (~1e-6
+ *                     relative).  Only 2-D 3x3 stride-1 dilation-1 layers with 32 output channels and
+ *                     cols % 4 == 0 (mvsn_conv_winograd_supported); weights are packed per form. */
 #define MVSN_CONV_FP32 0
 #define MVSN_CONV_BF16X3 1
+#define MVSN_CONV_FP32_WINO 2
 int mvsn_conv_bf16x3_supported(const mvsn_conv_desc *desc);
+int mvsn_conv_winograd_supported(const mvsn_conv_desc *desc);
 
 size_t mvsn_conv_packed_floats(const mvsn_conv_desc *desc);
 int mvsn_conv_pack_weights(const mvsn_conv_desc *desc, const float *weight, float *packed,

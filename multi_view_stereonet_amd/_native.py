@@ -21,7 +21,7 @@ class ConvDesc(Structure):
                 ("dilation", c_int), ("precision", c_int)]
 
 
-CONV_FP32, CONV_BF16X3 = 0, 1
+CONV_FP32, CONV_BF16X3, CONV_FP32_WINO = 0, 1, 2
 
 
 # name -> (restype, argtypes); mirrors include/mvsn_hip.h one to one
@@ -35,6 +35,7 @@ SIGNATURES = {
     "mvsn_incremental_cost_volume_workspace_bytes": (c_size_t, [c_int] * 3),
     "mvsn_incremental_cost_volume": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 4 + [c_size_t, c_void_p]),
     "mvsn_conv_bf16x3_supported": (c_int, [POINTER(ConvDesc)]),
+    "mvsn_conv_winograd_supported": (c_int, [POINTER(ConvDesc)]),
     "mvsn_conv_packed_floats": (c_size_t, [POINTER(ConvDesc)]),
     "mvsn_conv_pack_weights": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p]),
     "mvsn_conv_num_tiles": (c_int, [POINTER(ConvDesc)]),

@@ -13,6 +13,7 @@
 // fragment read is bank-conflict-free at stride 1.
 #include "mvsn_common.h"
 #include "mvsn_conv_bf16x3.h"
+#include "mvsn_conv_wino.h"
 
 namespace mvsn {
 
@@ -789,7 +790,16 @@ extern "C" int mvsn_conv_bf16x3_supported(const mvsn_conv_desc *desc) {
   return mvsn::bf16x3_geom(desc, &g) ? 1 : 0;
 }
 
+extern "C" int mvsn_conv_winograd_supported(const mvsn_conv_desc *desc) {
+  mvsn::WinoGeom g;
+  return mvsn::wino_geom(desc, &g) ? 1 : 0;
+}
+
 extern "C" size_t mvsn_conv_packed_floats(const mvsn_conv_desc *desc) {
+  if (desc && desc->precision == MVSN_CONV_FP32_WINO) {
+    mvsn::WinoGeom wg;
+    return mvsn::wino_geom(desc, &wg) ? wg.packed_floats : 0;
+  }
   if (desc && desc->precision == MVSN_CONV_BF16X3) {
     mvsn::Bf16x3Geom bg;
     return mvsn::bf16x3_geom(desc, &bg) ? (size_t)desc->kd * 9 * 1024 : 0;   // [tap][2][2][64][8] bf16
@@ -801,6 +811,10 @@ extern "C" size_t mvsn_conv_packed_floats(const mvsn_conv_desc *desc) {
 
 extern "C" int mvsn_conv_num_tiles(const mvsn_conv_desc *desc) {
   // number of GroupNorm partial records per sample: one per (tile, wave), 4 waves per workgroup tile
+  if (desc && desc->precision == MVSN_CONV_FP32_WINO) {
+    mvsn::WinoGeom wg;
+    return mvsn::wino_geom(desc, &wg) ? wg.tiles * 8 : 0;   // 8 waves per workgroup tile
+  }
   if (desc && desc->precision == MVSN_CONV_BF16X3) {
     mvsn::Bf16x3Geom bg;
     return mvsn::bf16x3_geom(desc, &bg) ? bg.tiles * 4 : 0;
@@ -813,6 +827,11 @@ extern "C" int mvsn_conv_num_tiles(const mvsn_conv_desc *desc) {
 extern "C" int mvsn_conv_pack_weights(const mvsn_conv_desc *desc, const float *weight, float *packed,
                                       mvsn_stream_t stream) {
   MVSN_REQUIRE(weight && packed, MVSN_E_BADARG, "mvsn_conv_pack_weights: null pointer");
+  if (desc && desc->precision == MVSN_CONV_FP32_WINO) {
+    mvsn::WinoGeom wg;
+    MVSN_REQUIRE(mvsn::wino_geom(desc, &wg), MVSN_E_BADARG, "mvsn_conv_pack_weights: layer has no Winograd form");
+    return mvsn::wino_pack(desc, weight, packed, (hipStream_t)stream);
+  }
   if (desc && desc->precision == MVSN_CONV_BF16X3) {
     mvsn::Bf16x3Geom bg;
     MVSN_REQUIRE(mvsn::bf16x3_geom(desc, &bg), MVSN_E_BADARG, "mvsn_conv_pack_weights: layer has no bf16x3 form");
@@ -832,6 +851,16 @@ extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, co
                                  float *out_partials, mvsn_stream_t stream) {
   using namespace mvsn;
   MVSN_REQUIRE(in && weight_packed && out, MVSN_E_BADARG, "mvsn_conv_forward: null pointer");
+  if (desc && desc->precision == MVSN_CONV_FP32_WINO) {
+    WinoGeom wg;
+    MVSN_REQUIRE(wino_geom(desc, &wg), MVSN_E_BADARG, "mvsn_conv_forward: layer has no Winograd form");
+    MVSN_REQUIRE(!in_residual && !out_staged, MVSN_E_BADARG, "mvsn_conv_forward: Winograd form has no residual folding");
+    MVSN_REQUIRE(!in_stats || (in_gamma && in_beta && wg.cin == 32), MVSN_E_BADARG,
+                 "mvsn_conv_forward: input transform needs gamma/beta and 32 channels");
+    MVSN_REQUIRE(wg.n <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_forward: batch too large for one launch");
+    return wino_launch(wg, in, weight_packed, bias, in_stats, in_gamma, in_beta, out, out_partials,
+                       (hipStream_t)stream);
+  }
   if (desc && desc->precision == MVSN_CONV_BF16X3) {
     Bf16x3Geom bg;
     MVSN_REQUIRE(bf16x3_geom(desc, &bg), MVSN_E_BADARG, "mvsn_conv_forward: layer has no bf16x3 form");

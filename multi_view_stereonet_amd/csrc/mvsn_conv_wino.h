@@ -1,0 +1,21 @@
+// Internal interface between mvsn_conv.hip (C-ABI entry points) and the Winograd F(2x2,3x3) kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+#include "../../include/mvsn_hip.h"
+
+namespace mvsn {
+
+struct WinoGeom {
+  int n, cin, H, W;
+  int nty, ntx, tiles, nchunks;
+  size_t packed_floats;
+};
+
+bool wino_geom(const mvsn_conv_desc *d, WinoGeom *g);
+int wino_pack(const mvsn_conv_desc *d, const float *weight, float *packed, hipStream_t stream);
+int wino_launch(const WinoGeom &g, const float *in, const float *upk, const float *bias, const float *in_stats,
+                const float *in_gamma, const float *in_beta, float *out, float *out_partials, hipStream_t stream);
+
+}  // namespace mvsn

@@ -1,0 +1,507 @@
+// Winograd F(2x2, 3x3) form of the 2-D 3x3 stride-1 convolutions with 32 output channels
+// (mvsn_conv_forward with desc.precision = MVSN_CONV_FP32_WINO).
+//
+// The fp32 matrix pipe is the ceiling of the refiner layers (v_mfma_f32_16x16x4_f32 at 1/16 of the bf16 rate,
+// and the direct kernels already keep it ~85 % busy at the sustained clock), so the remaining lever is fewer
+// multiplies: Y = A^T [ (G g G^T) . (B^T d B) ] A turns every 2x2 output patch into 16 products per
+// (cin, cout) pair instead of 36.  The sum over input channels is taken in the transformed domain, i.e. one
+// small GEMM per Winograd coefficient xi:  M_xi[patch][cout] = sum_cin V_xi[patch][cin] * U_xi[cin][cout].
+// All arithmetic is fp32; the result differs from the direct form by rounding only (~1e-6 relative).
+//
+// Persistent workgroups, one per CU: 512 threads (8 waves), a 16 x 32 output tile (8 x 16 patches) at a time:
+//   * the layer's transformed weights U (16 coefficients x cin x 32 couts, 64 KB at 32 input channels) are
+//     loaded into LDS ONCE per workgroup and stay there while it walks its tiles -- streamed per chunk they
+//     were two thirds of the DMA instructions, and the CU's DMA issue rate (~1 piece per ~115 cycles), not the
+//     matrix pipe, set the pace;
+//   * the haloed raw tiles (18 rows x 40 columns from the aligned column x0 - 4, 4 channels per chunk = one MFMA
+//     k-step) arrive by LDS-DMA (16-byte pieces, 12 instructions per chunk per CU) in a three-stage ring that
+//     runs ahead across tile boundaries (a chunk is only 32 MFMAs per wave, shorter than a DMA round trip);
+//     one barrier per chunk;
+//   * wave w owns patch row w (16 patches) and both cout tiles.  Lane (k = lane>>4, p = lane&15) reads the 4 x 4
+//     input patch p of channel k from the raw tile and transforms it in registers (B^T d B: 32 adds): the 16
+//     coefficients it ends up with are exactly its A-fragment values (A = V_xi: 16 patches x 4 cins), so the
+//     transformed input never touches LDS;
+//   * per chunk 16 xi x 2 MFMAs with B = U_xi (4 cins x 16 couts) read from LDS; 128 accumulator registers;
+//   * output transform in registers (D = patches x couts: a lane holds 4 consecutive patches of one cout, i.e.
+//     8 consecutive output columns of 2 rows): A^T m A (24 adds per patch), bias, 16-byte stores, per-wave
+//     GroupNorm partials.
+// MODE 1: the previous layer's LeakyReLU(GroupNorm(.)) is applied to d in registers before the transform
+// (out-of-image elements stay zero, as the padding of the materialised tensor would be).
+#include "mvsn_common.h"
+#include "mvsn_conv_wino.h"
+
+namespace mvsn {
+
+constexpr int WN_THREADS = 512, WN_WAVES = 8;
+constexpr int WN_TY = 16, WN_TX = 32;                  // output tile
+constexpr int WN_HY = WN_TY + 2;                       // haloed rows
+constexpr int WN_XS = 40;                              // row stride: columns x0 - 4 .. x0 + 35
+constexpr int WN_GROUPS = WN_HY * 10;                  // 16-byte groups per channel tile (180)
+constexpr int WN_PIECES = (WN_GROUPS + 63) / 64;       // DMA instructions per channel (3; the last is lane-masked)
+constexpr int WN_RCST = WN_HY * WN_XS + 16;            // raw channel stride (floats)
+constexpr int WN_UFLOATS = 16 * 128;                   // U fragments per chunk: [xi][cout tile][lane]
+constexpr int WN_MAX_CHUNKS = 8;                       // resident U: up to 32 input channels (64 KB)
+constexpr float WN_EPS = 1e-5f;
+static_assert(WN_PIECES == 3, "DMA split below assumes three pieces per channel");
+
+__device__ floatx4 g_wn_zero16 = {0.f, 0.f, 0.f, 0.f};
+#define WN_GPTR(p) ((const __attribute__((address_space(1))) void *)(p))
+#define WN_LPTR(p) ((__attribute__((address_space(3))) void *)(p))
+
+#ifdef MVSN_WN_STAMPS   // tuning aid (tools/wino_phases.py): s_memtime stamps of one mid-launch wave
+__device__ unsigned long long *g_wn_stamps = nullptr;
+#define WN_STAMP() do { if (dbg && dbg_i < 60) dbg[dbg_i++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WN_STAMP() do { } while (0)
+#endif
+
+struct WinoDiv {
+  unsigned mul, shift;
+};
+static WinoDiv wino_div(unsigned d) {
+  unsigned s = 0;
+  while ((1u << s) < d) ++s;
+  const unsigned long long m = ((1ull << 32) * ((1ull << s) - d)) / d + 1;
+  return WinoDiv{(unsigned)m, s};
+}
+__device__ __forceinline__ int wdiv(int n, WinoDiv f) { return (int)((__umulhi((unsigned)n, f.mul) + (unsigned)n) >> f.shift); }
+
+struct WinoArgs {
+  int n, cin, H, W, ntx, tiles, nchunks;
+  WinoDiv fd_ntx;
+};
+
+// U = G g G^T per (cout, cin), packed [chunk of 4 cin][xi = 4i + j][cout tile][lane]; lane = k*16 + c holds
+// U_xi[cin = chunk*4 + k][cout = t*16 + c] (the B fragment of the MFMA), zero outside (c_in, 32).
+__global__ void wino_pack_kernel(const float *__restrict__ w, int cin, int cout, int nchunks, float *__restrict__ out) {
+  const int total = nchunks * WN_UFLOATS;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = idx & 63, t = (idx >> 6) & 1, xi = (idx >> 7) & 15, chunk = idx >> 11;
+  const int co = t * 16 + (lane & 15), ci = chunk * 4 + (lane >> 4);
+  float u = 0.0f;
+  if (co < cout && ci < cin) {
+    const float *g = w + ((size_t)co * cin + ci) * 9;
+    const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+    const int i = xi >> 2, j = xi & 3;
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) u += G[i][a] * g[a * 3 + b] * G[j][b];
+  }
+  out[idx] = u;
+}
+
+// KS      MFMA k-steps (4 input channels each) per step: 2 for the 32-channel layers (half the barriers per
+//         tile), 1 for the 4-channel head
+// NSTAGE  depth of the raw-tile ring (KS = 2: 4 x 23 KB next to the 64 KB of U; a step is ~2 us, a DMA round
+//         trip under load longer)
+template <int MODE, int KS, int NSTAGE>
+__global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, const float *__restrict__ in,
+                                                                  const float *__restrict__ upk,
+                                                                  const float *__restrict__ bias,
+                                                                  const float *__restrict__ in_stats,
+                                                                  const float *__restrict__ in_gamma,
+                                                                  const float *__restrict__ in_beta,
+                                                                  float *__restrict__ out,
+                                                                  float *__restrict__ out_partials) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int STAGE = KS * 4 * WN_RCST;            // ring stage (floats)
+  float *U = smem + NSTAGE * STAGE;                  // nchunks * WN_UFLOATS, resident
+  float *scsh = U + g.nchunks * WN_UFLOATS;          // 2 x (32 scale + 32 shift): double-buffered per tile
+  const int nsteps = (g.nchunks + KS - 1) / KS;      // steps per tile
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const size_t plane = (size_t)g.H * g.W;
+  const int total = g.n * g.tiles;                   // work items in (image, tile) order
+  const int G = gridDim.x;
+  // item of this workgroup in round r: r * G + an XCD-contiguous slot (neighbouring tiles share halo lines in one L2)
+  const int slot = xcd_tile_index(blockIdx.x, G);
+#ifdef MVSN_WN_STAMPS
+  unsigned long long *dbg = (blockIdx.x == gridDim.x / 3 && tid == 0) ? g_wn_stamps : nullptr;
+  int dbg_i = 0;
+#endif
+  WN_STAMP();   // entry
+
+  // ---- resident U: wave w fetches 1 KB runs w, w + 8, ...
+  {
+    const int runs = g.nchunks * (WN_UFLOATS / 256);
+    for (int run = wave; run < runs; run += WN_WAVES)
+      __builtin_amdgcn_global_load_lds(WN_GPTR(upk + (size_t)run * 256 + lane * 4), WN_LPTR(U + run * 256), 16, 0, 0);
+  }
+
+  // ---- prefetcher state: DMA of (item, chunk) steps runs two steps ahead of the multiplies
+  // KS = 2: wave w fetches channel w of the step (3 pieces); KS = 1: waves 0-3 fetch pieces 0, 1 of channel w,
+  // waves 4-7 piece 2 of channel w - 4
+  const int dch = KS == 2 ? wave : (wave & 3);
+  const int dp0 = (KS == 2 || wave < 4) ? 0 : 2, dpn = KS == 2 ? 3 : (wave < 4 ? 2 : 1);
+  const float *zero = reinterpret_cast<const float *>(&g_wn_zero16);
+  int pf_round = 0, pf_chunk = 0, pf_stage = 0;
+  int pf_goff[3] = {-1, -1, -1};
+  const float *pf_src = in;
+  bool pf_live = slot < total;
+  auto pf_plan = [&]() {   // DMA plan of the prefetcher's current item
+    const int flat = pf_round * G + slot;
+    const int n = flat / g.tiles, tile = flat - n * g.tiles;
+    const int tyi = wdiv(tile, g.fd_ntx), txi = tile - tyi * g.ntx;
+    const int y0 = tyi * WN_TY, x0 = txi * WN_TX;
+    pf_src = in + (size_t)n * g.cin * plane;
+#pragma unroll
+    for (int i = 0; i < (KS == 2 ? 3 : 2); ++i) {
+      const int e = (dp0 + i) * 64 + lane;
+      const int row = e / 10, q = e - row * 10;
+      const int gy = y0 - 1 + row, gx = x0 - 4 + 4 * q;
+      pf_goff[i] = (i < dpn && e < WN_GROUPS && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) ? gy * g.W + gx : -1;
+    }
+  };
+  auto pf_issue = [&]() {   // issue the DMA of the prefetcher's step and advance it
+    if (!pf_live) return;
+    const int c = pf_chunk * (KS * 4) + dch;
+    const bool cok = c < g.cin;
+    const float *src = pf_src + (size_t)(cok ? c : 0) * plane;
+    float *dst = smem + pf_stage * STAGE + dch * WN_RCST;
+#pragma unroll
+    for (int i = 0; i < (KS == 2 ? 3 : 2); ++i) {
+      if (i < dpn) {   // uniform
+        const float *p = (cok && pf_goff[i] >= 0) ? src + pf_goff[i] : zero;
+        if ((dp0 + i) * 64 + lane < WN_GROUPS)   // lanes past the tile's last 16-byte group stay out of the slot
+          __builtin_amdgcn_global_load_lds(WN_GPTR(p), WN_LPTR(dst + (dp0 + i) * 256), 16, 0, 0);
+      }
+    }
+    pf_stage = pf_stage + 1 == NSTAGE ? 0 : pf_stage + 1;
+    if (++pf_chunk == nsteps) {
+      pf_chunk = 0;
+      ++pf_round;
+      pf_live = pf_round * G + slot < total;
+      if (pf_live) pf_plan();
+    }
+  };
+  if (pf_live) pf_plan();
+#pragma unroll
+  for (int i = 0; i < NSTAGE; ++i) pf_issue();
+  WN_STAMP();   // prologue
+
+  const int pcol = lane & 15, kc = lane >> 4;   // this lane's patch column / channel within the chunk; patch row = wave
+  const int my_items = slot < total ? (total - slot + G - 1) / G : 0;
+  const int total_steps = my_items * nsteps;
+
+  // wait until this wave's DMA pieces of a step have landed, `younger` later steps having been issued since
+  // (vmcnt retires in order; waves 0-3 issue two pieces per step, waves 4-7 one)
+  auto wait_landed = [&](int younger) {
+#define WN_WAIT_CASE(K)                                                              \
+  case K:                                                                            \
+    if (KS == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (K)) : "memory");        \
+    else if (wave < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (K)) : "memory"); \
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory");                       \
+    break;
+    switch (younger) {   // uniform
+      WN_WAIT_CASE(0)
+      WN_WAIT_CASE(1)
+      WN_WAIT_CASE(2)
+      WN_WAIT_CASE(3)
+      WN_WAIT_CASE(4)
+      default:
+        WN_WAIT_CASE(5)
+    }
+#undef WN_WAIT_CASE
+  };
+  static_assert(NSTAGE - 1 <= 5, "wait_landed covers up to 5 younger steps");
+
+  // ---- transform side: runs one step ahead of the multiplies (its tile may already be the next one)
+  int tr_round = 0, tr_chunk = 0, tr_stage = 0;
+  unsigned tr_rowok = 0, tr_colok = 0;   // MODE 1: which of the 4 x 4 patch elements are inside the image
+  auto tr_setup = [&]() {   // entering tile `tr_round`: masks, and the tile's scale/shift into its half of scsh
+    if constexpr (MODE == 1) {
+      const int flat = tr_round * G + slot;
+      if (flat >= total) return;
+      const int n = flat / g.tiles, tile = flat - n * g.tiles;
+      const int tyi = wdiv(tile, g.fd_ntx), txi = tile - tyi * g.ntx;
+      const int y0 = tyi * WN_TY, x0 = txi * WN_TX;
+      tr_rowok = 0, tr_colok = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int gy = y0 - 1 + 2 * wave + i, gx = x0 - 1 + 2 * pcol + i;
+        if (gy >= 0 && gy < g.H) tr_rowok |= 1u << i;
+        if (gx >= 0 && gx < g.W) tr_colok |= 1u << i;
+      }
+      if (tid < 32) {   // read after the next barrier; the tile two back used this half
+        float *sc_t = scsh + (tr_round & 1) * 64;
+        const int grp = tid >> 3;
+        const float mean = in_stats[((size_t)n * 4 + grp) * 2 + 0];
+        const float rstd = in_stats[((size_t)n * 4 + grp) * 2 + 1];
+        const float sc = rstd * in_gamma[tid];
+        sc_t[tid] = sc;
+        sc_t[32 + tid] = in_beta[tid] - mean * sc;
+      }
+    }
+  };
+  // the 4 x 4 patch of (channel kc, patch pcol of patch row wave) of the transform side's step, transformed:
+  // the result IS the A fragment of the 16 coefficient GEMMs
+  auto tr_load = [&](float (&d)[KS][4][4]) {
+#pragma unroll
+    for (int h = 0; h < KS; ++h) {
+      const float *raw = smem + tr_stage * STAGE + (h * 4 + kc) * WN_RCST + (2 * wave) * WN_XS + 2 * pcol + 3;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[h][i][j] = raw[i * WN_XS + j];
+    }
+  };
+  auto tr_finish = [&](float (&d)[KS][4][4], float (&v)[KS][16]) {
+#pragma unroll
+    for (int h = 0; h < KS; ++h) {
+      if constexpr (MODE == 1) {
+        const float *sc_t = scsh + (tr_round & 1) * 64;
+        const int c = (tr_chunk * KS + h) * 4 + kc;
+        const bool cok = c < g.cin;
+        const float sc = sc_t[cok ? c : 0], sh = sc_t[32 + (cok ? c : 0)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            d[h][i][j] = (cok && ((tr_rowok >> i) & 1u) && ((tr_colok >> j) & 1u)) ? lrelu02(d[h][i][j] * sc + sh) : 0.0f;
+      }
+      float t[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t[0][j] = d[h][0][j] - d[h][2][j];
+        t[1][j] = d[h][1][j] + d[h][2][j];
+        t[2][j] = d[h][2][j] - d[h][1][j];
+        t[3][j] = d[h][1][j] - d[h][3][j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[h][i * 4 + 0] = t[i][0] - t[i][2];
+        v[h][i * 4 + 1] = t[i][1] + t[i][2];
+        v[h][i * 4 + 2] = t[i][2] - t[i][1];
+        v[h][i * 4 + 3] = t[i][1] - t[i][3];
+      }
+    }
+    // advance the transform side
+    tr_stage = tr_stage + 1 == NSTAGE ? 0 : tr_stage + 1;
+    if (++tr_chunk == nsteps) {
+      tr_chunk = 0;
+      ++tr_round;
+      tr_setup();
+    }
+  };
+
+  float v[KS][16];
+  if (total_steps > 0) {
+    tr_setup();
+    wait_landed(total_steps - 1 < NSTAGE - 1 ? total_steps - 1 : NSTAGE - 1);
+    __syncthreads();   // step 0 (and U, and the first tile's scale/shift) visible to everyone
+    float d0[KS][4][4];
+    tr_load(d0);
+    tr_finish(d0, v);
+  }
+
+  int step = 0;
+  for (int round = 0; round < my_items; ++round) {
+    const int flat = round * G + slot;
+    const int n = flat / g.tiles, tile_id = flat - n * g.tiles;
+    const int tyi = wdiv(tile_id, g.fd_ntx), txi = tile_id - tyi * g.ntx;
+    const int y0 = tyi * WN_TY, x0 = txi * WN_TX;
+
+    floatx4 acc[16][2];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) acc[xi][0] = acc[xi][1] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    for (int chunk = 0; chunk < nsteps; ++chunk, ++step) {
+      const bool has_next = step + 1 < total_steps;   // uniform
+      if (has_next) {
+        const int rest = total_steps - (step + 2);     // steps issued after step + 1 so far
+        wait_landed(rest < 0 ? 0 : (rest < NSTAGE - 2 ? rest : NSTAGE - 2));   // step + 1 has landed
+        WN_STAMP();   // landed
+        __syncthreads();   // ... for everyone; everyone has read the raw tile of `step`; next tile's scale/shift visible
+        WN_STAMP();   // barrier
+      }
+      // multiplies of `step` with the transform of `step + 1` slotted between them
+      float dn[KS][4][4];
+      if (has_next) tr_load(dn);
+#pragma unroll
+      for (int h = 0; h < KS; ++h) {
+        if (KS == 2 && h == 1 && chunk * KS + 1 >= g.nchunks) break;   // uniform: odd chunk count, nothing in the second half
+        const float *ub = U + (chunk * KS + h) * WN_UFLOATS + lane;
+        float fb[2][2];
+        fb[0][0] = ub[0], fb[0][1] = ub[64];
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {   // next coefficient's U fragments in flight behind this one's MFMAs
+          const int cur = xi & 1;
+          if (xi + 1 < 16) {
+            fb[cur ^ 1][0] = ub[(xi + 1) * 128];
+            fb[cur ^ 1][1] = ub[(xi + 1) * 128 + 64];
+          }
+          acc[xi][0] = mfma16x16x4(v[h][xi], fb[cur][0], acc[xi][0]);
+          acc[xi][1] = mfma16x16x4(v[h][xi], fb[cur][1], acc[xi][1]);
+          if (h == 0 && xi == 1 && has_next) pf_issue();   // step + NSTAGE into the stage `step` released, behind the first MFMAs
+        }
+      }
+      if (has_next) tr_finish(dn, v);   // v: A fragments of step + 1 (written after the last MFMA read it)
+      WN_STAMP();   // MFMAs issued + next transform
+    }
+
+    // ---- output transform, bias, stores, GroupNorm partials
+    // lane: cout t*16 + (lane&15); patches 4*(lane>>4) + r of patch row `wave` = output rows y0 + 2 wave (+1),
+    // columns x0 + 8 (lane>>4) .. + 7
+    const int cl = lane & 15;
+    const int oy = y0 + 2 * wave, ox = x0 + 8 * (lane >> 4);
+    const bool row0 = oy < g.H, row1 = oy + 1 < g.H;
+    const bool q0 = ox < g.W, q1 = ox + 4 < g.W;   // W % 4 == 0: each float4 is all inside or all outside
+    float *outn = out + (size_t)n * 32 * plane;
+    const int cnt = ((row0 ? 1 : 0) + (row1 ? 1 : 0)) * ((q0 ? 4 : 0) + (q1 ? 4 : 0));
+    float s[2] = {0.f, 0.f};
+    float y[2][2][8];   // [t][row][col]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float bv = bias ? bias[t * 16 + cl] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s0[4], s1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s0[j] = acc[j][t][r] + acc[4 + j][t][r] + acc[8 + j][t][r];
+          s1[j] = acc[4 + j][t][r] - acc[8 + j][t][r] - acc[12 + j][t][r];
+        }
+        y[t][0][2 * r] = s0[0] + s0[1] + s0[2] + bv;
+        y[t][0][2 * r + 1] = s0[1] - s0[2] - s0[3] + bv;
+        y[t][1][2 * r] = s1[0] + s1[1] + s1[2] + bv;
+        y[t][1][2 * r + 1] = s1[1] - s1[2] - s1[3] + bv;
+      }
+      float *oc = outn + (size_t)(t * 16 + cl) * plane + (size_t)oy * g.W + ox;
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const bool rok = rr ? row1 : row0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bool ok = rok && (h ? q1 : q0);
+          if (ok) {
+            *reinterpret_cast<floatx4 *>(oc + (size_t)rr * g.W + 4 * h) =
+                floatx4{y[t][rr][4 * h], y[t][rr][4 * h + 1], y[t][rr][4 * h + 2], y[t][rr][4 * h + 3]};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[t] += y[t][rr][4 * h + k];
+          }
+        }
+      }
+    }
+    WN_STAMP();   // output transform + stores issued
+    if (out_partials != nullptr) {   // uniform
+      auto pixel_sum = [&](float v) {
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        return v;
+      };
+      auto group_sum = [&](float v) {
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        return pixel_sum(v);
+      };
+      const int hi = (lane >> 3) & 1;
+      const float npos = pixel_sum((float)cnt) * 8.0f;
+      float m[2], qv[2] = {0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        s[t] = group_sum(s[t]);
+        m[t] = npos > 0.0f ? s[t] / npos : 0.0f;
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            if ((rr ? row1 : row0) && (h ? q1 : q0)) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const float dv = y[t][rr][4 * h + k] - m[t];
+                qv[t] += dv * dv;
+              }
+            }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) qv[t] = group_sum(qv[t]);
+      if ((lane & 0x37) == 0) {   // lanes 0 and 8
+        float *rec = out_partials + (((size_t)n * g.tiles + tile_id) * WN_WAVES + wave) * 12;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          rec[(t * 2 + hi) * 3 + 0] = npos;
+          rec[(t * 2 + hi) * 3 + 1] = m[t];
+          rec[(t * 2 + hi) * 3 + 2] = qv[t];
+        }
+      }
+    }
+  }
+}
+
+bool wino_geom(const mvsn_conv_desc *d, WinoGeom *g) {
+  if (!d || d->precision != MVSN_CONV_FP32_WINO) return false;
+  if (d->n <= 0 || d->c_in <= 0 || d->c_out != 32 || d->depth != 1 || d->rows <= 0 || d->cols <= 0) return false;
+  if (d->kd != 1 || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->dilation != 1) return false;
+  if (d->cols % 4 != 0) return false;
+  g->n = d->n, g->cin = d->c_in, g->H = d->rows, g->W = d->cols;
+  g->nty = (d->rows + WN_TY - 1) / WN_TY;
+  g->ntx = (d->cols + WN_TX - 1) / WN_TX;
+  g->tiles = g->nty * g->ntx;
+  g->nchunks = (d->c_in + 3) / 4;
+  if (g->nchunks > WN_MAX_CHUNKS) return false;   // U must stay resident in LDS
+  g->packed_floats = (size_t)g->nchunks * WN_UFLOATS;
+  return true;
+}
+
+int wino_pack(const mvsn_conv_desc *d, const float *weight, float *packed, hipStream_t stream) {
+  WinoGeom g;
+  if (!wino_geom(d, &g)) return MVSN_E_BADARG;
+  const int total = g.nchunks * WN_UFLOATS;
+  hipLaunchKernelGGL(wino_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, weight, g.cin, 32, g.nchunks,
+                     packed);
+  return check_launch("mvsn_conv_pack_weights(winograd)");
+}
+
+int wino_launch(const WinoGeom &g, const float *in, const float *upk, const float *bias, const float *in_stats,
+                const float *in_gamma, const float *in_beta, float *out, float *out_partials, hipStream_t stream) {
+  WinoArgs a;
+  a.n = g.n, a.cin = g.cin, a.H = g.H, a.W = g.W, a.ntx = g.ntx, a.tiles = g.tiles, a.nchunks = g.nchunks;
+  a.fd_ntx = wino_div((unsigned)g.ntx);
+  const bool wide = g.nchunks > 1;                    // two k-steps per step
+  const int nstage = wide ? 4 : 6;
+  const size_t lds = ((size_t)nstage * (wide ? 2 : 1) * 4 * WN_RCST + (size_t)g.nchunks * WN_UFLOATS + 128) * sizeof(float);
+  static size_t opted[4] = {0, 0, 0, 0};
+  const int mode = (in_stats ? 1 : 0) + (wide ? 2 : 0);
+  const void *kern = mode == 3   ? (const void *)conv_wino_kernel<1, 2, 4>
+                     : mode == 2 ? (const void *)conv_wino_kernel<0, 2, 4>
+                     : mode == 1 ? (const void *)conv_wino_kernel<1, 1, 6>
+                                 : (const void *)conv_wino_kernel<0, 1, 6>;
+  if (lds > opted[mode]) {
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("mvsn_conv_forward(winograd): LDS opt-in of %zu bytes failed: %s", lds, hipGetErrorString(e));
+      return (int)e;
+    }
+    opted[mode] = lds;
+  }
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+  }
+  const long total = (long)g.n * g.tiles;
+  dim3 grid((unsigned)(total < cus ? total : cus));   // persistent: one workgroup per CU walks items grid-strided
+#define WN_LAUNCH(M, K, N)                                                                                          \
+  hipLaunchKernelGGL((conv_wino_kernel<M, K, N>), grid, dim3(WN_THREADS), lds, stream, a, in, upk, bias, in_stats, \
+                     in_gamma, in_beta, out, out_partials)
+  if (mode == 3) WN_LAUNCH(1, 2, 4);
+  else if (mode == 2) WN_LAUNCH(0, 2, 4);
+  else if (mode == 1) WN_LAUNCH(1, 1, 6);
+  else WN_LAUNCH(0, 1, 6);
+#undef WN_LAUNCH
+  return check_launch("mvsn_conv_forward(winograd)");
+}
+
+}  // namespace mvsn
+
+#ifdef MVSN_WN_STAMPS
+extern "C" int mvsn_debug_set_wino_stamps(void *buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(mvsn::g_wn_stamps), &buf, sizeof(buf));
+}
+#endif

@@ -63,6 +63,15 @@ class _Conv:
             _native.check(lib.mvsn_conv_pack_weights(ctypes.byref(dbx), _native.ptr(w), _native.ptr(self.packed_bx),
                                                      _native.stream()), "mvsn_conv_pack_weights(bf16x3)")
 
+        # third packing: Winograd F(2x2,3x3) coefficients for the 2-D 3x3 stride-1 dilation-1 layers
+        self.packed_wino = None
+        dwn = self.desc(1, 1, 8, 32, _native.CONV_FP32_WINO)
+        if self.dims == 2 and lib.mvsn_conv_winograd_supported(ctypes.byref(dwn)):
+            nwn = lib.mvsn_conv_packed_floats(ctypes.byref(dwn))
+            self.packed_wino = torch.empty(nwn, dtype=torch.float32, device=weight.device)
+            _native.check(lib.mvsn_conv_pack_weights(ctypes.byref(dwn), _native.ptr(w), _native.ptr(self.packed_wino),
+                                                     _native.stream()), "mvsn_conv_pack_weights(winograd)")
+
     def desc(self, n, depth, rows, cols, precision=_native.CONV_FP32):
         return _native.ConvDesc(n, self.cin, self.cout, depth, rows, cols, self.kd, self.kh, self.kw,
                                 self.stride, self.dilation, precision)
@@ -89,6 +98,8 @@ class PlaneSweepEngine:
         # Arithmetic of the 32 -> 32 channel 3x3 / 3x3x3 layers: "fp32" = exact fp32 MFMA;
         # "bf16x3" = 3 x bf16 split on the bf16 matrix cores (fp32-equivalent to ~2^-16 per product).
         self.conv_precision = "fp32"
+        # Winograd F(2x2,3x3) form of the 2-D 3x3 dilation-1 layers (fp32 throughout, 2.25x fewer multiplies).
+        self.winograd = True
         # Skip the stand-alone normalise/activate pass at both ends of a refiner tower (see
         # residual_tower_unfused); False keeps one pass per block (tests compare the two).
         self.trim_tower_ends = True
@@ -152,6 +163,11 @@ class PlaneSweepEngine:
             dbx = c.desc(n, depth, rows, cols, _native.CONV_BF16X3)
             if lib.mvsn_conv_bf16x3_supported(ctypes.byref(dbx)):
                 d, packed = dbx, c.packed_bx
+        elif self.winograd and c.packed_wino is not None and in_residual is None and not write_staged and \
+                (in_stats is None or c.cin == 32):
+            dwn = c.desc(n, depth, rows, cols, _native.CONV_FP32_WINO)
+            if lib.mvsn_conv_winograd_supported(ctypes.byref(dwn)):
+                d, packed = dwn, c.packed_wino
         ro, co = (rows - 1) // c.stride + 1, (cols - 1) // c.stride + 1
         shape = (n, c.cout, depth, ro, co) if c.dims == 3 else (n, c.cout, ro, co)
         out = torch.empty(shape, dtype=torch.float32, device=x.device)
@@ -163,7 +179,8 @@ class PlaneSweepEngine:
         taps = c.kd * c.kh * c.kw
         tag = (f"conv{c.dims}d k{c.kh}" + (f"s{c.stride}" if c.stride > 1 else "") +
                (f"d{c.dilation}" if c.dilation > 1 else "") + f" {c.cin}->{c.cout}" +
-               (" bf16x3" if d.precision == _native.CONV_BF16X3 else ""))
+               (" bf16x3" if d.precision == _native.CONV_BF16X3 else "") +
+               (" wino" if d.precision == _native.CONV_FP32_WINO else ""))
         nbytes = 4.0 * (x.numel() * (2 if in_residual is not None else 1) + out.numel() +
                         (staged.numel() if staged is not None else 0))
         self._call("mvsn_conv_forward[" + tag + "]", lib.mvsn_conv_forward, ctypes.byref(d), _native.ptr(x),
