@@ -254,11 +254,19 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         const int c = (tr_chunk * KS + h) * 4 + kc;
         const bool cok = c < g.cin;
         const float sc = sc_t[cok ? c : 0], sh = sc_t[32 + (cok ? c : 0)];
+        if (__builtin_amdgcn_read_exec() == __builtin_amdgcn_ballot_w64(cok && tr_rowok == 15u && tr_colok == 15u)) {
+          // interior patches in every lane (the usual case): no padding to keep at zero
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            d[h][i][j] = (cok && ((tr_rowok >> i) & 1u) && ((tr_colok >> j) & 1u)) ? lrelu02(d[h][i][j] * sc + sh) : 0.0f;
+            for (int j = 0; j < 4; ++j) d[h][i][j] = lrelu02(d[h][i][j] * sc + sh);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              d[h][i][j] = (cok && ((tr_rowok >> i) & 1u) && ((tr_colok >> j) & 1u)) ? lrelu02(d[h][i][j] * sc + sh) : 0.0f;
+        }
       }
       float t[4][4];
 #pragma unroll

@@ -100,6 +100,9 @@ class PlaneSweepEngine:
         self.conv_precision = "fp32"
         # Winograd F(2x2,3x3) form of the 2-D 3x3 dilation-1 layers (fp32 throughout, 2.25x fewer multiplies).
         self.winograd = True
+        # ... but not where the previous layer's LeakyReLU(GN(.)) is applied on load: there the extra VALU work
+        # in the transform makes it slower than the direct kernel (2.9 vs 2.65 ms at level 0).
+        self.winograd_with_input_transform = False
         # Skip the stand-alone normalise/activate pass at both ends of a refiner tower (see
         # residual_tower_unfused); False keeps one pass per block (tests compare the two).
         self.trim_tower_ends = True
@@ -164,7 +167,7 @@ class PlaneSweepEngine:
             if lib.mvsn_conv_bf16x3_supported(ctypes.byref(dbx)):
                 d, packed = dbx, c.packed_bx
         elif self.winograd and c.packed_wino is not None and in_residual is None and not write_staged and \
-                (in_stats is None or c.cin == 32):
+                (in_stats is None or self.winograd_with_input_transform):
             dwn = c.desc(n, depth, rows, cols, _native.CONV_FP32_WINO)
             if lib.mvsn_conv_winograd_supported(ctypes.byref(dwn)):
                 d, packed = dwn, c.packed_wino

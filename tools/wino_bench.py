@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Timing aid: Winograd vs direct form of the level-0 3x3 32->32 layer."""
+"""Timing aid: Winograd vs direct form of the level-0 3x3 32->32 layer (plain and with the fused input transform)."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multi_view_stereonet_amd import MultiViewStereoNet
@@ -9,6 +9,7 @@ eng = net.engine()
 conv, norm = eng.refiners[0]["res"][0]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 x = torch.randn(B, 32, 256, 512, device="cuda")
+st = torch.zeros(B, 4, 2, device="cuda"); st[:, :, 1] = 1
 def timed(fn, reps=3):
     for _ in range(reps):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -18,4 +19,5 @@ gf = 2.0 * 9 * 32 * 32 * x[:, 0].numel() / 1e9
 for wino in (True, False):
     eng.winograd = wino
     ms = timed(lambda: eng.conv(conv, x, want_stats=True))
-    print("winograd" if wino else "direct  ", "%.3f ms  %.1f algorithmic TFLOP/s" % (ms, gf / ms))
+    ms1 = timed(lambda: eng.conv(conv, x, in_stats=st, in_norm=norm, want_stats=True))
+    print("winograd" if wino else "direct  ", "%.3f ms  %.1f algorithmic TFLOP/s;  with input transform %.3f ms" % (ms, gf / ms, ms1))
