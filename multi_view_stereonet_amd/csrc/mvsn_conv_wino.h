@@ -8,7 +8,7 @@
 namespace mvsn {
 
 struct WinoGeom {
-  int n, cin, H, W;
+  int n, cin, H, W, dil;
   int nty, ntx, tiles, nchunks;
   size_t packed_floats;
 };

@@ -34,15 +34,18 @@ namespace mvsn {
 
 constexpr int WN_THREADS = 512, WN_WAVES = 8;
 constexpr int WN_TY = 16, WN_TX = 32;                  // output tile
-constexpr int WN_HY = WN_TY + 2;                       // haloed rows
-constexpr int WN_XS = 40;                              // row stride: columns x0 - 4 .. x0 + 35
-constexpr int WN_GROUPS = WN_HY * 10;                  // 16-byte groups per channel tile (180)
-constexpr int WN_PIECES = (WN_GROUPS + 63) / 64;       // DMA instructions per channel (3; the last is lane-masked)
-constexpr int WN_RCST = WN_HY * WN_XS + 16;            // raw channel stride (floats)
+// haloed raw tile of a layer with dilation DIL (a dilated layer is DIL x DIL interleaved dilation-1 problems:
+// a "2 x 2 patch" is the outputs (y, x), (y, x + DIL), (y + DIL, x), (y + DIL, x + DIL), its input window the
+// 4 x 4 samples at stride DIL)
+constexpr int wn_pa(int dil) { return (dil + 3) / 4 * 4; }                 // halo rounded up to 16-byte columns
+constexpr int wn_xs(int dil) { return WN_TX + 2 * wn_pa(dil); }            // row stride: columns x0 - pa .. x0 + 31 + pa
+constexpr int wn_hy(int dil) { return WN_TY + 2 * dil; }                   // haloed rows
+constexpr int wn_groups(int dil) { return wn_hy(dil) * (wn_xs(dil) / 4); } // 16-byte groups per channel tile
+constexpr int wn_pieces(int dil) { return (wn_groups(dil) + 63) / 64; }    // DMA instructions per channel
+constexpr int wn_rcst(int dil) { return wn_hy(dil) * wn_xs(dil) + 16; }    // raw channel stride (floats)
 constexpr int WN_UFLOATS = 16 * 128;                   // U fragments per chunk: [xi][cout tile][lane]
 constexpr int WN_MAX_CHUNKS = 8;                       // resident U: up to 32 input channels (64 KB)
 constexpr float WN_EPS = 1e-5f;
-static_assert(WN_PIECES == 3, "DMA split below assumes three pieces per channel");
 
 __device__ floatx4 g_wn_zero16 = {0.f, 0.f, 0.f, 0.f};
 #define WN_GPTR(p) ((const __attribute__((address_space(1))) void *)(p))
@@ -94,7 +97,8 @@ __global__ void wino_pack_kernel(const float *__restrict__ w, int cin, int cout,
 //         tile), 1 for the 4-channel head
 // NSTAGE  depth of the raw-tile ring (KS = 2: 4 x 23 KB next to the 64 KB of U; a step is ~2 us, a DMA round
 //         trip under load longer)
-template <int MODE, int KS, int NSTAGE>
+// DIL     dilation (1, 2, 4, 8)
+template <int MODE, int KS, int NSTAGE, int DIL>
 __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, const float *__restrict__ in,
                                                                   const float *__restrict__ upk,
                                                                   const float *__restrict__ bias,
@@ -104,7 +108,9 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
                                                                   float *__restrict__ out,
                                                                   float *__restrict__ out_partials) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int STAGE = KS * 4 * WN_RCST;            // ring stage (floats)
+  constexpr int PA = wn_pa(DIL), XS = wn_xs(DIL), DQ = XS / 4, GROUPS = wn_groups(DIL), PIECES = wn_pieces(DIL);
+  constexpr int RCST = wn_rcst(DIL);
+  constexpr int STAGE = KS * 4 * RCST;               // ring stage (floats)
   float *U = smem + NSTAGE * STAGE;                  // nchunks * WN_UFLOATS, resident
   float *scsh = U + g.nchunks * WN_UFLOATS;          // 2 x (32 scale + 32 shift): double-buffered per tile
   const int nsteps = (g.nchunks + KS - 1) / KS;      // steps per tile
@@ -130,13 +136,19 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   }
 
   // ---- prefetcher state: DMA of (item, chunk) steps runs two steps ahead of the multiplies
-  // KS = 2: wave w fetches channel w of the step (3 pieces); KS = 1: waves 0-3 fetch pieces 0, 1 of channel w,
-  // waves 4-7 piece 2 of channel w - 4
-  const int dch = KS == 2 ? wave : (wave & 3);
-  const int dp0 = (KS == 2 || wave < 4) ? 0 : 2, dpn = KS == 2 ? 3 : (wave < 4 ? 2 : 1);
+  // the step's KS * 4 * PIECES pieces are dealt to the 8 waves in order (channel-major); where they do not
+  // divide evenly (the 4-channel head: 12 pieces) waves 0-3 take pieces 0, 1 of channel w, waves 4-7 piece 2
+  constexpr int STEP_PIECES = KS * 4 * PIECES;
+  constexpr bool EVEN = STEP_PIECES % WN_WAVES == 0;
+  constexpr int PER = EVEN ? STEP_PIECES / WN_WAVES : 2;   // pieces per wave (upper bound)
+  static_assert(EVEN || (KS == 1 && PIECES == 3), "uneven DMA split only for the 12-piece case");
+  static_assert(!EVEN || PIECES % PER == 0 || PER % PIECES == 0, "a wave's pieces stay within one channel");
+  const int dch = EVEN ? (wave * PER) / PIECES : (wave & 3);
+  const int dp0 = EVEN ? (wave * PER) % PIECES : (wave < 4 ? 0 : 2);
+  const int dpn = EVEN ? (PER < PIECES ? PER : PIECES) : (wave < 4 ? 2 : 1);
   const float *zero = reinterpret_cast<const float *>(&g_wn_zero16);
   int pf_round = 0, pf_chunk = 0, pf_stage = 0;
-  int pf_goff[3] = {-1, -1, -1};
+  int pf_goff[PER];
   const float *pf_src = in;
   bool pf_live = slot < total;
   auto pf_plan = [&]() {   // DMA plan of the prefetcher's current item
@@ -146,11 +158,11 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     const int y0 = tyi * WN_TY, x0 = txi * WN_TX;
     pf_src = in + (size_t)n * g.cin * plane;
 #pragma unroll
-    for (int i = 0; i < (KS == 2 ? 3 : 2); ++i) {
+    for (int i = 0; i < PER; ++i) {
       const int e = (dp0 + i) * 64 + lane;
-      const int row = e / 10, q = e - row * 10;
-      const int gy = y0 - 1 + row, gx = x0 - 4 + 4 * q;
-      pf_goff[i] = (i < dpn && e < WN_GROUPS && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) ? gy * g.W + gx : -1;
+      const int row = e / DQ, q = e - row * DQ;
+      const int gy = y0 - DIL + row, gx = x0 - PA + 4 * q;
+      pf_goff[i] = (i < dpn && e < GROUPS && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) ? gy * g.W + gx : -1;
     }
   };
   auto pf_issue = [&]() {   // issue the DMA of the prefetcher's step and advance it
@@ -158,12 +170,12 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     const int c = pf_chunk * (KS * 4) + dch;
     const bool cok = c < g.cin;
     const float *src = pf_src + (size_t)(cok ? c : 0) * plane;
-    float *dst = smem + pf_stage * STAGE + dch * WN_RCST;
+    float *dst = smem + pf_stage * STAGE + dch * RCST;
 #pragma unroll
-    for (int i = 0; i < (KS == 2 ? 3 : 2); ++i) {
+    for (int i = 0; i < PER; ++i) {
       if (i < dpn) {   // uniform
         const float *p = (cok && pf_goff[i] >= 0) ? src + pf_goff[i] : zero;
-        if ((dp0 + i) * 64 + lane < WN_GROUPS)   // lanes past the tile's last 16-byte group stay out of the slot
+        if ((dp0 + i) * 64 + lane < GROUPS)   // lanes past the tile's last 16-byte group stay out of the slot
           __builtin_amdgcn_global_load_lds(WN_GPTR(p), WN_LPTR(dst + (dp0 + i) * 256), 16, 0, 0);
       }
     }
@@ -181,6 +193,8 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   WN_STAMP();   // prologue
 
   const int pcol = lane & 15, kc = lane >> 4;   // this lane's patch column / channel within the chunk; patch row = wave
+  // first output row / column of patch row `wave` / patch column `pcol` inside the tile (the second is + DIL)
+  const int ya = (wave / DIL) * 2 * DIL + wave % DIL, xa = (pcol / DIL) * 2 * DIL + pcol % DIL;
   const int my_items = slot < total ? (total - slot + G - 1) / G : 0;
   const int total_steps = my_items * nsteps;
 
@@ -189,7 +203,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   auto wait_landed = [&](int younger) {
 #define WN_WAIT_CASE(K)                                                              \
   case K:                                                                            \
-    if (KS == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (K)) : "memory");        \
+    if (EVEN) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER * (K)) : "memory");         \
     else if (wave < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (K)) : "memory"); \
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory");                       \
     break;
@@ -204,7 +218,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     }
 #undef WN_WAIT_CASE
   };
-  static_assert(NSTAGE - 1 <= 5, "wait_landed covers up to 5 younger steps");
+  static_assert(NSTAGE - 1 <= 5 && PER * 5 <= 63, "wait_landed covers up to 5 younger steps within the vmcnt range");
 
   // ---- transform side: runs one step ahead of the multiplies (its tile may already be the next one)
   int tr_round = 0, tr_chunk = 0, tr_stage = 0;
@@ -219,7 +233,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       tr_rowok = 0, tr_colok = 0;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int gy = y0 - 1 + 2 * wave + i, gx = x0 - 1 + 2 * pcol + i;
+        const int gy = y0 + ya + (i - 1) * DIL, gx = x0 + xa + (i - 1) * DIL;
         if (gy >= 0 && gy < g.H) tr_rowok |= 1u << i;
         if (gx >= 0 && gx < g.W) tr_colok |= 1u << i;
       }
@@ -239,11 +253,11 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   auto tr_load = [&](float (&d)[KS][4][4]) {
 #pragma unroll
     for (int h = 0; h < KS; ++h) {
-      const float *raw = smem + tr_stage * STAGE + (h * 4 + kc) * WN_RCST + (2 * wave) * WN_XS + 2 * pcol + 3;
+      const float *raw = smem + tr_stage * STAGE + (h * 4 + kc) * RCST + ya * XS + xa + (PA - DIL);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) d[h][i][j] = raw[i * WN_XS + j];
+        for (int j = 0; j < 4; ++j) d[h][i][j] = raw[i * DIL * XS + j * DIL];
     }
   };
   auto tr_finish = [&](float (&d)[KS][4][4], float (&v)[KS][16]) {
@@ -349,16 +363,22 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     }
 
     // ---- output transform, bias, stores, GroupNorm partials
-    // lane: cout t*16 + (lane&15); patches 4*(lane>>4) + r of patch row `wave` = output rows y0 + 2 wave (+1),
-    // columns x0 + 8 (lane>>4) .. + 7
-    const int cl = lane & 15;
-    const int oy = y0 + 2 * wave, ox = x0 + 8 * (lane >> 4);
-    const bool row0 = oy < g.H, row1 = oy + 1 < g.H;
-    const bool q0 = ox < g.W, q1 = ox + 4 < g.W;   // W % 4 == 0: each float4 is all inside or all outside
+    // lane: cout t*16 + (lane&15); patches p = 4*(lane>>4) + r of patch row `wave`: output rows ya, ya + DIL and
+    // columns xa(p), xa(p) + DIL.  Whatever the dilation, the eight columns of a lane's four patches form two
+    // aligned groups of four consecutive columns: element (r, second) goes to slot k of group h.
+    const int cl = lane & 15, gq = lane >> 4;
+    constexpr int PSH = DIL <= 2 ? 1 : 0;   // DIL 1, 2: h = r >> 1; DIL 4, 8: h = second
+    auto slot_h = [](int r, int sec) { return PSH ? (r >> 1) : sec; };
+    auto slot_k = [](int r, int sec) { return DIL == 1 ? 2 * (r & 1) + sec : (DIL == 2 ? (r & 1) + 2 * sec : r); };
+    const int oy = y0 + ya;
+    const int xg0 = DIL == 8 ? 16 * (gq >> 1) + 4 * (gq & 1) : 8 * gq;   // first column of group 0 inside the tile
+    const int xg1 = xg0 + (DIL == 8 ? 8 : 4);
+    const bool row0 = oy < g.H, row1 = oy + DIL < g.H;
+    const bool q0 = x0 + xg0 < g.W, q1 = x0 + xg1 < g.W;   // W % 4 == 0: each float4 is all inside or all outside
     float *outn = out + (size_t)n * 32 * plane;
     const int cnt = ((row0 ? 1 : 0) + (row1 ? 1 : 0)) * ((q0 ? 4 : 0) + (q1 ? 4 : 0));
     float s[2] = {0.f, 0.f};
-    float y[2][2][8];   // [t][row][col]
+    float y[2][2][8];   // [t][row][group * 4 + slot]
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const float bv = bias ? bias[t * 16 + cl] : 0.0f;
@@ -370,12 +390,12 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
           s0[j] = acc[j][t][r] + acc[4 + j][t][r] + acc[8 + j][t][r];
           s1[j] = acc[4 + j][t][r] - acc[8 + j][t][r] - acc[12 + j][t][r];
         }
-        y[t][0][2 * r] = s0[0] + s0[1] + s0[2] + bv;
-        y[t][0][2 * r + 1] = s0[1] - s0[2] - s0[3] + bv;
-        y[t][1][2 * r] = s1[0] + s1[1] + s1[2] + bv;
-        y[t][1][2 * r + 1] = s1[1] - s1[2] - s1[3] + bv;
+        y[t][0][slot_h(r, 0) * 4 + slot_k(r, 0)] = s0[0] + s0[1] + s0[2] + bv;
+        y[t][0][slot_h(r, 1) * 4 + slot_k(r, 1)] = s0[1] - s0[2] - s0[3] + bv;
+        y[t][1][slot_h(r, 0) * 4 + slot_k(r, 0)] = s1[0] + s1[1] + s1[2] + bv;
+        y[t][1][slot_h(r, 1) * 4 + slot_k(r, 1)] = s1[1] - s1[2] - s1[3] + bv;
       }
-      float *oc = outn + (size_t)(t * 16 + cl) * plane + (size_t)oy * g.W + ox;
+      float *oc = outn + (size_t)(t * 16 + cl) * plane + (size_t)oy * g.W + x0;
 #pragma unroll
       for (int rr = 0; rr < 2; ++rr) {
         const bool rok = rr ? row1 : row0;
@@ -383,7 +403,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         for (int h = 0; h < 2; ++h) {
           const bool ok = rok && (h ? q1 : q0);
           if (ok) {
-            *reinterpret_cast<floatx4 *>(oc + (size_t)rr * g.W + 4 * h) =
+            *reinterpret_cast<floatx4 *>(oc + (size_t)rr * DIL * g.W + (h ? xg1 : xg0)) =
                 floatx4{y[t][rr][4 * h], y[t][rr][4 * h + 1], y[t][rr][4 * h + 2], y[t][rr][4 * h + 3]};
 #pragma unroll
             for (int k = 0; k < 4; ++k) s[t] += y[t][rr][4 * h + k];
@@ -443,9 +463,10 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
 bool wino_geom(const mvsn_conv_desc *d, WinoGeom *g) {
   if (!d || d->precision != MVSN_CONV_FP32_WINO) return false;
   if (d->n <= 0 || d->c_in <= 0 || d->c_out != 32 || d->depth != 1 || d->rows <= 0 || d->cols <= 0) return false;
-  if (d->kd != 1 || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->dilation != 1) return false;
+  if (d->kd != 1 || d->kh != 3 || d->kw != 3 || d->stride != 1) return false;
+  if (d->dilation != 1 && d->dilation != 2 && d->dilation != 4 && d->dilation != 8) return false;
   if (d->cols % 4 != 0) return false;
-  g->n = d->n, g->cin = d->c_in, g->H = d->rows, g->W = d->cols;
+  g->n = d->n, g->cin = d->c_in, g->H = d->rows, g->W = d->cols, g->dil = d->dilation;
   g->nty = (d->rows + WN_TY - 1) / WN_TY;
   g->ntx = (d->cols + WN_TX - 1) / WN_TX;
   g->tiles = g->nty * g->ntx;
@@ -469,23 +490,6 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   WinoArgs a;
   a.n = g.n, a.cin = g.cin, a.H = g.H, a.W = g.W, a.ntx = g.ntx, a.tiles = g.tiles, a.nchunks = g.nchunks;
   a.fd_ntx = wino_div((unsigned)g.ntx);
-  const bool wide = g.nchunks > 1;                    // two k-steps per step
-  const int nstage = wide ? 4 : 6;
-  const size_t lds = ((size_t)nstage * (wide ? 2 : 1) * 4 * WN_RCST + (size_t)g.nchunks * WN_UFLOATS + 128) * sizeof(float);
-  static size_t opted[4] = {0, 0, 0, 0};
-  const int mode = (in_stats ? 1 : 0) + (wide ? 2 : 0);
-  const void *kern = mode == 3   ? (const void *)conv_wino_kernel<1, 2, 4>
-                     : mode == 2 ? (const void *)conv_wino_kernel<0, 2, 4>
-                     : mode == 1 ? (const void *)conv_wino_kernel<1, 1, 6>
-                                 : (const void *)conv_wino_kernel<0, 1, 6>;
-  if (lds > opted[mode]) {
-    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-      set_error("mvsn_conv_forward(winograd): LDS opt-in of %zu bytes failed: %s", lds, hipGetErrorString(e));
-      return (int)e;
-    }
-    opted[mode] = lds;
-  }
   static int cus = 0;
   if (cus == 0) {
     int dev = 0;
@@ -493,16 +497,44 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
       cus = 256;
   }
+  // (k-steps per step, ring depth) by what fits next to the resident U: the raw tile grows with the dilation
+  //   dilation 1: 2 k-steps x 4 stages (94 KB); 2, 4: 2 x 3 (78 / 94 KB); 8: 1 x 3 (74 KB); 4-channel head: 1 x 6
+  const bool head = g.nchunks == 1;
+  const int ks = (head || g.dil == 8) ? 1 : 2;
+#ifndef MVSN_WN_D1_STAGES
+#define MVSN_WN_D1_STAGES 4
+#endif
+  const int nstage = head ? 6 : (g.dil == 1 ? MVSN_WN_D1_STAGES : 3);
+  const size_t lds = ((size_t)nstage * ks * 4 * wn_rcst(g.dil) + (size_t)g.nchunks * WN_UFLOATS + 128) * sizeof(float);
+  if (head && g.dil != 1) {
+    set_error("mvsn_conv_forward(winograd): dilated 4-channel layers are not instantiated");
+    return MVSN_E_BADARG;
+  }
+  dim3 grid(1);
+#define WN_CASE(M, K, N, D)                                                                                        \
+  do {                                                                                                             \
+    static size_t opted = 0;                                                                                       \
+    if (lds > opted) {                                                                                             \
+      hipError_t e = hipFuncSetAttribute((const void *)conv_wino_kernel<M, K, N, D>,                               \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+      if (e != hipSuccess) {                                                                                       \
+        set_error("mvsn_conv_forward(winograd): LDS opt-in of %zu bytes failed: %s", lds, hipGetErrorString(e));   \
+        return (int)e;                                                                                             \
+      }                                                                                                            \
+      opted = lds;                                                                                                 \
+    }                                                                                                              \
+    hipLaunchKernelGGL((conv_wino_kernel<M, K, N, D>), grid, dim3(WN_THREADS), lds, stream, a, in, upk, bias,      \
+                       in_stats, in_gamma, in_beta, out, out_partials);                                            \
+  } while (0)
   const long total = (long)g.n * g.tiles;
-  dim3 grid((unsigned)(total < cus ? total : cus));   // persistent: one workgroup per CU walks items grid-strided
-#define WN_LAUNCH(M, K, N)                                                                                          \
-  hipLaunchKernelGGL((conv_wino_kernel<M, K, N>), grid, dim3(WN_THREADS), lds, stream, a, in, upk, bias, in_stats, \
-                     in_gamma, in_beta, out, out_partials)
-  if (mode == 3) WN_LAUNCH(1, 2, 4);
-  else if (mode == 2) WN_LAUNCH(0, 2, 4);
-  else if (mode == 1) WN_LAUNCH(1, 1, 6);
-  else WN_LAUNCH(0, 1, 6);
-#undef WN_LAUNCH
+  grid = dim3((unsigned)(total < cus ? total : cus));   // persistent: one workgroup per CU walks items grid-strided
+  const bool xf = in_stats != nullptr;
+  if (head) { if (xf) WN_CASE(1, 1, 6, 1); else WN_CASE(0, 1, 6, 1); }
+  else if (g.dil == 1) { if (xf) WN_CASE(1, 2, MVSN_WN_D1_STAGES, 1); else WN_CASE(0, 2, MVSN_WN_D1_STAGES, 1); }
+  else if (g.dil == 2) { if (xf) WN_CASE(1, 2, 3, 2); else WN_CASE(0, 2, 3, 2); }
+  else if (g.dil == 4) { if (xf) WN_CASE(1, 2, 3, 4); else WN_CASE(0, 2, 3, 4); }
+  else { if (xf) WN_CASE(1, 1, 3, 8); else WN_CASE(0, 1, 3, 8); }
+#undef WN_CASE
   return check_launch("mvsn_conv_forward(winograd)");
 }
 

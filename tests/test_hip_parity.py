@@ -145,19 +145,23 @@ def test_conv2d(cin, cout, k, stride, dil, rows, cols, n):
         close(y2, yref + ref, rtol=1e-4, atol=2e-4)
 
 
-@pytest.mark.parametrize("cin,rows,cols,n", [(32, 8, 32, 2), (32, 16, 32, 1), (32, 37, 68, 2), (36, 40, 72, 1),
-                                              (4, 24, 40, 3), (32, 256, 512, 3), (32, 5, 4, 2), (32, 64, 128, 37),
-                                              (4, 256, 512, 2)])
-def test_conv_winograd_form(cin, rows, cols, n):
+@pytest.mark.parametrize("cin,rows,cols,n,dil", [(32, 8, 32, 2, 1), (32, 16, 32, 1, 1), (32, 37, 68, 2, 1), (36, 40, 72, 1, 1),
+                                                  (4, 24, 40, 3, 1), (32, 256, 512, 3, 1), (32, 5, 4, 2, 1),
+                                                  (32, 64, 128, 37, 1), (4, 256, 512, 2, 1),
+                                                  (32, 16, 32, 2, 2), (32, 37, 68, 2, 2), (32, 128, 256, 5, 2),
+                                                  (32, 16, 32, 2, 4), (32, 41, 76, 3, 4), (32, 256, 512, 2, 4),
+                                                  (32, 16, 32, 2, 8), (32, 37, 68, 2, 8), (32, 256, 512, 2, 8),
+                                                  (32, 9, 12, 1, 8)])
+def test_conv_winograd_form(cin, rows, cols, n, dil):
     """Winograd F(2x2,3x3) form of the 3x3 layers (MVSN_CONV_FP32_WINO) against ATen and against the direct
     fp32 kernel: values, GroupNorm statistics, and the fused input transform (32-channel inputs)."""
     from multi_view_stereonet_amd.multi_view_stereonet import _Conv, _Norm
     eng = net_for("gta_sfm_150epochs").engine()
-    g = torch.Generator().manual_seed(cin * 10 + rows)
+    g = torch.Generator().manual_seed(cin * 10 + rows + dil)
     w = torch.randn(32, cin, 3, 3, generator=g) * 0.1
     b = torch.randn(32, generator=g) * 0.1
     x = torch.randn(n, cin, rows, cols, generator=g)
-    c = _Conv(eng.lib, w.to(DEV), b.to(DEV))
+    c = _Conv(eng.lib, w.to(DEV), b.to(DEV), dilation=dil)
     if cin > 32:
         assert c.packed_wino is None      # the transformed weights must fit LDS: the direct kernel serves 36 -> 32
         return
@@ -167,7 +171,7 @@ def test_conv_winograd_form(cin, rows, cols, n):
     eng.winograd = False
     out_d, stats_d = eng.conv(c, x.to(DEV), want_stats=True)
     eng.winograd = True
-    ref = F.conv2d(x, w, b, padding=1)
+    ref = F.conv2d(x, w, b, padding=dil, dilation=dil)
     close(out, ref, rtol=1e-4, atol=1e-4)
     assert rel_err(out.cpu(), out_d.cpu())[0] < 2e-6      # mean-rel vs the direct kernel: rounding only
     rg = ref.reshape(n, 4, -1).double()
@@ -183,7 +187,7 @@ def test_conv_winograd_form(cin, rows, cols, n):
         eng.winograd_with_input_transform = True
         out2, _ = eng.conv(c, x.to(DEV), in_stats=st_in.to(DEV), in_norm=_Norm(P))
         eng.winograd_with_input_transform = False
-        ref2 = F.conv2d(F.leaky_relu(F.group_norm(x, 4, gamma, beta, 1e-5), 0.2), w, b, padding=1)
+        ref2 = F.conv2d(F.leaky_relu(F.group_norm(x, 4, gamma, beta, 1e-5), 0.2), w, b, padding=dil, dilation=dil)
         close(out2, ref2, rtol=1e-4, atol=2e-4)
 
 

@@ -6,7 +6,6 @@ from multi_view_stereonet_amd import MultiViewStereoNet
 from multi_view_stereonet_amd.weights import load_weights
 net = MultiViewStereoNet(); net.load_state_dict(load_weights("gta_sfm_150epochs")); net = net.cuda().eval()
 eng = net.engine()
-conv, norm = eng.refiners[0]["res"][0]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 x = torch.randn(B, 32, 256, 512, device="cuda")
 st = torch.zeros(B, 4, 2, device="cuda"); st[:, :, 1] = 1
@@ -16,8 +15,12 @@ def timed(fn, reps=3):
         a.record(); fn(); b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b)
 gf = 2.0 * 9 * 32 * 32 * x[:, 0].numel() / 1e9
-for wino in (True, False):
-    eng.winograd = wino
-    ms = timed(lambda: eng.conv(conv, x, want_stats=True))
-    ms1 = timed(lambda: eng.conv(conv, x, in_stats=st, in_norm=norm, want_stats=True))
-    print("winograd" if wino else "direct  ", "%.3f ms  %.1f algorithmic TFLOP/s;  with input transform %.3f ms" % (ms, gf / ms, ms1))
+eng.winograd_with_input_transform = True
+for blk in (0, 1, 2, 3):            # dilations 1, 2, 4, 8
+    conv, norm = eng.refiners[0]["res"][blk]
+    for wino in (True, False):
+        eng.winograd = wino
+        ms = timed(lambda: eng.conv(conv, x, want_stats=True))
+        ms1 = timed(lambda: eng.conv(conv, x, in_stats=st, in_norm=norm, want_stats=True))
+        print("dilation %d" % conv.dilation, "winograd" if wino else "direct  ",
+              "%.3f ms  %.1f algorithmic TFLOP/s;  with input transform %.3f ms" % (ms, gf / ms, ms1))
