@@ -35,7 +35,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for s in SOURCES:
         o = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(o)
-        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, s), "-o", o]
+        # -fno-slp-vectorize: packed f32 VALU (v_pk_add_f32 ...) next to MFMAs costs more issue time than the two
+        # scalar ops it replaces (measured: +1.3 % end to end, +3-4 % on the Winograd kernels)
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-c",
+               os.path.join(CSRC, s), "-o", o]
         cmd += os.environ.get("MVSN_HIPCC_FLAGS", "").split()   # experiments: -D switches for A/B builds
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for cmd, p in procs:

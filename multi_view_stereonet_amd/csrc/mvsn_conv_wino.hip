@@ -254,10 +254,23 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
 #pragma unroll
     for (int h = 0; h < KS; ++h) {
       const float *raw = smem + tr_stage * STAGE + (h * 4 + kc) * RCST + ya * XS + xa + (PA - DIL);
+      if constexpr (DIL == 1) {
+        // columns (0, 2) and (1, 3) from two bases the compiler cannot relate: it would otherwise fuse the
+        // middle pair into a ds_read_b64 (three LDS instructions per row instead of two ds_read2_b32)
+        int oa = 0, ob = 1;
+        asm volatile("" : "+v"(oa), "+v"(ob));
+        const float *ra = raw + oa, *rb = raw + ob;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+          d[h][i][0] = ra[i * XS], d[h][i][2] = ra[i * XS + 2];
+          d[h][i][1] = rb[i * XS], d[h][i][3] = rb[i * XS + 2];
+        }
+      } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) d[h][i][j] = raw[i * DIL * XS + j * DIL];
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) d[h][i][j] = raw[i * DIL * XS + j * DIL];
+      }
     }
   };
   auto tr_finish = [&](float (&d)[KS][4][4], float (&v)[KS][16]) {
@@ -501,10 +514,7 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   //   dilation 1: 2 k-steps x 4 stages (94 KB); 2, 4: 2 x 3 (78 / 94 KB); 8: 1 x 3 (74 KB); 4-channel head: 1 x 6
   const bool head = g.nchunks == 1;
   const int ks = (head || g.dil == 8) ? 1 : 2;
-#ifndef MVSN_WN_D1_STAGES
-#define MVSN_WN_D1_STAGES 4
-#endif
-  const int nstage = head ? 6 : (g.dil == 1 ? MVSN_WN_D1_STAGES : 3);
+  const int nstage = head ? 6 : (g.dil == 1 ? 4 : 3);
   const size_t lds = ((size_t)nstage * ks * 4 * wn_rcst(g.dil) + (size_t)g.nchunks * WN_UFLOATS + 128) * sizeof(float);
   if (head && g.dil != 1) {
     set_error("mvsn_conv_forward(winograd): dilated 4-channel layers are not instantiated");
@@ -530,7 +540,7 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   grid = dim3((unsigned)(total < cus ? total : cus));   // persistent: one workgroup per CU walks items grid-strided
   const bool xf = in_stats != nullptr;
   if (head) { if (xf) WN_CASE(1, 1, 6, 1); else WN_CASE(0, 1, 6, 1); }
-  else if (g.dil == 1) { if (xf) WN_CASE(1, 2, MVSN_WN_D1_STAGES, 1); else WN_CASE(0, 2, MVSN_WN_D1_STAGES, 1); }
+  else if (g.dil == 1) { if (xf) WN_CASE(1, 2, 4, 1); else WN_CASE(0, 2, 4, 1); }
   else if (g.dil == 2) { if (xf) WN_CASE(1, 2, 3, 2); else WN_CASE(0, 2, 3, 2); }
   else if (g.dil == 4) { if (xf) WN_CASE(1, 2, 3, 4); else WN_CASE(0, 2, 3, 4); }
   else { if (xf) WN_CASE(1, 1, 3, 8); else WN_CASE(0, 1, 3, 8); }
