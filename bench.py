@@ -141,6 +141,10 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    # set-up, outside the warm-up / timed protocol and reported as "setup_forwards": the first forward packs the
+    # weights, opts the kernels into their LDS sizes and grows the allocator pools (one-time work per process)
+    run_forward(net, inp)
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         out = run_forward(net, inp)
     torch.cuda.synchronize()
@@ -167,7 +171,8 @@ def main():
     if rank == 0:
         line = {"metric": "depthmaps/sec at 512x256, 64 hypotheses, 2 src views; L1 vs ref",
                 "value": B * world * args.steps / elapsed, "unit": "depthmaps/s", "n_gpus": world,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                "steps": args.steps, "warmup": args.warmup, "setup_forwards": 1,
+                "ms_per_step": elapsed / args.steps * 1e3,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                 "data": "synthetic (seeded uniform frames, pretrained gta_sfm_150epochs weights)",
                 "config": {"workload": "GTA-SfM-shaped 512x256, D=64 hypotheses, 2 source views, "
