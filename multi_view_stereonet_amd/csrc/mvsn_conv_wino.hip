@@ -25,8 +25,8 @@
 //   * output transform in registers (D = patches x couts: a lane holds 4 consecutive patches of one cout, i.e.
 //     8 consecutive output columns of 2 rows): A^T m A (24 adds per patch), bias, 16-byte stores, per-wave
 //     GroupNorm partials.
-// MODE 1: the previous layer's LeakyReLU(GroupNorm(.)) is applied to d in registers before the transform
-// (out-of-image elements stay zero, as the padding of the materialised tensor would be).
+// MODE 1: the previous layer's LeakyReLU(GroupNorm(.)) is applied in LDS, once per element, by the wave that
+// fetched the piece (out-of-image pieces keep their zeros, as the padding of the materialised tensor would be).
 #include "mvsn_common.h"
 #include "mvsn_conv_wino.h"
 
@@ -220,34 +220,64 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   };
   static_assert(NSTAGE - 1 <= 5 && PER * 5 <= 63, "wait_landed covers up to 5 younger steps within the vmcnt range");
 
-  // ---- transform side: runs one step ahead of the multiplies (its tile may already be the next one)
-  int tr_round = 0, tr_chunk = 0, tr_stage = 0;
-  unsigned tr_rowok = 0, tr_colok = 0;   // MODE 1: which of the 4 x 4 patch elements are inside the image
-  auto tr_setup = [&]() {   // entering tile `tr_round`: masks, and the tile's scale/shift into its half of scsh
+  // ---- MODE 1: the previous layer's LeakyReLU(GroupNorm(.)) is applied IN LDS by the wave that fetched a piece,
+  // once per element, between the piece's arrival and the barrier that publishes the step (the patches overlap
+  // 2 x 2: transformed in registers per patch every element would be processed four times).  Pieces outside
+  // the image keep their zeros, as the padding of the materialised tensor would be.
+  int xf_round = 0, xf_chunk = 0, xf_stage = 0;
+  unsigned xf_mask = 0;            // which of this wave's pieces of the current tile lie inside the image
+  float xf_sc = 0.f, xf_sh = 0.f;  // scale / shift of this wave's channel of the current step
+  bool xf_on = false;
+  auto xf_prepare = [&]() {        // parameters of the step the in-LDS side handles next (issued one step early)
     if constexpr (MODE == 1) {
-      const int flat = tr_round * G + slot;
-      if (flat >= total) return;
+      const int flat = xf_round * G + slot;
+      xf_on = flat < total;
+      if (!xf_on) return;
       const int n = flat / g.tiles, tile = flat - n * g.tiles;
-      const int tyi = wdiv(tile, g.fd_ntx), txi = tile - tyi * g.ntx;
-      const int y0 = tyi * WN_TY, x0 = txi * WN_TX;
-      tr_rowok = 0, tr_colok = 0;
+      if (xf_chunk == 0) {
+        const int tyi = wdiv(tile, g.fd_ntx), txi = tile - tyi * g.ntx;
+        const int y0 = tyi * WN_TY, x0 = txi * WN_TX;
+        xf_mask = 0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int gy = y0 + ya + (i - 1) * DIL, gx = x0 + xa + (i - 1) * DIL;
-        if (gy >= 0 && gy < g.H) tr_rowok |= 1u << i;
-        if (gx >= 0 && gx < g.W) tr_colok |= 1u << i;
+        for (int i = 0; i < PER; ++i) {
+          const int e = (dp0 + i) * 64 + lane;
+          const int row = e / DQ, q = e - row * DQ;
+          const int gy = y0 - DIL + row, gx = x0 - PA + 4 * q;
+          if (i < dpn && e < GROUPS && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) xf_mask |= 1u << i;
+        }
       }
-      if (tid < 32) {   // read after the next barrier; the tile two back used this half
-        float *sc_t = scsh + (tr_round & 1) * 64;
-        const int grp = tid >> 3;
-        const float mean = in_stats[((size_t)n * 4 + grp) * 2 + 0];
-        const float rstd = in_stats[((size_t)n * 4 + grp) * 2 + 1];
-        const float sc = rstd * in_gamma[tid];
-        sc_t[tid] = sc;
-        sc_t[32 + tid] = in_beta[tid] - mean * sc;
+      const int c = xf_chunk * (KS * 4) + dch;   // wave-uniform: scalar loads
+      if (c < g.cin) {
+        const float mean = in_stats[((size_t)n * 4 + (c >> 3)) * 2 + 0];
+        const float rstd = in_stats[((size_t)n * 4 + (c >> 3)) * 2 + 1];
+        xf_sc = rstd * in_gamma[c];
+        xf_sh = in_beta[c] - mean * xf_sc;
+      } else {
+        xf_on = false;
       }
     }
   };
+  auto xf_apply = [&]() {          // ... applied to this wave's landed pieces; then the side moves on one step
+    if constexpr (MODE == 1) {
+      if (xf_on) {
+        float *dst = smem + xf_stage * STAGE + dch * RCST + lane * 4;
+#pragma unroll
+        for (int i = 0; i < PER; ++i)
+          if ((xf_mask >> i) & 1u) {
+            floatx4 v = *reinterpret_cast<floatx4 *>(dst + (dp0 + i) * 256);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = lrelu02(v[r] * xf_sc + xf_sh);
+            *reinterpret_cast<floatx4 *>(dst + (dp0 + i) * 256) = v;
+          }
+      }
+      xf_stage = xf_stage + 1 == NSTAGE ? 0 : xf_stage + 1;
+      if (++xf_chunk == nsteps) xf_chunk = 0, ++xf_round;
+    }
+  };
+
+  // ---- transform side: runs one step ahead of the multiplies (its tile may already be the next one)
+  int tr_round = 0, tr_chunk = 0, tr_stage = 0;
+  auto tr_setup = [&]() {};   // (nothing per tile on this side: MODE 1 is applied in LDS by the fetching wave)
   // the 4 x 4 patch of (channel kc, patch pcol of patch row wave) of the transform side's step, transformed:
   // the result IS the A fragment of the 16 coefficient GEMMs
   auto tr_load = [&](float (&d)[KS][4][4]) {
@@ -276,25 +306,6 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   auto tr_finish = [&](float (&d)[KS][4][4], float (&v)[KS][16]) {
 #pragma unroll
     for (int h = 0; h < KS; ++h) {
-      if constexpr (MODE == 1) {
-        const float *sc_t = scsh + (tr_round & 1) * 64;
-        const int c = (tr_chunk * KS + h) * 4 + kc;
-        const bool cok = c < g.cin;
-        const float sc = sc_t[cok ? c : 0], sh = sc_t[32 + (cok ? c : 0)];
-        if (__builtin_amdgcn_read_exec() == __builtin_amdgcn_ballot_w64(cok && tr_rowok == 15u && tr_colok == 15u)) {
-          // interior patches in every lane (the usual case): no padding to keep at zero
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) d[h][i][j] = lrelu02(d[h][i][j] * sc + sh);
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              d[h][i][j] = (cok && ((tr_rowok >> i) & 1u) && ((tr_colok >> j) & 1u)) ? lrelu02(d[h][i][j] * sc + sh) : 0.0f;
-        }
-      }
       float t[4][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -323,8 +334,11 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   float v[KS][16];
   if (total_steps > 0) {
     tr_setup();
+    xf_prepare();
     wait_landed(total_steps - 1 < NSTAGE - 1 ? total_steps - 1 : NSTAGE - 1);
-    __syncthreads();   // step 0 (and U, and the first tile's scale/shift) visible to everyone
+    xf_apply();        // step 0
+    xf_prepare();      // step 1
+    __syncthreads();   // step 0 (and U) visible to everyone
     float d0[KS][4][4];
     tr_load(d0);
     tr_finish(d0, v);
@@ -346,9 +360,11 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       if (has_next) {
         const int rest = total_steps - (step + 2);     // steps issued after step + 1 so far
         wait_landed(rest < 0 ? 0 : (rest < NSTAGE - 2 ? rest : NSTAGE - 2));   // step + 1 has landed
+        xf_apply();        // step + 1
         WN_STAMP();   // landed
-        __syncthreads();   // ... for everyone; everyone has read the raw tile of `step`; next tile's scale/shift visible
+        __syncthreads();   // ... for everyone; everyone has read the raw tile of `step`
         WN_STAMP();   // barrier
+        xf_prepare();      // step + 2: its scalar loads travel behind this step's multiplies
       }
       // multiplies of `step` with the transform of `step + 1` slotted between them
       float dn[KS][4][4];

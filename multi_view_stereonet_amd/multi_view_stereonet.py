@@ -100,9 +100,8 @@ class PlaneSweepEngine:
         self.conv_precision = "fp32"
         # Winograd F(2x2,3x3) form of the 2-D 3x3 dilation-1 layers (fp32 throughout, 2.25x fewer multiplies).
         self.winograd = True
-        # ... but not where the previous layer's LeakyReLU(GN(.)) is applied on load: there the extra VALU work
-        # in the transform makes it slower than the direct kernel (2.9 vs 2.65 ms at level 0).
-        self.winograd_with_input_transform = False
+        # ... also where the previous layer's LeakyReLU(GN(.)) is applied on load (in LDS, by the fetching wave)
+        self.winograd_with_input_transform = True
         # Skip the stand-alone normalise/activate pass at both ends of a refiner tower (see
         # residual_tower_unfused); False keeps one pass per block (tests compare the two).
         self.trim_tower_ends = True

@@ -184,9 +184,7 @@ def test_conv_winograd_form(cin, rows, cols, n, dil):
             weight, bias = gamma.to(DEV), beta.to(DEV)
         xg = x.reshape(n, 4, -1).double()
         st_in = torch.stack([xg.mean(2), 1.0 / (xg.var(2, unbiased=False) + 1e-5).sqrt()], 2).float().contiguous()
-        eng.winograd_with_input_transform = True
         out2, _ = eng.conv(c, x.to(DEV), in_stats=st_in.to(DEV), in_norm=_Norm(P))
-        eng.winograd_with_input_transform = False
         ref2 = F.conv2d(F.leaky_relu(F.group_norm(x, 4, gamma, beta, 1e-5), 0.2), w, b, padding=dil, dilation=dil)
         close(out2, ref2, rtol=1e-4, atol=2e-4)
 
