@@ -688,3 +688,21 @@ def test_forward_vs_oracle_small_batch():
         assert mean_rel < 2e-4 and max_rel < 2e-3, (lvl, mean_rel, max_rel)
         diff = int((out["left_idepthmap_mask_pyr"][lvl].cpu() != ref["left_idepthmap_mask_pyr"][lvl]).sum())
         assert diff <= 2 * 4 ** (4 - lvl), (lvl, diff)
+
+
+@pytest.mark.parametrize("rows,cols,S,D", [(250, 500, 1, 12), (131, 277, 2, 8), (72, 200, 1, 16)])
+def test_forward_ragged_sizes_vs_oracle(rows, cols, S, D):
+    """Sizes whose pyramid levels are not multiples of 4 / 16 / 32: the layers fall back from the LDS-DMA,
+    Winograd and tap-GEMM kernels to the register-staged ones level by level; the result must not care."""
+    wname = "gta_sfm_150epochs"
+    w = load_weights(wname)
+    batch = synthetic.make_batch(rows, cols, S, batch=2, seed=rows + cols, pose_jitter=0.2, smooth=True)
+    inp = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
+    ref = oracle.forward(w, inp["left_image_pyr"], inp["K_pyr"], inp["T_right_in_left"], inp["right_image_pyr"], D)
+    lp, kp, ts, rp = to_dev(inp)
+    out = net_for(wname)(lp, kp, ts, rp, D, True, [True] * 5)
+    for lvl in range(5):
+        got = out["left_idepthmap_pyr"][lvl].cpu()
+        assert got.shape == ref["left_idepthmap_pyr"][lvl].shape
+        mean_rel, max_rel = rel_err(got, ref["left_idepthmap_pyr"][lvl])
+        assert mean_rel < 2e-4 and max_rel < 3e-3, (lvl, mean_rel, max_rel)
