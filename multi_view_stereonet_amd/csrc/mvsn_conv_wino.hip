@@ -13,10 +13,10 @@
 //     loaded into LDS ONCE per workgroup and stay there while it walks its tiles -- streamed per chunk they
 //     were two thirds of the DMA instructions, and the CU's DMA issue rate (~1 piece per ~115 cycles), not the
 //     matrix pipe, set the pace;
-//   * the haloed raw tiles (18 rows x 40 columns from the aligned column x0 - 4, 4 channels per chunk = one MFMA
-//     k-step) arrive by LDS-DMA (16-byte pieces, 12 instructions per chunk per CU) in a three-stage ring that
-//     runs ahead across tile boundaries (a chunk is only 32 MFMAs per wave, shorter than a DMA round trip);
-//     one barrier per chunk;
+//   * the haloed raw tiles (dilation 1: 18 rows x 40 columns from the aligned column x0 - 4) arrive by LDS-DMA
+//     (16-byte pieces, 12 instructions per 4-channel chunk per CU) in a 3-6 stage ring that runs ahead across tile
+//     boundaries (a chunk is only 32 MFMAs per wave, shorter than a DMA round trip); one barrier per step of one
+//     or two chunks (template KS);
 //   * wave w owns patch row w (16 patches) and both cout tiles.  Lane (k = lane>>4, p = lane&15) reads the 4 x 4
 //     input patch p of channel k from the raw tile and transforms it in registers (B^T d B: 32 adds): the 16
 //     coefficients it ends up with are exactly its A-fragment values (A = V_xi: 16 patches x 4 cins), so the
@@ -45,7 +45,6 @@ constexpr int wn_pieces(int dil) { return (wn_groups(dil) + 63) / 64; }    // DM
 constexpr int wn_rcst(int dil) { return wn_hy(dil) * wn_xs(dil) + 16; }    // raw channel stride (floats)
 constexpr int WN_UFLOATS = 16 * 128;                   // U fragments per chunk: [xi][cout tile][lane]
 constexpr int WN_MAX_CHUNKS = 8;                       // resident U: up to 32 input channels (64 KB)
-constexpr float WN_EPS = 1e-5f;
 
 __device__ floatx4 g_wn_zero16 = {0.f, 0.f, 0.f, 0.f};
 #define WN_GPTR(p) ((const __attribute__((address_space(1))) void *)(p))
@@ -112,7 +111,6 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   constexpr int RCST = wn_rcst(DIL);
   constexpr int STAGE = KS * 4 * RCST;               // ring stage (floats)
   float *U = smem + NSTAGE * STAGE;                  // nchunks * WN_UFLOATS, resident
-  float *scsh = U + g.nchunks * WN_UFLOATS;          // 2 x (32 scale + 32 shift): double-buffered per tile
   const int nsteps = (g.nchunks + KS - 1) / KS;      // steps per tile
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -531,7 +529,7 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   const bool head = g.nchunks == 1;
   const int ks = (head || g.dil == 8) ? 1 : 2;
   const int nstage = head ? 6 : (g.dil == 1 ? 4 : 3);
-  const size_t lds = ((size_t)nstage * ks * 4 * wn_rcst(g.dil) + (size_t)g.nchunks * WN_UFLOATS + 128) * sizeof(float);
+  const size_t lds = ((size_t)nstage * ks * 4 * wn_rcst(g.dil) + (size_t)g.nchunks * WN_UFLOATS) * sizeof(float);
   if (head && g.dil != 1) {
     set_error("mvsn_conv_forward(winograd): dilated 4-channel layers are not instantiated");
     return MVSN_E_BADARG;
