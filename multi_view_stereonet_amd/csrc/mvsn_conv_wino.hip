@@ -44,7 +44,7 @@ constexpr int wn_groups(int dil) { return wn_hy(dil) * (wn_xs(dil) / 4); } // 16
 constexpr int wn_pieces(int dil) { return (wn_groups(dil) + 63) / 64; }    // DMA instructions per channel
 constexpr int wn_rcst(int dil) { return wn_hy(dil) * wn_xs(dil) + 16; }    // raw channel stride (floats)
 constexpr int WN_UFLOATS = 16 * 128;                   // U fragments per chunk: [xi][cout tile][lane]
-constexpr int WN_MAX_CHUNKS = 8;                       // resident U: up to 32 input channels (64 KB)
+constexpr int WN_MAX_CHUNKS = 9;                       // resident U: up to 36 input channels (72 KB)
 
 __device__ floatx4 g_wn_zero16 = {0.f, 0.f, 0.f, 0.f};
 #define WN_GPTR(p) ((const __attribute__((address_space(1))) void *)(p))
@@ -499,6 +499,8 @@ bool wino_geom(const mvsn_conv_desc *d, WinoGeom *g) {
   g->tiles = g->nty * g->ntx;
   g->nchunks = (d->c_in + 3) / 4;
   if (g->nchunks > WN_MAX_CHUNKS) return false;   // U must stay resident in LDS
+  if (g->nchunks > 8 && d->dilation > 2) return false;   // ... next to the (larger) raw-tile ring of dilation 4 / 8
+  if (g->nchunks == 1 && d->dilation != 1) return false;  // dilated 4-channel layers are not instantiated
   g->packed_floats = (size_t)g->nchunks * WN_UFLOATS;
   return true;
 }
@@ -528,11 +530,15 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   //   dilation 1: 2 k-steps x 4 stages (94 KB); 2, 4: 2 x 3 (78 / 94 KB); 8: 1 x 3 (74 KB); 4-channel head: 1 x 6
   const bool head = g.nchunks == 1;
   const int ks = (head || g.dil == 8) ? 1 : 2;
-  const int nstage = head ? 6 : (g.dil == 1 ? 4 : 3);
+  const int nstage = head ? 6 : ((g.dil == 1 && g.nchunks <= 8) ? 4 : 3);
   const size_t lds = ((size_t)nstage * ks * 4 * wn_rcst(g.dil) + (size_t)g.nchunks * WN_UFLOATS) * sizeof(float);
   if (head && g.dil != 1) {
     set_error("mvsn_conv_forward(winograd): dilated 4-channel layers are not instantiated");
     return MVSN_E_BADARG;
+  }
+  if (lds > 160 * 1024) {
+    set_error("mvsn_conv_forward(winograd): %zu bytes of LDS needed", lds);
+    return MVSN_E_TOOLARGE;
   }
   dim3 grid(1);
 #define WN_CASE(M, K, N, D)                                                                                        \
@@ -554,6 +560,7 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   grid = dim3((unsigned)(total < cus ? total : cus));   // persistent: one workgroup per CU walks items grid-strided
   const bool xf = in_stats != nullptr;
   if (head) { if (xf) WN_CASE(1, 1, 6, 1); else WN_CASE(0, 1, 6, 1); }
+  else if (g.dil == 1 && g.nchunks > 8) { if (xf) WN_CASE(1, 2, 3, 1); else WN_CASE(0, 2, 3, 1); }
   else if (g.dil == 1) { if (xf) WN_CASE(1, 2, 4, 1); else WN_CASE(0, 2, 4, 1); }
   else if (g.dil == 2) { if (xf) WN_CASE(1, 2, 3, 2); else WN_CASE(0, 2, 3, 2); }
   else if (g.dil == 4) { if (xf) WN_CASE(1, 2, 3, 4); else WN_CASE(0, 2, 3, 4); }
