@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("MVSN_BENCH_LANES", "1")),
                     help="batch slices run on separate HIP streams (images are independent)")
     ap.add_argument("--fold", action="store_true", help="fold residual blocks into the next conv's tile load")
-    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default=os.environ.get("MVSN_BENCH_PRECISION", "fp32"),
+    ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16"], default=os.environ.get("MVSN_BENCH_PRECISION", "fp32"),
                     help="arithmetic of the 32->32 3x3 layers: exact fp32 MFMA, or the 3 x bf16 split tier")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -219,30 +219,37 @@ def main():
             line["kernel_ms_per_step"] = {k: round(v["ms"], 3) for k, v in
                                           sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]}
             if args.precision == "fp32":
-                # the 3 x bf16 split tier (fp32-equivalent arithmetic on the bf16 matrix cores, BASELINE.md
-                # section 2) on the same resident inputs: reported beside the exact-fp32 headline, never as it
+                # the two bf16-matrix-core tiers on the same resident inputs, reported beside the fp32 headline, never
+                # as it: the 3 x bf16 split (fp32-equivalent arithmetic) and plain bf16 operands
+                # (BASELINE config 5's speed tier -- outside the 1e-3 parity contract, its error is reported)
                 eng = net.engine()
-                eng.conv_precision = "bf16x3"
-                for _ in range(max(1, args.warmup)):
-                    out_t = run_forward(net, inp)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    out_t = run_forward(net, inp)
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t1
-                got_t = out_t["left_idepthmap_pyr"][0][:1].cpu()
-                l1_t = float((got_t - ref0).abs().mean())
-                agg_t = kernel_breakdown(net, inp)
-                name_t, dom_t = max(agg_t.items(), key=lambda kv: kv[1]["ms"])
-                line["bf16x3_split_tier"] = {
-                    "value": B * args.steps / dt, "unit": "depthmaps/s", "ms_per_step": dt / args.steps * 1e3,
-                    "dtype": "3 x bf16 split (hi+lo operands, fp32 accumulate) on the 32->32 3x3 layers, f32 elsewhere",
-                    "l1_vs_ref": {"l1": l1_t, "mean_rel": l1_t / float(ref0.abs().mean()),
-                                  "max_rel": float((got_t - ref0).abs().max() / ref0.abs().max())},
-                    "dominant_kernel": name_t, "dominant_kernel_ms": round(dom_t["ms"], 3),
-                    "kernel_ms_per_step": {k: round(v["ms"], 3) for k, v in
-                                           sorted(agg_t.items(), key=lambda kv: -kv[1]["ms"])[:6]}}
+                for tier, key, dtype in (
+                        ("bf16x3", "bf16x3_split_tier",
+                         "3 x bf16 split (hi+lo operands, fp32 accumulate) on the 32->32 3x3 layers, f32 elsewhere"),
+                        ("bf16", "bf16_operand_tier",
+                         "bf16 operands, fp32 accumulate on the 32->32 3x3 layers (regulariser + refiner blocks), f32 "
+                         "elsewhere; NOT within the 1e-3 parity contract")):
+                    eng.conv_precision = tier
+                    for _ in range(max(1, args.warmup)):
+                        out_t = run_forward(net, inp)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(args.steps):
+                        out_t = run_forward(net, inp)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t1
+                    got_t = out_t["left_idepthmap_pyr"][0][:1].cpu()
+                    l1_t = float((got_t - ref0).abs().mean())
+                    agg_t = kernel_breakdown(net, inp)
+                    name_t, dom_t = max(agg_t.items(), key=lambda kv: kv[1]["ms"])
+                    line[key] = {
+                        "value": B * args.steps / dt, "unit": "depthmaps/s", "ms_per_step": dt / args.steps * 1e3,
+                        "dtype": dtype,
+                        "l1_vs_ref": {"l1": l1_t, "mean_rel": l1_t / float(ref0.abs().mean()),
+                                      "max_rel": float((got_t - ref0).abs().max() / ref0.abs().max())},
+                        "dominant_kernel": name_t, "dominant_kernel_ms": round(dom_t["ms"], 3),
+                        "kernel_ms_per_step": {k: round(v["ms"], 3) for k, v in
+                                               sorted(agg_t.items(), key=lambda kv: -kv[1]["ms"])[:6]}}
                 eng.conv_precision = "fp32"
             if not args.no_cpu_baseline:
                 cb, ref_out = cpu_baseline()

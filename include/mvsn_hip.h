@@ -138,10 +138,14 @@ typedef struct {
  *                     products per 2x2 outputs and (cin, cout) pair instead of 36; every operand and
  *                     accumulation is fp32, the result differs from MVSN_CONV_FP32 by rounding only (~1e-6
  *                     relative).  Only 2-D 3x3 stride-1 dilation-1 layers with 32 output channels and
- *                     cols % 4 == 0 (mvsn_conv_winograd_supported); weights are packed per form. */
+ *                     cols % 4 == 0 (mvsn_conv_winograd_supported); weights are packed per form.
+ *   MVSN_CONV_BF16    plain bf16 operands (the hi halves only), fp32 accumulation, on the same kernels and packed
+ *                     weights as MVSN_CONV_BF16X3: BASELINE config 5's speed tier.  ~2^-9 relative per operand:
+ *                     the final depth lands OUTSIDE the 1e-3 parity contract (measured ~2e-3 mean-rel). */
 #define MVSN_CONV_FP32 0
 #define MVSN_CONV_BF16X3 1
 #define MVSN_CONV_FP32_WINO 2
+#define MVSN_CONV_BF16 3
 int mvsn_conv_bf16x3_supported(const mvsn_conv_desc *desc);
 int mvsn_conv_winograd_supported(const mvsn_conv_desc *desc);
 

@@ -21,7 +21,7 @@ class ConvDesc(Structure):
                 ("dilation", c_int), ("precision", c_int)]
 
 
-CONV_FP32, CONV_BF16X3, CONV_FP32_WINO = 0, 1, 2
+CONV_FP32, CONV_BF16X3, CONV_FP32_WINO, CONV_BF16 = 0, 1, 2, 3
 
 
 # name -> (restype, argtypes); mirrors include/mvsn_hip.h one to one

@@ -800,7 +800,7 @@ extern "C" size_t mvsn_conv_packed_floats(const mvsn_conv_desc *desc) {
     mvsn::WinoGeom wg;
     return mvsn::wino_geom(desc, &wg) ? wg.packed_floats : 0;
   }
-  if (desc && desc->precision == MVSN_CONV_BF16X3) {
+  if (desc && (desc->precision == MVSN_CONV_BF16X3 || desc->precision == MVSN_CONV_BF16)) {
     mvsn::Bf16x3Geom bg;
     return mvsn::bf16x3_geom(desc, &bg) ? (size_t)desc->kd * 9 * 1024 : 0;   // [tap][2][2][64][8] bf16
   }
@@ -815,7 +815,7 @@ extern "C" int mvsn_conv_num_tiles(const mvsn_conv_desc *desc) {
     mvsn::WinoGeom wg;
     return mvsn::wino_geom(desc, &wg) ? wg.tiles * 8 : 0;   // 8 waves per workgroup tile
   }
-  if (desc && desc->precision == MVSN_CONV_BF16X3) {
+  if (desc && (desc->precision == MVSN_CONV_BF16X3 || desc->precision == MVSN_CONV_BF16)) {
     mvsn::Bf16x3Geom bg;
     return mvsn::bf16x3_geom(desc, &bg) ? bg.tiles * 4 : 0;
   }
@@ -832,7 +832,7 @@ extern "C" int mvsn_conv_pack_weights(const mvsn_conv_desc *desc, const float *w
     MVSN_REQUIRE(mvsn::wino_geom(desc, &wg), MVSN_E_BADARG, "mvsn_conv_pack_weights: layer has no Winograd form");
     return mvsn::wino_pack(desc, weight, packed, (hipStream_t)stream);
   }
-  if (desc && desc->precision == MVSN_CONV_BF16X3) {
+  if (desc && (desc->precision == MVSN_CONV_BF16X3 || desc->precision == MVSN_CONV_BF16)) {
     mvsn::Bf16x3Geom bg;
     MVSN_REQUIRE(mvsn::bf16x3_geom(desc, &bg), MVSN_E_BADARG, "mvsn_conv_pack_weights: layer has no bf16x3 form");
     return mvsn::bf16x3_pack(desc, weight, packed, (hipStream_t)stream);
@@ -861,7 +861,7 @@ extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, co
     return wino_launch(wg, in, weight_packed, bias, in_stats, in_gamma, in_beta, out, out_partials,
                        (hipStream_t)stream);
   }
-  if (desc && desc->precision == MVSN_CONV_BF16X3) {
+  if (desc && (desc->precision == MVSN_CONV_BF16X3 || desc->precision == MVSN_CONV_BF16)) {
     Bf16x3Geom bg;
     MVSN_REQUIRE(bf16x3_geom(desc, &bg), MVSN_E_BADARG, "mvsn_conv_forward: layer has no bf16x3 form");
     MVSN_REQUIRE(!in_residual && !out_staged, MVSN_E_BADARG, "mvsn_conv_forward: bf16x3 has no residual folding");

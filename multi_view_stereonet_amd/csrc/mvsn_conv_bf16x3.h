@@ -9,6 +9,7 @@ namespace mvsn {
 
 struct Bf16x3Geom {
   int n, D, H, W, dil, kd;
+  int nprod;            // 3: hi/lo split products (fp32-equivalent); 1: plain bf16 operands
   int tzo, ty;          // output planes / rows per workgroup (32 columns)
   int HY, HX;           // staged plane tile
   int ntz, nty, ntx, tiles;

@@ -61,7 +61,9 @@ __global__ void conv_bf16x3_pack_kernel(const float *__restrict__ w, int ntaps, 
 // are fetched into registers while the MFMAs of stage s run, then converted to hi/lo bf16 records and
 // written to the single LDS plane between two barriers.
 // DIL  dilation as a compile-time constant: the tap offsets become ds_read immediates (no address VALU)
-template <int KD, int TZO, int TY, int TPW, int NIT, int MODE, int DIL>
+// NPROD  3: a*b ~= ah*bh + ah*bl + al*bh (fp32-equivalent split); 1: ah*bh only = plain bf16 operands with fp32
+//        accumulation (MVSN_CONV_BF16: BASELINE config 5's speed tier, outside the 1e-3 parity contract)
+template <int KD, int TZO, int TY, int TPW, int NIT, int MODE, int DIL, int NPROD>
 __global__ __launch_bounds__(BX_THREADS, 2) void conv_bf16x3_kernel(Bf16x3Geom g, const float *__restrict__ in,
                                                                     const uintx4 *__restrict__ wpk,
                                                                     const float *__restrict__ bias,
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(BX_THREADS, 2) void conv_bf16x3_kernel(Bf16x3Geom g
     for (int k = 0; k < 9; ++k) {
       const uintx4 *wt = wpk + (size_t)(tz * 9 + k) * 256 + tw * 128 + lane;  // [tap][t][part][lane]
       wh[k] = __builtin_bit_cast(bf16x8, wt[0]);
-      wl[k] = __builtin_bit_cast(bf16x8, wt[64]);
+      if (NPROD == 3) wl[k] = __builtin_bit_cast(bf16x8, wt[64]);
     }
     slab_tz = tz;
   };
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(BX_THREADS, 2) void conv_bf16x3_kernel(Bf16x3Geom g
         const int toff = ((tap / 3) * DIL * HX + (tap % 3) * DIL) * BX_REC;   // compile-time: a ds_read immediate
         const unsigned int *rec = plane + prec[j] + toff;
         h = *reinterpret_cast<const uintx4 *>(rec);
-        l = *reinterpret_cast<const uintx4 *>(rec + 16);
+        if (NPROD == 3) l = *reinterpret_cast<const uintx4 *>(rec + 16);
       };
       frag(0, fh[0][0], fl[0][0]);
       frag(1, fh[0][1], fl[0][1]);
@@ -347,10 +349,12 @@ __global__ __launch_bounds__(BX_THREADS, 2) void conv_bf16x3_kernel(Bf16x3Geom g
         const bf16x8 ah = wh[tap], al = wl[tap];
         const bf16x8 bh0 = __builtin_bit_cast(bf16x8, fh[cur][0]), bl0 = __builtin_bit_cast(bf16x8, fl[cur][0]);
         const bf16x8 bh1 = __builtin_bit_cast(bf16x8, fh[cur][1]), bl1 = __builtin_bit_cast(bf16x8, fl[cur][1]);
-        acc[zo][j0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh0, acc[zo][j0], 0, 0, 0);
-        acc[zo][j1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh1, acc[zo][j1], 0, 0, 0);
-        acc[zo][j0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl0, acc[zo][j0], 0, 0, 0);
-        acc[zo][j1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl1, acc[zo][j1], 0, 0, 0);
+        if constexpr (NPROD == 3) {
+          acc[zo][j0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh0, acc[zo][j0], 0, 0, 0);
+          acc[zo][j1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh1, acc[zo][j1], 0, 0, 0);
+          acc[zo][j0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl0, acc[zo][j0], 0, 0, 0);
+          acc[zo][j1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl1, acc[zo][j1], 0, 0, 0);
+        }
         acc[zo][j0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh0, acc[zo][j0], 0, 0, 0);
         acc[zo][j1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh1, acc[zo][j1], 0, 0, 0);
       }
@@ -393,6 +397,7 @@ bool bf16x3_geom(const mvsn_conv_desc *d, Bf16x3Geom *g) {
   if (!d || d->c_in != 32 || d->c_out != 32 || d->stride != 1 || d->kh != 3 || d->kw != 3) return false;
   if (!(d->kd == 1 || d->kd == 3) || (d->kd == 1 && d->depth != 1) || d->dilation < 1) return false;
   g->n = d->n, g->D = d->depth, g->H = d->rows, g->W = d->cols, g->dil = d->dilation, g->kd = d->kd;
+  g->nprod = d->precision == MVSN_CONV_BF16 ? 1 : 3;
   g->tzo = d->kd == 3 ? 4 : 1;
   g->ty = 4;
   g->HY = g->ty + 2 * g->dil;
@@ -437,13 +442,18 @@ int bf16x3_launch(const Bf16x3Geom &g, const float *in, const void *wpk, const f
   static unsigned long long *dbgp = getenv("MVSN_BX_DEBUG_PTR") ? (unsigned long long *)strtoull(getenv("MVSN_BX_DEBUG_PTR"), nullptr, 0) : nullptr;
   constexpr int TPW2D = 8;
   const dim3 grid(g.kd == 3 ? g.tiles : (g.tiles + TPW2D - 1) / TPW2D, g.n);
+#define MVSN_BX_BOTH(...)                                                         \
+  do {                                                                            \
+    if (g.nprod == 3) MVSN_BX_LAUNCH(__VA_ARGS__, 3); else MVSN_BX_LAUNCH(__VA_ARGS__, 1); \
+  } while (0)
   if (g.kd == 3) {          // TZO 4, TY 4: 6 x 34 positions -> 816 items -> 4 per thread
-    if (xf) MVSN_BX_LAUNCH(3, 4, 4, 1, 4, 1, 1); else MVSN_BX_LAUNCH(3, 4, 4, 1, 4, 0, 1);
+    if (xf) MVSN_BX_BOTH(3, 4, 4, 1, 4, 1, 1); else MVSN_BX_BOTH(3, 4, 4, 1, 4, 0, 1);
   } else if (g.dil == 1) {  // TY 4: 6 x 34 -> 816 items -> 4 per thread
-    if (xf) MVSN_BX_LAUNCH(1, 1, 4, TPW2D, 4, 1, 1); else MVSN_BX_LAUNCH(1, 1, 4, TPW2D, 4, 0, 1);
+    if (xf) MVSN_BX_BOTH(1, 1, 4, TPW2D, 4, 1, 1); else MVSN_BX_BOTH(1, 1, 4, TPW2D, 4, 0, 1);
   } else {                  // dilation 2: 8 x 36 -> 1152 items -> 5 per thread
-    if (xf) MVSN_BX_LAUNCH(1, 1, 4, TPW2D, 5, 1, 2); else MVSN_BX_LAUNCH(1, 1, 4, TPW2D, 5, 0, 2);
+    if (xf) MVSN_BX_BOTH(1, 1, 4, TPW2D, 5, 1, 2); else MVSN_BX_BOTH(1, 1, 4, TPW2D, 5, 0, 2);
   }
+#undef MVSN_BX_BOTH
 #undef MVSN_BX_LAUNCH
   return check_launch("mvsn_conv_forward(bf16x3)");
 }

@@ -96,7 +96,8 @@ class PlaneSweepEngine:
         # 3 % slower end to end (the doubled staging loads are exposed), so it is off by default.
         self.fold_residual_blocks = False
         # Arithmetic of the 32 -> 32 channel 3x3 / 3x3x3 layers: "fp32" = exact fp32 MFMA;
-        # "bf16x3" = 3 x bf16 split on the bf16 matrix cores (fp32-equivalent to ~2^-16 per product).
+        # "bf16x3" = 3 x bf16 split on the bf16 matrix cores (fp32-equivalent to ~2^-16 per product);
+        # "bf16" = plain bf16 operands on the same kernels (BASELINE config 5's speed tier, outside the 1e-3 contract).
         self.conv_precision = "fp32"
         # Winograd F(2x2,3x3) form of the 2-D 3x3 dilation-1 layers (fp32 throughout, 2.25x fewer multiplies).
         self.winograd = True
@@ -161,8 +162,10 @@ class PlaneSweepEngine:
         rows, cols = x.shape[-2], x.shape[-1]
         d = c.desc(n, depth, rows, cols)
         packed = c.packed
-        if self.conv_precision == "bf16x3" and c.packed_bx is not None and in_residual is None and not write_staged:
-            dbx = c.desc(n, depth, rows, cols, _native.CONV_BF16X3)
+        if self.conv_precision in ("bf16x3", "bf16") and c.packed_bx is not None and in_residual is None and \
+                not write_staged:
+            dbx = c.desc(n, depth, rows, cols,
+                         _native.CONV_BF16X3 if self.conv_precision == "bf16x3" else _native.CONV_BF16)
             if lib.mvsn_conv_bf16x3_supported(ctypes.byref(dbx)):
                 d, packed = dbx, c.packed_bx
         elif self.winograd and c.packed_wino is not None and in_residual is None and not write_staged and \
@@ -182,6 +185,7 @@ class PlaneSweepEngine:
         tag = (f"conv{c.dims}d k{c.kh}" + (f"s{c.stride}" if c.stride > 1 else "") +
                (f"d{c.dilation}" if c.dilation > 1 else "") + f" {c.cin}->{c.cout}" +
                (" bf16x3" if d.precision == _native.CONV_BF16X3 else "") +
+               (" bf16" if d.precision == _native.CONV_BF16 else "") +
                (" wino" if d.precision == _native.CONV_FP32_WINO else ""))
         nbytes = 4.0 * (x.numel() * (2 if in_residual is not None else 1) + out.numel() +
                         (staged.numel() if staged is not None else 0))
