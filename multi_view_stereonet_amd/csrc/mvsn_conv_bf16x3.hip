@@ -197,75 +197,76 @@ __global__ __launch_bounds__(BX_THREADS, 2) void conv_bf16x3_kernel(Bf16x3Geom g
 
   // Bias of this lane's four channels, read once: a global load inside the per-tile epilogue would make
   // its s_waitcnt (vmcnt retires in order) wait for the next stage's prefetch and the previous tile's stores.
-  float bias4[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) bias4[r] = bias ? bias[tw * 16 + (lane >> 4) * 4 + r] : 0.0f;
+  const float bias1 = bias ? bias[tw * 16 + (lane & 15)] : 0.0f;   // this lane's cout (D = pixels x couts)
 
   // bias, store, GroupNorm partials of one finished tile.  This wave holds channels tw*16 + cbase + r,
   // i.e. GroupNorm groups 2*tw + (lane >> 5); the tile's positions are split over the two `half` waves.
+  // The MFMAs run with A = activation records (16 pixels x 32 cins) and B = weights (32 cins x 16 couts), so
+  // D = pixels x couts: lane l holds, for cout tw*16 + (l & 15), the four consecutive pixels 4*(l>>4) + r of each
+  // pixel tile -- one 16-byte store per accumulator, no transpose.
   auto epilogue = [&](int tile) {
     int z0, y0, x0;
     origin(tile, z0, y0, x0);
-    const int cbase = (lane >> 4) * 4;
+    const int c = tw * 16 + (lane & 15);
     float s = 0.f;
     int cnt = 0;
+    int ovalid[TZO][NPT];
 #pragma unroll
     for (int zo = 0; zo < TZO; ++zo)
 #pragma unroll
       for (int j = 0; j < NPT; ++j) {
         const int pt = half * NPT + j;
-        const int oz = z0 + zo, oy = y0 + (pt >> 1), ox = x0 + (pt & 1) * 16 + (lane & 15);
-        const bool ok = oz < g.D && oy < g.H && ox < g.W;
-        if (ok) cnt += 1;
-        const size_t pos = (size_t)oz * in_plane + (size_t)oy * g.W + ox;
+        const int oz = z0 + zo, oy = y0 + (pt >> 1), ox4 = x0 + (pt & 1) * 16 + (lane >> 4) * 4;
+        const int nv = (oz < g.D && oy < g.H && ox4 < g.W) ? min(4, g.W - ox4) : 0;
+        ovalid[zo][j] = nv;
+        cnt += nv;
+        const size_t pos = (size_t)oz * in_plane + (size_t)oy * g.W + ox4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float v = acc[zo][j][r] + bias4[r];
-          acc[zo][j][r] = ok ? v : 0.0f;
-          if (ok) s += v;
+          const float v = acc[zo][j][r] + bias1;
+          acc[zo][j][r] = r < nv ? v : 0.0f;
+          if (r < nv) s += v;
         }
-        if ((g.W & 3) == 0) {   // 4 couts x 1 pixel -> 1 cout x 4 pixels, one 16-byte store
-          const floatx4 tv = quad_transpose(acc[zo][j], lane);
-          const int c = tw * 16 + cbase + (lane & 3);
-          if (ok) *reinterpret_cast<floatx4 *>(outn + (size_t)c * in_chan + (pos - (lane & 3))) = tv;
+        if ((g.W & 3) == 0) {   // the four pixels are all inside or all outside, and 16-byte aligned
+          if (nv == 4) *reinterpret_cast<floatx4 *>(outn + (size_t)c * in_chan + pos) = acc[zo][j];
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (ok) outn[(size_t)(tw * 16 + cbase + r) * in_chan + pos] = acc[zo][j][r];
+            if (r < nv) outn[(size_t)c * in_chan + pos + r] = acc[zo][j][r];
         }
       }
     if (out_partials == nullptr) return;
-    // Per-wave GroupNorm partials (count, mean, M2), reduced with shuffles only -- no LDS, no barrier.
-    // Record (tile, wave) holds this wave's two groups; the other two are written with count 0.
-    auto half_wave_sum = [&](float v) {
+    // Per-wave GroupNorm partials (count, mean, M2), reduced with shuffles only -- no LDS, no barrier.  The
+    // group of a lane's channel is tw*2 + ((l>>3)&1); record (tile, wave) holds this wave's two groups, the
+    // other two are written with count 0.
+    auto pixel_sum = [&](float v) {   // over the lanes holding the same cout: bits 4, 5
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      return v;
+    };
+    auto group_sum = [&](float v) {   // over the 8 couts of a group (bits 0-2) and all pixels
       v += __shfl_xor(v, 1, 64);
       v += __shfl_xor(v, 2, 64);
       v += __shfl_xor(v, 4, 64);
-      v += __shfl_xor(v, 8, 64);
-      v += __shfl_xor(v, 16, 64);
-      return v;
+      return pixel_sum(v);
     };
-    const int hi = lane >> 5;
-    const float npos_out = half_wave_sum((lane & 16) == 0 ? (float)cnt : 0.0f) * 8.0f;
-    s = half_wave_sum(s);
+    const int hi = (lane >> 3) & 1;
+    const float npos_out = pixel_sum((float)cnt) * 8.0f;
+    s = group_sum(s);
     const float m = npos_out > 0.0f ? s / npos_out : 0.0f;
     float q = 0.f;
 #pragma unroll
     for (int zo = 0; zo < TZO; ++zo)
 #pragma unroll
-      for (int j = 0; j < NPT; ++j) {
-        const int pt = half * NPT + j;
-        const bool ok = z0 + zo < g.D && y0 + (pt >> 1) < g.H && x0 + (pt & 1) * 16 + (lane & 15) < g.W;
-        if (ok) {
+      for (int j = 0; j < NPT; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 4; ++r)
+          if (r < ovalid[zo][j]) {
             const float dv = acc[zo][j][r] - m;
             q += dv * dv;
           }
-        }
-      }
-    q = half_wave_sum(q);
-    if ((lane & 31) == 0) {
+    q = group_sum(q);
+    if ((lane & 0x37) == 0) {   // lanes 0 and 8
       float *rec = out_partials + (((size_t)n * g.tiles + tile) * 4 + wave) * 12;
       float *mine = rec + (tw * 2 + hi) * 3, *other = rec + ((1 - tw) * 2 + hi) * 3;
       mine[0] = npos_out, mine[1] = m, mine[2] = q;
@@ -350,13 +351,13 @@ __global__ __launch_bounds__(BX_THREADS, 2) void conv_bf16x3_kernel(Bf16x3Geom g
         const bf16x8 bh0 = __builtin_bit_cast(bf16x8, fh[cur][0]), bl0 = __builtin_bit_cast(bf16x8, fl[cur][0]);
         const bf16x8 bh1 = __builtin_bit_cast(bf16x8, fh[cur][1]), bl1 = __builtin_bit_cast(bf16x8, fl[cur][1]);
         if constexpr (NPROD == 3) {
-          acc[zo][j0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh0, acc[zo][j0], 0, 0, 0);
-          acc[zo][j1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh1, acc[zo][j1], 0, 0, 0);
-          acc[zo][j0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl0, acc[zo][j0], 0, 0, 0);
-          acc[zo][j1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl1, acc[zo][j1], 0, 0, 0);
+          acc[zo][j0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh0, al, acc[zo][j0], 0, 0, 0);
+          acc[zo][j1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh1, al, acc[zo][j1], 0, 0, 0);
+          acc[zo][j0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl0, ah, acc[zo][j0], 0, 0, 0);
+          acc[zo][j1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl1, ah, acc[zo][j1], 0, 0, 0);
         }
-        acc[zo][j0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh0, acc[zo][j0], 0, 0, 0);
-        acc[zo][j1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh1, acc[zo][j1], 0, 0, 0);
+        acc[zo][j0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh0, ah, acc[zo][j0], 0, 0, 0);   // D = pixels x couts
+        acc[zo][j1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh1, ah, acc[zo][j1], 0, 0, 0);
       }
     }
     if (KD == 3 && !prefetched && next < NSTAGE) fetch(next);
