@@ -38,29 +38,6 @@ __device__ __forceinline__ floatx4 mfma16x16x4(float a, float b, floatx4 c) {
 
 __device__ __forceinline__ float lrelu02(float v) { return v > 0.0f ? v : 0.2f * v; }
 
-// 4x4 transpose across each aligned group of four lanes (two DPP quad-permute exchanges).
-// The MFMA accumulator gives a lane 4 consecutive couts of ONE pixel; after the transpose lane i of the
-// quad holds cout i of the quad's FOUR consecutive pixels, i.e. one 16-byte store per lane instead of
-// four scattered 4-byte ones (the conv epilogues are store-issue-bound otherwise).
-__device__ __forceinline__ float dpp_quad_xor1(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float dpp_quad_xor2(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-}
-__device__ __forceinline__ floatx4 quad_transpose(floatx4 v, int lane) {
-  const bool odd = lane & 1, hi = lane & 2;
-  float r = dpp_quad_xor1(odd ? v[0] : v[1]);
-  if (odd) v[0] = r; else v[1] = r;
-  r = dpp_quad_xor1(odd ? v[2] : v[3]);
-  if (odd) v[2] = r; else v[3] = r;
-  r = dpp_quad_xor2(hi ? v[0] : v[2]);
-  if (hi) v[0] = r; else v[2] = r;
-  r = dpp_quad_xor2(hi ? v[1] : v[3]);
-  if (hi) v[1] = r; else v[3] = r;
-  return v;
-}
-
 // Workgroup b is observed to run on XCD b % 8, each XCD with its own L2.  Neighbouring tiles share halo
 // rows, so hand each XCD a contiguous range of tiles instead of every 8th one (bijective for any tile
 // count; placement only affects speed, never results).
