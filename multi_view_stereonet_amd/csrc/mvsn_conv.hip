@@ -55,6 +55,8 @@ struct ConvGeom {
   int HZ, HY, HX, XS;   // staged extent and padded row stride
   int CST;              // channel stride in LDS (floats)
   int ipc;              // 64-element DMA runs per staged channel
+  int v4;               // register-staged kernel stages 16-byte groups from the aligned column x0 - 4 (3-D layers)
+  int xoff;             // ... column of tap (.,.,0) of output column 0 inside a staged row
   int ntz, nty, ntx, tiles;
   int ntaps, nchunks;
   int wfloats_chunk;    // ntaps * 2 cout-tiles * 64
@@ -98,6 +100,12 @@ static bool make_geom(const mvsn_conv_desc *d, ConvGeom *g) {
   g->HY = (g->TY - 1) * d->stride + d->dilation * (d->kh - 1) + 1;
   g->HX = (CV_TX - 1) * d->stride + d->dilation * (d->kw - 1) + 1;
   g->XS = g->HX;
+  g->v4 = (is3d && d->kd == 3 && d->stride == 1 && d->dilation == 1 && d->cols % 4 == 0) ? 1 : 0;
+  g->xoff = 0;
+  if (g->v4) {   // rows of 40 floats (10 groups of 16 bytes) starting at x0 - 4: one load / LDS write moves 4 elements
+    g->XS = CV_TX + 8;
+    g->xoff = 4 - g->pw;
+  }
   // channel stride: whole 64-element DMA runs (the last run may overshoot the tile and lands in the
   // slot's tail) + 16 so that CST = 16 (mod 32)
   g->ipc = (g->HZ * g->HY * g->XS + 63) / 64;
@@ -253,6 +261,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvGeom &g, floatx4 (&acc)[
   }
 }
 
+#ifdef MVSN_DMA_STAMPS   // tuning aid (tools/dma_phases.py): s_memtime stamps of one mid-launch wave
+__device__ unsigned long long *g_dma_stamps = nullptr;
+#define DMA_STAMP() do { if (dbg && dbg_i < 60) dbg[dbg_i++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DMA_STAMP() do { } while (0)
+#endif
+
+#ifdef MVSN_DMA_STAMPS   // register-staged kernel: per-phase totals of one workgroup's thread 0, kept in LDS
+#define MFMA_PHASE(k) do { if (stamped) { const unsigned long long now_ = __builtin_readcyclecounter(); ph_lds[k] += now_ - ph_last; ph_last = now_; } } while (0)
+#else
+#define MFMA_PHASE(k) do { } while (0)
+#endif
+
 // NPT   pixel tiles (16 output columns each) per wave = TZ*TY*2/4
 // KD/KH/KW/STRIDE compile-time so the tap loops unroll completely and LDS reads run ahead of the MFMAs
 // SE    staged input elements per thread per channel (upper bound, ceil(HZ*HY*HX/256))
@@ -265,7 +286,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvGeom &g, floatx4 (&acc)[
 //       block folded into the load);
 //       with out_staged != null every workgroup also writes the staged values of its own output
 //       positions, so the block's output tensor is produced as a by-product (stride 1 only).
-template <int NPT, int KD, int KH, int KW, int STRIDE, int SE, int CT, bool RES>
+// V4    (3-D layers, cols % 4 == 0) the tile is staged as 16-byte groups: a third of the loads and LDS writes
+template <int NPT, int KD, int KH, int KW, int STRIDE, int SE, int CT, bool RES, bool V4 = false>
 __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, const float *__restrict__ in,
                                                                   const float *__restrict__ wpk,
                                                                   const float *__restrict__ bias,
@@ -302,19 +324,27 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
     const int pt = wave * NPT + j;
     const int xt = pt & 1, zz = fdiv(pt >> 1, g.fd_ty), yy = (pt >> 1) - zz * g.TY;
     const int xx = xt * 16 + (lane & 15);
-    lpos[j] = (zz * g.HY + yy * STRIDE) * g.XS + xx * STRIDE + (lane >> 4) * g.CST;
+    lpos[j] = (zz * g.HY + yy * STRIDE) * g.XS + xx * STRIDE + g.xoff + (lane >> 4) * g.CST;
   }
 
-  // staging plan: element e = tid + k*256 of the HZ x HY x HX chunk tile (same for every channel)
+  // staging plan: element e = tid + k*256 of the HZ x HY x HX chunk tile (same for every channel); V4: 16-byte
+  // group e of the HZ x HY x 10 groups (columns x0 - 4 + 4q .. + 3: all inside or all outside the image)
   int goff[SE];
   unsigned interior = 0;  // bit k: staged element k is one of this workgroup's own output positions
-  const int tile_elems = g.HZ * g.HY * g.HX;
+  const int tile_elems = V4 ? g.HZ * g.HY * (g.XS / 4) : g.HZ * g.HY * g.HX;
 #pragma unroll
   for (int k = 0; k < SE; ++k) {
     const int e = tid + k * CV_THREADS;
     int off = -2;  // -2: beyond the tile, -1: zero padding
     if (e < tile_elems) {
-      const int row = fdiv(e, g.fd_hx), x = e - row * g.HX;
+      int row, x;
+      if constexpr (V4) {
+        row = e / 10;
+        x = (e - row * 10) * 4 - 4 + g.pw;   // so that gx0 + x = x0 - 4 + 4q
+      } else {
+        row = fdiv(e, g.fd_hx);
+        x = e - row * g.HX;
+      }
       const int z = fdiv(row, g.fd_hy), y = row - z * g.HY;
       const int gz = gz0 + z, gy = gy0 + y, gx = gx0 + x;
       off = (gz >= 0 && gz < g.D && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) ? (gz * g.H + gy) * g.W + gx : -1;
@@ -343,7 +373,9 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
 #pragma unroll
     for (int t = 0; t < CT; ++t) acc[j][t] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  float sreg[CV_CK][SE];
+  static_assert(!(V4 && RES), "the 16-byte staging path has no residual folding");
+  float sreg[V4 ? 1 : CV_CK][V4 ? 1 : SE];
+  floatx4 sreg4[V4 ? CV_CK : 1][V4 ? SE : 1];
   float rreg[RES ? CV_CK : 1][RES ? SE : 1];
   floatx4 wreg[WR];
   auto stage_load = [&](int chunk) {
@@ -352,6 +384,13 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
 #pragma unroll
     for (int c = 0; c < CV_CK; ++c) {
       const float *src = inn + (size_t)(c0 + c) * in_chan;
+      if constexpr (V4) {
+#pragma unroll
+        for (int k = 0; k < SE; ++k)
+          sreg4[c][k] = (c < cc && goff[k] >= 0) ? *reinterpret_cast<const floatx4 *>(src + goff[k])
+                                                 : floatx4{0.f, 0.f, 0.f, 0.f};
+        continue;
+      }
 #pragma unroll
       for (int k = 0; k < SE; ++k) sreg[c][k] = (c < cc && goff[k] >= 0) ? src[goff[k]] : 0.0f;
       if constexpr (RES) {
@@ -376,6 +415,19 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
         sc = scsh[c0 + c];
         sh = scsh[32 + c0 + c];
       }
+      if constexpr (V4) {
+#pragma unroll
+        for (int k = 0; k < SE; ++k)
+          if (goff[k] != -2) {
+            floatx4 v = sreg4[c][k];
+            if (xform && goff[k] >= 0) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = lrelu02(v[r] * sc + sh);
+            }
+            *reinterpret_cast<floatx4 *>(tile + c * g.CST + (tid + k * CV_THREADS) * 4) = v;
+          }
+        continue;
+      }
 #pragma unroll
       for (int k = 0; k < SE; ++k) {
         if (goff[k] != -2) {
@@ -396,12 +448,24 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
     }
   };
 
+#ifdef MVSN_DMA_STAMPS
+  __shared__ unsigned long long ph_lds[8];
+  const bool stamped = g_dma_stamps && blockIdx.x == gridDim.x / 3 && blockIdx.y == gridDim.y / 2 && tid == 0;
+  unsigned long long ph_last = __builtin_readcyclecounter();
+  const unsigned long long ph_t0 = ph_last;
+  if (stamped) for (int k = 0; k < 8; ++k) ph_lds[k] = 0;
+#endif
   stage_load(0);
+  MFMA_PHASE(0);   // prologue
   for (int chunk = 0; chunk < g.nchunks; ++chunk) {
     __syncthreads();  // the previous chunk's MFMAs are done with LDS (and scsh is visible)
+    MFMA_PHASE(1);   // barrier 1
     stage_store(chunk);
+    MFMA_PHASE(2);   // transform + LDS writes (waits for the staged loads)
     __syncthreads();
+    MFMA_PHASE(3);   // barrier 2
     if (chunk + 1 < g.nchunks) stage_load(chunk + 1);
+    MFMA_PHASE(4);   // next chunk's loads issued
     // taps software-pipelined by hand: the next tap's weight and activation fragments are read from LDS
     // before the current tap's MFMAs are issued (the compiler otherwise waits lgkmcnt(0) per fragment)
     const float *wt = wl + lane;
@@ -425,19 +489,20 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
         if (CT == 2) acc[j][CT - 1] = mfma16x16x4(fb[cur][j], fw[cur][1], acc[j][CT - 1]);
       }
     }
+    MFMA_PHASE(5);   // MFMAs issued
   }
 
   conv_epilogue<NPT, CT>(g, acc, z0, y0, x0, tid, n, tile_id, bias, out, out_partials);
+#ifdef MVSN_DMA_STAMPS
+  MFMA_PHASE(6);   // epilogue issued
+  if (stamped) {
+    for (int k = 0; k < 7; ++k) g_dma_stamps[32 + k] = ph_lds[k];
+    g_dma_stamps[39] = __builtin_readcyclecounter() - ph_t0;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
-#ifdef MVSN_DMA_STAMPS   // tuning aid (tools/dma_phases.py): s_memtime stamps of one mid-launch wave
-__device__ unsigned long long *g_dma_stamps = nullptr;
-#define DMA_STAMP() do { if (dbg && dbg_i < 60) dbg[dbg_i++] = __builtin_readcyclecounter(); } while (0)
-#else
-#define DMA_STAMP() do { } while (0)
-#endif
-
 // LDS-DMA variant (3x3 / 3x3x3, stride 1): the same implicit GEMM, but the haloed chunk tiles and the
 // weight fragments go HBM -> LDS with global_load_lds (no VGPR round trip, no LDS store pass) into a
 // two-stage ring, one barrier per chunk.  Wave w owns channel w of every 4-channel chunk: it issues
@@ -958,7 +1023,9 @@ extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, co
       else     { if (res) MVSN_CONV_LAUNCH(NPTV, 1, 3, 3, 1, 6, 2, true); else MVSN_CONV_LAUNCH(NPTV, 1, 3, 3, 1, 6, 2, false); } \
     }                                                                                           \
   } while (0)
-  if (g.kd == 3) {                       // 3-D 3x3x3, TZ=2 TY=8 -> NPT 8, SE 6
+  if (g.kd == 3 && g.v4) {               // 3-D 3x3x3 staged as 16-byte groups: 4*10*10 = 400 groups -> 2 per thread
+    if (one_tile) MVSN_CONV_LAUNCH(8, 3, 3, 3, 1, 2, 1, false, true); else MVSN_CONV_LAUNCH(8, 3, 3, 3, 1, 2, 2, false, true);
+  } else if (g.kd == 3) {                // 3-D 3x3x3, TZ=2 TY=8 -> NPT 8, SE 6
     if (one_tile) MVSN_CONV_LAUNCH(8, 3, 3, 3, 1, 6, 1, false); else MVSN_CONV_LAUNCH(8, 3, 3, 3, 1, 6, 2, false);
   } else if (g.kh == 5) {                // 2-D 5x5 stride 2, TY=8 -> NPT 4
     MVSN_CONV_LAUNCH(4, 1, 5, 5, 2, 6, 2, false);
