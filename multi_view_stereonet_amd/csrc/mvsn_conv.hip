@@ -48,7 +48,7 @@ __device__ __forceinline__ int fdiv(int n, FastDiv f) {
 }
 
 struct ConvGeom {
-  FastDiv fd_hx, fd_hy, fd_ntx, fd_nty, fd_ty;
+  FastDiv fd_hx, fd_hy, fd_ntx, fd_nty, fd_ty, fd_gq;
   int n, cin, cout, D, H, W, Do, Ho, Wo;
   int kd, kh, kw, stride, dil, pd, ph, pw;
   int TZ, TY;           // output tile (TX = 32)
@@ -100,12 +100,16 @@ static bool make_geom(const mvsn_conv_desc *d, ConvGeom *g) {
   g->HY = (g->TY - 1) * d->stride + d->dilation * (d->kh - 1) + 1;
   g->HX = (CV_TX - 1) * d->stride + d->dilation * (d->kw - 1) + 1;
   g->XS = g->HX;
-  g->v4 = (is3d && d->kd == 3 && d->stride == 1 && d->dilation == 1 && d->cols % 4 == 0) ? 1 : 0;
+  // the register-staged layers with aligned rows (3-D 3x3x3; 2-D 5x5 stride 2): whole 16-byte groups starting at
+  // the aligned column x0 * stride - 4 -- one load / LDS write moves 4 elements
+  g->v4 = (d->cols % 4 == 0 && d->dilation == 1 && g->pw <= 4 &&
+           ((is3d && d->kd == 3 && d->stride == 1) || (!is3d && d->kh == 5 && d->stride == 2))) ? 1 : 0;
   g->xoff = 0;
-  if (g->v4) {   // rows of 40 floats (10 groups of 16 bytes) starting at x0 - 4: one load / LDS write moves 4 elements
-    g->XS = CV_TX + 8;
+  if (g->v4) {
     g->xoff = 4 - g->pw;
+    g->XS = (g->HX + g->xoff + 3) / 4 * 4;   // 40 floats (stride 1, 3 taps), 72 (stride 2, 5 taps)
   }
+  g->fd_gq = make_fastdiv((unsigned)(g->XS / 4));
   // channel stride: whole 64-element DMA runs (the last run may overshoot the tile and lands in the
   // slot's tail) + 16 so that CST = 16 (mod 32)
   g->ipc = (g->HZ * g->HY * g->XS + 63) / 64;
@@ -339,8 +343,8 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
     if (e < tile_elems) {
       int row, x;
       if constexpr (V4) {
-        row = e / 10;
-        x = (e - row * 10) * 4 - 4 + g.pw;   // so that gx0 + x = x0 - 4 + 4q
+        row = fdiv(e, g.fd_gq);
+        x = (e - row * (g.XS / 4)) * 4 - 4 + g.pw;   // so that gx0 + x = x0 * stride - 4 + 4q
       } else {
         row = fdiv(e, g.fd_hx);
         x = e - row * g.HX;
@@ -1027,6 +1031,8 @@ extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, co
     if (one_tile) MVSN_CONV_LAUNCH(8, 3, 3, 3, 1, 2, 1, false, true); else MVSN_CONV_LAUNCH(8, 3, 3, 3, 1, 2, 2, false, true);
   } else if (g.kd == 3) {                // 3-D 3x3x3, TZ=2 TY=8 -> NPT 8, SE 6
     if (one_tile) MVSN_CONV_LAUNCH(8, 3, 3, 3, 1, 6, 1, false); else MVSN_CONV_LAUNCH(8, 3, 3, 3, 1, 6, 2, false);
+  } else if (g.kh == 5 && g.v4) {        // 2-D 5x5 stride 2 staged as 16-byte groups: 19 * 18 = 342 groups -> 2 per thread
+    MVSN_CONV_LAUNCH(4, 1, 5, 5, 2, 2, 2, false, true);
   } else if (g.kh == 5) {                // 2-D 5x5 stride 2, TY=8 -> NPT 4
     MVSN_CONV_LAUNCH(4, 1, 5, 5, 2, 6, 2, false);
   } else if (g.TY == 16) {               // 2-D 3x3, NPT 8
