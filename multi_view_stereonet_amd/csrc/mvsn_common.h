@@ -36,7 +36,9 @@ __device__ __forceinline__ floatx4 mfma16x16x4(float a, float b, floatx4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float lrelu02(float v) { return v > 0.0f ? v : 0.2f * v; }
+// LeakyReLU(0.2) as max(v, 0.2 v): two VALU instructions (multiply, max) instead of multiply / compare / select.
+// Identical for every finite v (0.2 v < v exactly when v > 0); -0.0 maps to -0.0 either way.
+__device__ __forceinline__ float lrelu02(float v) { return fmaxf(v, 0.2f * v); }
 
 // Workgroup b is observed to run on XCD b % 8, each XCD with its own L2.  Neighbouring tiles share halo
 // rows, so hand each XCD a contiguous range of tiles instead of every 8th one (bijective for any tile

@@ -424,9 +424,10 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
         for (int k = 0; k < SE; ++k)
           if (goff[k] != -2) {
             floatx4 v = sreg4[c][k];
-            if (xform && goff[k] >= 0) {
+            if (xform) {   // uniform; groups outside the image hold zeros and must stay zero: LReLU(0 * sc + 0) = 0
+              const float shk = goff[k] >= 0 ? sh : 0.0f;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = lrelu02(v[r] * sc + sh);
+              for (int r = 0; r < 4; ++r) v[r] = lrelu02(v[r] * sc + shk);
             }
             *reinterpret_cast<floatx4 *>(tile + c * g.CST + (tid + k * CV_THREADS) * 4) = v;
           }
