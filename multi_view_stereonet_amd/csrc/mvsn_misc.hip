@@ -480,9 +480,10 @@ __global__ __launch_bounds__(256) void conv_to1_2d_mfma_kernel(const float *__re
     for (int p = 0; p < 4; ++p) d[p] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      if constexpr (XFORM) {
+      if constexpr (XFORM) {   // groups outside the image were loaded as zeros and must stay zero: shift masked once
+        const float shk = ok ? sh[ks] : 0.0f;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) bfr[ks][p] = ok ? rfr[ks][p] + lrelu02(bfr[ks][p] * sc[ks] + sh[ks]) : 0.0f;
+        for (int p = 0; p < 4; ++p) bfr[ks][p] = rfr[ks][p] + lrelu02(bfr[ks][p] * sc[ks] + shk);
       }
 #pragma unroll
       for (int p = 0; p < 4; ++p) d[p] = mfma16x16x4(a[ks], bfr[ks][p], d[p]);
