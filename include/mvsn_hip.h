@@ -157,6 +157,15 @@ int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, const float *
                       const float *bias, const float *in_stats, const float *in_gamma,
                       const float *in_beta, const float *in_residual, float *out_staged, float *out,
                       float *out_partials, mvsn_stream_t stream);
+/* mvsn_conv_forward on an input handed over as up to three channel blocks instead of one tensor: block b is
+ * a contiguous (N, block_channels[b], rows, cols) tensor and the layer convolves their channel-wise
+ * concatenation (sum of block_channels = desc->c_in) without it ever being assembled.  Replaces the
+ * torch.cat([image, features, idepth], 1) in front of every IDepthmapRefiner (multi_view_stereonet.py:466,
+ * :602-605).  Winograd form only (desc->precision = MVSN_CONV_FP32_WINO, mvsn_conv_winograd_supported);
+ * 1 <= num_blocks <= 3, every block 16-byte aligned. */
+int mvsn_conv_forward_blocks(const mvsn_conv_desc *desc, const float *const *in_blocks, const int *block_channels,
+                             int num_blocks, const float *weight_packed, const float *bias, float *out,
+                             float *out_partials, mvsn_stream_t stream);
 /* partials (N,tiles,4,3) -> stats (N,4,2) = {mean, rstd}, eps 1e-5, biased variance */
 int mvsn_groupnorm_finalize(const float *partials, int n, int tiles, float *stats, mvsn_stream_t stream);
 /* out = [residual +] LeakyReLU_0.2(GroupNorm(x)) on (N,32,spatial); residual may be NULL; out may alias x */

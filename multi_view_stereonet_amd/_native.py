@@ -40,6 +40,7 @@ SIGNATURES = {
     "mvsn_conv_pack_weights": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p]),
     "mvsn_conv_num_tiles": (c_int, [POINTER(ConvDesc)]),
     "mvsn_conv_forward": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 10 + [c_void_p]),
+    "mvsn_conv_forward_blocks": (c_int, [POINTER(ConvDesc), c_void_p, POINTER(c_int), c_int] + [c_void_p] * 4 + [c_void_p]),
     "mvsn_groupnorm_finalize": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mvsn_groupnorm_lrelu_apply": (c_int, [c_void_p] * 5 + [c_int, c_long, c_void_p, c_void_p]),
     "mvsn_groupnorm_lrelu_add2": (c_int, [c_void_p] * 8 + [c_int, c_long, c_void_p, c_void_p]),

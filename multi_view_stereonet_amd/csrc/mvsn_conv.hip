@@ -915,6 +915,35 @@ extern "C" int mvsn_conv_pack_weights(const mvsn_conv_desc *desc, const float *w
   return mvsn::check_launch("mvsn_conv_pack_weights");
 }
 
+extern "C" int mvsn_conv_forward_blocks(const mvsn_conv_desc *desc, const float *const *in_blocks,
+                                        const int *block_channels, int num_blocks, const float *weight_packed,
+                                        const float *bias, float *out, float *out_partials, mvsn_stream_t stream) {
+  using namespace mvsn;
+  MVSN_REQUIRE(desc && in_blocks && block_channels && weight_packed && out, MVSN_E_BADARG,
+               "mvsn_conv_forward_blocks: null pointer");
+  MVSN_REQUIRE(num_blocks >= 1 && num_blocks <= 3, MVSN_E_BADARG, "mvsn_conv_forward_blocks: 1..3 blocks");
+  MVSN_REQUIRE(desc->precision == MVSN_CONV_FP32_WINO, MVSN_E_BADARG,
+               "mvsn_conv_forward_blocks: only the Winograd form takes channel blocks");
+  WinoGeom wg;
+  MVSN_REQUIRE(wino_geom(desc, &wg), MVSN_E_BADARG, "mvsn_conv_forward_blocks: layer has no Winograd form");
+  MVSN_REQUIRE(wg.n <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_forward_blocks: batch too large for one launch");
+  int sum = 0;
+  for (int b = 0; b < num_blocks; ++b) {
+    MVSN_REQUIRE(in_blocks[b] && block_channels[b] >= 1, MVSN_E_BADARG, "mvsn_conv_forward_blocks: empty block");
+    MVSN_REQUIRE((reinterpret_cast<uintptr_t>(in_blocks[b]) & 15) == 0, MVSN_E_BADARG,
+                 "mvsn_conv_forward_blocks: blocks must be 16-byte aligned");
+    sum += block_channels[b];
+  }
+  MVSN_REQUIRE(sum == wg.cin, MVSN_E_BADARG, "mvsn_conv_forward_blocks: block channels do not add up to c_in");
+  WinoBlocks wb;
+  wb.cb0 = block_channels[0];
+  wb.cb1 = num_blocks > 1 ? block_channels[1] : 0;
+  wb.in1 = num_blocks > 1 ? in_blocks[1] : in_blocks[0];
+  wb.in2 = num_blocks > 2 ? in_blocks[2] : in_blocks[0];
+  return wino_launch(wg, in_blocks[0], weight_packed, bias, nullptr, nullptr, nullptr, out, out_partials,
+                     (hipStream_t)stream, &wb);
+}
+
 extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, const float *weight_packed,
                                  const float *bias, const float *in_stats, const float *in_gamma,
                                  const float *in_beta, const float *in_residual, float *out_staged, float *out,

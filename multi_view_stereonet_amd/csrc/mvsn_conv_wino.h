@@ -15,7 +15,13 @@ struct WinoGeom {
 
 bool wino_geom(const mvsn_conv_desc *d, WinoGeom *g);
 int wino_pack(const mvsn_conv_desc *d, const float *weight, float *packed, hipStream_t stream);
+// input handed over as channel blocks: [0, cb0) from `in`, [cb0, cb0 + cb1) from in1, the rest from in2
+struct WinoBlocks {
+  int cb0, cb1;
+  const float *in1, *in2;
+};
 int wino_launch(const WinoGeom &g, const float *in, const float *upk, const float *bias, const float *in_stats,
-                const float *in_gamma, const float *in_beta, float *out, float *out_partials, hipStream_t stream);
+                const float *in_gamma, const float *in_beta, float *out, float *out_partials, hipStream_t stream,
+                const WinoBlocks *blocks = nullptr);
 
 }  // namespace mvsn

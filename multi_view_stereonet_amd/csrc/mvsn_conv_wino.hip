@@ -27,6 +27,8 @@
 //     GroupNorm partials.
 // MODE 1: the previous layer's LeakyReLU(GroupNorm(.)) is applied in LDS, once per element, by the wave that
 // fetched the piece (out-of-image pieces keep their zeros, as the padding of the materialised tensor would be).
+#include <type_traits>
+
 #include "mvsn_common.h"
 #include "mvsn_conv_wino.h"
 
@@ -71,6 +73,10 @@ __device__ __forceinline__ int wdiv(int n, WinoDiv f) { return (int)((__umulhi((
 struct WinoArgs {
   int n, cin, H, W, ntx, tiles, nchunks;
   WinoDiv fd_ntx;
+  // input as up to three channel blocks (each a contiguous (n, c_b, H, W) tensor): channels [0, cb0) from `in`,
+  // [cb0, cb0 + cb1) from in1, the rest from in2.  One block: cb0 = cin.
+  int cb0, cb1;
+  const float *in1, *in2;
 };
 
 // U = G g G^T per (cout, cin), packed [chunk of 4 cin][xi = 4i + j][cout tile][lane]; lane = k*16 + c holds
@@ -147,14 +153,14 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   const float *zero = reinterpret_cast<const float *>(&g_wn_zero16);
   int pf_round = 0, pf_chunk = 0, pf_stage = 0;
   int pf_goff[PER];
-  const float *pf_src = in;
+  int pf_n = 0;
   bool pf_live = slot < total;
   auto pf_plan = [&]() {   // DMA plan of the prefetcher's current item
     const int flat = pf_round * G + slot;
     const int n = flat / g.tiles, tile = flat - n * g.tiles;
     const int tyi = wdiv(tile, g.fd_ntx), txi = tile - tyi * g.ntx;
     const int y0 = tyi * WN_TY, x0 = txi * WN_TX;
-    pf_src = in + (size_t)n * g.cin * plane;
+    pf_n = n;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int e = (dp0 + i) * 64 + lane;
@@ -167,7 +173,10 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     if (!pf_live) return;
     const int c = pf_chunk * (KS * 4) + dch;
     const bool cok = c < g.cin;
-    const float *src = pf_src + (size_t)(cok ? c : 0) * plane;
+    const int cc = cok ? c : 0, c1 = cc - g.cb0, c2 = c1 - g.cb1;   // wave-uniform: the block select is scalar work
+    const float *src = c1 < 0 ? in + ((size_t)pf_n * g.cb0 + cc) * plane
+                     : c2 < 0 ? g.in1 + ((size_t)pf_n * g.cb1 + c1) * plane
+                              : g.in2 + ((size_t)pf_n * (g.cin - g.cb0 - g.cb1) + c2) * plane;
     float *dst = smem + pf_stage * STAGE + dch * RCST;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -278,7 +287,9 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   auto tr_setup = [&]() {};   // (nothing per tile on this side: MODE 1 is applied in LDS by the fetching wave)
   // the 4 x 4 patch of (channel kc, patch pcol of patch row wave) of the transform side's step, transformed:
   // the result IS the A fragment of the 16 coefficient GEMMs
-  auto tr_load = [&](float (&d)[KS][4][4]) {
+  // raw patch as loaded: da = columns (0, 2), db = columns (1, 3) of each row -- the register pairs the
+  // ds_read2_b32 produce, consumed in place (no re-interleaving moves)
+  auto tr_load = [&](float (&da)[KS][4][2], float (&db)[KS][4][2]) {
 #pragma unroll
     for (int h = 0; h < KS; ++h) {
       const float *raw = smem + tr_stage * STAGE + (h * 4 + kc) * RCST + ya * XS + xa + (PA - DIL);
@@ -290,27 +301,30 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         const float *ra = raw + oa, *rb = raw + ob;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          d[h][i][0] = ra[i * XS], d[h][i][2] = ra[i * XS + 2];
-          d[h][i][1] = rb[i * XS], d[h][i][3] = rb[i * XS + 2];
+          da[h][i][0] = ra[i * XS], da[h][i][1] = ra[i * XS + 2];
+          db[h][i][0] = rb[i * XS], db[h][i][1] = rb[i * XS + 2];
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) d[h][i][j] = raw[i * DIL * XS + j * DIL];
+        for (int i = 0; i < 4; ++i) {
+          da[h][i][0] = raw[i * DIL * XS], da[h][i][1] = raw[i * DIL * XS + 2 * DIL];
+          db[h][i][0] = raw[i * DIL * XS + DIL], db[h][i][1] = raw[i * DIL * XS + 3 * DIL];
+        }
       }
     }
   };
-  auto tr_finish = [&](float (&d)[KS][4][4], float (&v)[KS][16]) {
+  auto tr_finish = [&](float (&da)[KS][4][2], float (&db)[KS][4][2], float (&v)[KS][16]) {
 #pragma unroll
     for (int h = 0; h < KS; ++h) {
       float t[4][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        t[0][j] = d[h][0][j] - d[h][2][j];
-        t[1][j] = d[h][1][j] + d[h][2][j];
-        t[2][j] = d[h][2][j] - d[h][1][j];
-        t[3][j] = d[h][1][j] - d[h][3][j];
+        const float d0 = (j & 1) ? db[h][0][j >> 1] : da[h][0][j >> 1], d1 = (j & 1) ? db[h][1][j >> 1] : da[h][1][j >> 1];
+        const float d2 = (j & 1) ? db[h][2][j >> 1] : da[h][2][j >> 1], d3 = (j & 1) ? db[h][3][j >> 1] : da[h][3][j >> 1];
+        t[0][j] = d0 - d2;
+        t[1][j] = d1 + d2;
+        t[2][j] = d2 - d1;
+        t[3][j] = d1 - d3;
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -337,59 +351,14 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     xf_apply();        // step 0
     xf_prepare();      // step 1
     __syncthreads();   // step 0 (and U) visible to everyone
-    float d0[KS][4][4];
-    tr_load(d0);
-    tr_finish(d0, v);
+    float a0[KS][4][2], b0[KS][4][2];
+    tr_load(a0, b0);
+    tr_finish(a0, b0, v);
   }
 
-  int step = 0;
-  for (int round = 0; round < my_items; ++round) {
-    const int flat = round * G + slot;
-    const int n = flat / g.tiles, tile_id = flat - n * g.tiles;
-    const int tyi = wdiv(tile_id, g.fd_ntx), txi = tile_id - tyi * g.ntx;
-    const int y0 = tyi * WN_TY, x0 = txi * WN_TX;
-
-    floatx4 acc[16][2];
-#pragma unroll
-    for (int xi = 0; xi < 16; ++xi) acc[xi][0] = acc[xi][1] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-    for (int chunk = 0; chunk < nsteps; ++chunk, ++step) {
-      const bool has_next = step + 1 < total_steps;   // uniform
-      if (has_next) {
-        const int rest = total_steps - (step + 2);     // steps issued after step + 1 so far
-        wait_landed(rest < 0 ? 0 : (rest < NSTAGE - 2 ? rest : NSTAGE - 2));   // step + 1 has landed
-        xf_apply();        // step + 1
-        WN_STAMP();   // landed
-        __syncthreads();   // ... for everyone; everyone has read the raw tile of `step`
-        WN_STAMP();   // barrier
-        xf_prepare();      // step + 2: its scalar loads travel behind this step's multiplies
-      }
-      // multiplies of `step` with the transform of `step + 1` slotted between them
-      float dn[KS][4][4];
-      if (has_next) tr_load(dn);
-#pragma unroll
-      for (int h = 0; h < KS; ++h) {
-        if (KS == 2 && h == 1 && chunk * KS + 1 >= g.nchunks) break;   // uniform: odd chunk count, nothing in the second half
-        const float *ub = U + (chunk * KS + h) * WN_UFLOATS + lane;
-        float fb[2][2];
-        fb[0][0] = ub[0], fb[0][1] = ub[64];
-#pragma unroll
-        for (int xi = 0; xi < 16; ++xi) {   // next coefficient's U fragments in flight behind this one's MFMAs
-          const int cur = xi & 1;
-          if (xi + 1 < 16) {
-            fb[cur ^ 1][0] = ub[(xi + 1) * 128];
-            fb[cur ^ 1][1] = ub[(xi + 1) * 128 + 64];
-          }
-          acc[xi][0] = mfma16x16x4(v[h][xi], fb[cur][0], acc[xi][0]);
-          acc[xi][1] = mfma16x16x4(v[h][xi], fb[cur][1], acc[xi][1]);
-          if (h == 0 && xi == 1 && has_next) pf_issue();   // step + NSTAGE into the stage `step` released, behind the first MFMAs
-        }
-      }
-      if (has_next) tr_finish(dn, v);   // v: A fragments of step + 1 (written after the last MFMA read it)
-      WN_STAMP();   // MFMAs issued + next transform
-    }
-
-    // ---- output transform, bias, stores, GroupNorm partials
+  // ---- a finished tile: output transform, bias, stores, GroupNorm partials
+  floatx4 acc[16][2];
+  auto finish_tile = [&](int n, int tile_id, int y0, int x0) {
     // lane: cout t*16 + (lane&15); patches p = 4*(lane>>4) + r of patch row `wave`: output rows ya, ya + DIL and
     // columns xa(p), xa(p) + DIL.  Whatever the dilation, the eight columns of a lane's four patches form two
     // aligned groups of four consecutive columns: element (r, second) goes to slot k of group h.
@@ -484,6 +453,67 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         }
       }
     }
+  };
+
+  int step = 0;
+  for (int round = 0; round < my_items; ++round) {
+    const int flat = round * G + slot;
+    const int n = flat / g.tiles, tile_id = flat - n * g.tiles;
+    const int tyi = wdiv(tile_id, g.fd_ntx), txi = tile_id - tyi * g.ntx;
+    const int y0 = tyi * WN_TY, x0 = txi * WN_TX;
+
+    // acc is first written by the tile's first 32 multiplies (C = 0): no zeroing pass.  The empty asm "defines"
+    // the registers here, so the allocator does not carry 128 undefined values around the tile loop.
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) asm volatile("" : "=v"(acc[xi][0]), "=v"(acc[xi][1]));
+
+    for (int chunk = 0; chunk < nsteps; ++chunk, ++step) {
+      const bool has_next = step + 1 < total_steps;   // uniform
+      if (has_next) {
+        const int rest = total_steps - (step + 2);     // steps issued after step + 1 so far
+        wait_landed(rest < 0 ? 0 : (rest < NSTAGE - 2 ? rest : NSTAGE - 2));   // step + 1 has landed
+        xf_apply();        // step + 1
+        WN_STAMP();   // landed
+        __syncthreads();   // ... for everyone; everyone has read the raw tile of `step`
+        WN_STAMP();   // barrier
+        xf_prepare();      // step + 2: its scalar loads travel behind this step's multiplies
+      }
+      // multiplies of `step` with the transform of `step + 1` slotted between them
+      float dna[KS][4][2], dnb[KS][4][2];
+      if (has_next) tr_load(dna, dnb);
+      auto multiply = [&](auto first, auto hc) {   // one k-step: 16 coefficient GEMMs x 2 cout tiles
+        constexpr bool FIRST = decltype(first)::value;
+        constexpr int h = decltype(hc)::value;
+        const float *ub = U + (chunk * KS + h) * WN_UFLOATS + lane;
+        float fb[2][2];
+        fb[0][0] = ub[0], fb[0][1] = ub[64];
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {   // next coefficient's U fragments in flight behind this one's MFMAs
+          const int cur = xi & 1;
+          if (xi + 1 < 16) {
+            fb[cur ^ 1][0] = ub[(xi + 1) * 128];
+            fb[cur ^ 1][1] = ub[(xi + 1) * 128 + 64];
+          }
+          if constexpr (FIRST) {
+            acc[xi][0] = mfma16x16x4(v[h][xi], fb[cur][0], floatx4{0.f, 0.f, 0.f, 0.f});
+            acc[xi][1] = mfma16x16x4(v[h][xi], fb[cur][1], floatx4{0.f, 0.f, 0.f, 0.f});
+          } else {
+            acc[xi][0] = mfma16x16x4(v[h][xi], fb[cur][0], acc[xi][0]);
+            acc[xi][1] = mfma16x16x4(v[h][xi], fb[cur][1], acc[xi][1]);
+          }
+          if (h == 0 && xi == 1 && has_next) pf_issue();   // step + NSTAGE into the stage `step` released, behind the first MFMAs
+        }
+      };
+      if (chunk == 0) multiply(std::true_type{}, std::integral_constant<int, 0>{});   // uniform
+      else multiply(std::false_type{}, std::integral_constant<int, 0>{});
+      if constexpr (KS == 2) {
+        if (chunk * KS + 1 < g.nchunks)   // uniform: odd chunk count, nothing in the second half
+          multiply(std::false_type{}, std::integral_constant<int, 1>{});
+      }
+      if (has_next) tr_finish(dna, dnb, v);   // v: A fragments of step + 1 (written after the last MFMA read it)
+      WN_STAMP();   // MFMAs issued + next transform
+    }
+    finish_tile(n, tile_id, y0, x0);
   }
 }
 
@@ -515,10 +545,13 @@ int wino_pack(const mvsn_conv_desc *d, const float *weight, float *packed, hipSt
 }
 
 int wino_launch(const WinoGeom &g, const float *in, const float *upk, const float *bias, const float *in_stats,
-                const float *in_gamma, const float *in_beta, float *out, float *out_partials, hipStream_t stream) {
+                const float *in_gamma, const float *in_beta, float *out, float *out_partials, hipStream_t stream,
+                const WinoBlocks *blocks) {
   WinoArgs a;
   a.n = g.n, a.cin = g.cin, a.H = g.H, a.W = g.W, a.ntx = g.ntx, a.tiles = g.tiles, a.nchunks = g.nchunks;
   a.fd_ntx = wino_div((unsigned)g.ntx);
+  a.cb0 = g.cin, a.cb1 = 0, a.in1 = a.in2 = in;
+  if (blocks) a.cb0 = blocks->cb0, a.cb1 = blocks->cb1, a.in1 = blocks->in1, a.in2 = blocks->in2;
   static int cus = 0;
   if (cus == 0) {
     int dev = 0;

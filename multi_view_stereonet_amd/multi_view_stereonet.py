@@ -106,6 +106,7 @@ class PlaneSweepEngine:
         # Skip the stand-alone normalise/activate pass at both ends of a refiner tower (see
         # residual_tower_unfused); False keeps one pass per block (tests compare the two).
         self.trim_tower_ends = True
+        self.cat_free_heads = True         # refiner heads read [image, features, idepth] in place (no torch.cat)
         fe = net.left_feature_extractor
         self.fe_down = [_Conv(lib, getattr(fe, f"conv{i}").weight, None, stride=2) for i in range(4)]
         self.fe_res = [(_Conv(lib, getattr(fe, f"res{i}").conv1.weight, None), _Norm(getattr(fe, f"res{i}").bn1))
@@ -157,6 +158,13 @@ class PlaneSweepEngine:
         returns that folded input as a tensor (it is the block's output, needed as the next residual).
         """
         lib = self.lib
+        if isinstance(x, (list, tuple)):
+            # input as channel blocks: the Winograd head reads them in place, anything else gets the concatenation
+            out = self.conv_blocks(c, x, want_stats) if (in_stats is None and in_residual is None and
+                                                         not write_staged) else None
+            if out is not None:
+                return out
+            x = torch.cat(list(x), 1)
         n = x.shape[0]
         depth = x.shape[2] if c.dims == 3 else 1
         rows, cols = x.shape[-2], x.shape[-1]
@@ -203,6 +211,40 @@ class PlaneSweepEngine:
             return out, stats, staged
         return out, stats
 
+    def conv_blocks(self, c: _Conv, blocks, want_stats=False):
+        """3x3 layer on the channel-wise concatenation of up to three tensors without assembling it
+        (mvsn_conv_forward_blocks); None when the layer / shape has no such path."""
+        lib = self.lib
+        x0 = blocks[0]
+        if not (self.winograd and self.cat_free_heads and c.packed_wino is not None and 1 <= len(blocks) <= 3
+                and self.conv_precision == "fp32" and all(b.dtype == torch.float32 for b in blocks)):
+            return None
+        n, rows, cols = x0.shape[0], x0.shape[-2], x0.shape[-1]
+        d = c.desc(n, 1, rows, cols, _native.CONV_FP32_WINO)
+        if not lib.mvsn_conv_winograd_supported(ctypes.byref(d)) or sum(b.shape[1] for b in blocks) != c.cin:
+            return None
+        blocks = [b.contiguous() for b in blocks]
+        if any(b.data_ptr() % 16 for b in blocks):
+            return None
+        out = torch.empty((n, c.cout, rows, cols), dtype=torch.float32, device=x0.device)
+        partials = None
+        if want_stats:
+            partials = torch.empty((n, lib.mvsn_conv_num_tiles(ctypes.byref(d)), 4, 3), dtype=torch.float32,
+                                   device=x0.device)
+        ptrs = (ctypes.c_void_p * len(blocks))(*[b.data_ptr() for b in blocks])
+        chans = (ctypes.c_int * len(blocks))(*[b.shape[1] for b in blocks])
+        self._call(f"mvsn_conv_forward_blocks[conv2d k3 {c.cin}->{c.cout} wino]", lib.mvsn_conv_forward_blocks,
+                   ctypes.byref(d), ptrs, chans, len(blocks), _native.ptr(c.packed_wino), _native.ptr(c.bias),
+                   _native.ptr(out), _native.ptr(partials), _native.stream(),
+                   flops=2.0 * c.cin * 9 * c.cout * out[:, 0].numel(),
+                   nbytes=4.0 * (sum(b.numel() for b in blocks) + out.numel()))
+        stats = None
+        if want_stats:
+            stats = torch.empty((n, 4, 2), dtype=torch.float32, device=x0.device)
+            self._call("mvsn_groupnorm_finalize", lib.mvsn_groupnorm_finalize, _native.ptr(partials), n,
+                       partials.shape[1], _native.ptr(stats), _native.stream())
+        return out, stats
+
     def conv_to1(self, c: _Conv, x: torch.Tensor, prior: Optional[torch.Tensor] = None,
                  fx: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         """32 -> 1 layer on the vector path (HBM-bound); None when the shape needs the MFMA kernel.
@@ -234,8 +276,9 @@ class PlaneSweepEngine:
                 pend = (r0, st0, first[1])
             else:
                 x = self.gn_lrelu(r0, st0, first[1], out=r0)
+        shp = x[0].shape if isinstance(x, (list, tuple)) else x.shape
         to1_ok = (final.cout == 1 and final.cin == 32 and final.dilation == 1 and final.stride == 1 and
-                  final.dims == 2 and self.lib.mvsn_conv_to1_supported(x.shape[-2], x.shape[-1]))
+                  final.dims == 2 and self.lib.mvsn_conv_to1_supported(shp[-2], shp[-1]))
         for i, (conv, norm) in enumerate(blocks):
             if pend is not None:
                 r0, st0, n0 = pend
@@ -342,7 +385,9 @@ class PlaneSweepEngine:
         p = self.refiners[level]
         scale = fx.view(-1, 1, 1, 1)
         scaled = prior * scale
-        x_in = torch.cat((list(guide) if isinstance(guide, (list, tuple)) else [guide]) + [scaled], 1)
+        x_in = (list(guide) if isinstance(guide, (list, tuple)) else [guide]) + [scaled]
+        if self.fold_residual_blocks or len(x_in) > 3:
+            x_in = torch.cat(x_in, 1)       # those towers take one tensor
         if self.fold_residual_blocks:
             delta, done = self.residual_tower(x_in, (p["conv0"], p["bn0"]), p["res"], p["final"]), False
         else:
@@ -352,10 +397,11 @@ class PlaneSweepEngine:
             return delta            # epilogue relu(prior*fx + delta)/fx already applied in the kernel
         return torch.relu(scaled + delta) / scale
 
-    def homography_warp(self, image: torch.Tensor, H: torch.Tensor):
+    def homography_warp(self, image: torch.Tensor, H: torch.Tensor, out: Optional[torch.Tensor] = None):
         B, C, rows, cols = image.shape
         n = H.shape[1]
-        vol = torch.empty((B, C, n, rows, cols), dtype=torch.float32, device=image.device)
+        vol = torch.empty((B, C, n, rows, cols), dtype=torch.float32, device=image.device) if out is None else out
+        assert vol.shape == (B, C, n, rows, cols) and vol.is_contiguous()
         mask = torch.empty((B, n, rows, cols), dtype=torch.bool, device=image.device)
         self._call("mvsn_homography_warp", self.lib.mvsn_homography_warp, _native.ptr(image), _native.ptr(H), B, C, n,
                    rows, cols, _native.ptr(vol), _native.ptr(mask), _native.stream(),
@@ -442,9 +488,14 @@ class PlaneSweepEngine:
         samples, H4, Hinc, H0, baseline = self.plane_sweep_setup(T, K0, K4, rows4, cols4, D)
 
         # 2. full-resolution source images on plane 0, 3. one extractor batch
-        src0 = torch.cat([p[0].float() for p in right_image_pyrs], 0).contiguous()
-        warped0, _ = self.homography_warp(src0, H0)
-        feats = self.feature_network(torch.cat([left0, warped0[:, :, 0]], 0))
+        #    (each source is warped straight into its slot of the extractor's frame batch)
+        frames = torch.empty(((S + 1) * B,) + tuple(left0.shape[1:]), dtype=torch.float32, device=left0.device)
+        frames[:B].copy_(left0)
+        for s_, pyr in enumerate(right_image_pyrs):
+            self.homography_warp(pyr[0].float().contiguous(), H0[s_ * B:(s_ + 1) * B],
+                                 out=frames[(s_ + 1) * B:(s_ + 2) * B].unsqueeze(2))
+        warped0 = frames[B:].unsqueeze(2)
+        feats = self.feature_network(frames)
         left_feats = [f[:B].contiguous() for f in feats]
         plane0 = feats[-1][B:].contiguous()
 

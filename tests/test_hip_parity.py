@@ -188,6 +188,57 @@ def test_conv_winograd_form(cin, rows, cols, n, dil):
         close(out2, ref2, rtol=1e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("split,rows,cols,n", [((3, 32, 1), 40, 72, 2), ((3, 1), 64, 128, 3), ((35, 1), 16, 32, 2),
+                                               ((3, 32, 1), 128, 256, 5), ((36,), 24, 40, 1), ((4, 4, 4), 33, 52, 2)])
+def test_conv_channel_blocks(split, rows, cols, n):
+    """mvsn_conv_forward_blocks: the layer on [image, features, idepth] handed over as separate tensors is
+    bit-identical to the same kernel on their torch.cat (same arithmetic, only the fetch addresses differ)."""
+    from multi_view_stereonet_amd.multi_view_stereonet import _Conv
+    eng = net_for("gta_sfm_150epochs").engine()
+    cin = sum(split)
+    g = torch.Generator().manual_seed(cin + rows)
+    w = torch.randn(32, cin, 3, 3, generator=g) * 0.1
+    b = torch.randn(32, generator=g) * 0.1
+    blocks = [torch.randn(n, c_, rows, cols, generator=g).to(DEV) for c_ in split]
+    c = _Conv(eng.lib, w.to(DEV), b.to(DEV))
+    got = eng.conv_blocks(c, blocks, want_stats=True)
+    assert got is not None
+    out, stats = got
+    out_c, stats_c = eng.conv(c, torch.cat(blocks, 1), want_stats=True)
+    assert torch.equal(out, out_c) and torch.equal(stats, stats_c)
+    ref = F.conv2d(torch.cat([t.cpu() for t in blocks], 1), w, b, padding=1)
+    close(out, ref, rtol=1e-4, atol=1e-4)
+    # conv() takes the list too, and falls back to the concatenation where the layer has no Winograd form
+    out_l, _ = eng.conv(c, blocks, want_stats=True)
+    assert torch.equal(out_l, out)
+    eng.cat_free_heads = False
+    out_f, _ = eng.conv(c, blocks, want_stats=True)
+    eng.cat_free_heads = True
+    assert torch.equal(out_f, out)
+
+
+def test_conv_channel_blocks_rejects_bad_arguments():
+    import ctypes
+    from multi_view_stereonet_amd import _native
+    from multi_view_stereonet_amd.multi_view_stereonet import _Conv
+    eng = net_for("gta_sfm_150epochs").engine()
+    lib = eng.lib
+    c = _Conv(lib, torch.randn(32, 36, 3, 3).to(DEV), None)
+    a, b_ = torch.zeros(1, 35, 8, 16, device=DEV), torch.zeros(1, 1, 8, 16, device=DEV)
+    out = torch.empty(1, 32, 8, 16, device=DEV)
+    d = c.desc(1, 1, 8, 16, _native.CONV_FP32_WINO)
+    ptrs = (ctypes.c_void_p * 2)(a.data_ptr(), b_.data_ptr())
+    for chans, prec in (((35, 2), _native.CONV_FP32_WINO), ((35, 1), _native.CONV_FP32)):
+        d.precision = prec
+        rc = lib.mvsn_conv_forward_blocks(ctypes.byref(d), ptrs, (ctypes.c_int * 2)(*chans), 2,
+                                          _native.ptr(c.packed_wino), None, _native.ptr(out), None, _native.stream())
+        assert rc != 0 and lib.mvsn_last_error()
+    d.precision = _native.CONV_FP32_WINO
+    rc = lib.mvsn_conv_forward_blocks(ctypes.byref(d), ptrs, (ctypes.c_int * 2)(35, 1), 4,
+                                      _native.ptr(c.packed_wino), None, _native.ptr(out), None, _native.stream())
+    assert rc != 0
+
+
 def test_conv_with_folded_groupnorm_input():
     from multi_view_stereonet_amd.multi_view_stereonet import _Conv, _Norm
     eng = net_for("gta_sfm_150epochs").engine()
@@ -317,6 +368,25 @@ def test_refiner_tower_end_trimming_is_equivalent():
         b = eng.idepth_refiner(lvl, guide, prior, fx)
         eng.trim_tower_ends = True
         close(a, b.cpu(), rtol=2e-5, atol=2e-6)
+
+
+def test_refiner_heads_without_concatenation_are_identical():
+    """Refiner input handed to the head conv as [image, features, idepth] blocks vs. one torch.cat: bit-identical,
+    for every refiner of the pretrained weights (the level-0 head has no feature block: 3 + 1 channels)."""
+    eng = net_for("gta_sfm_150epochs").engine()
+    g = torch.Generator().manual_seed(12)
+    for lvl, (rows, cols) in zip((3, 1, 0), ((32, 64), (128, 256), (256, 512))):
+        cin = eng.refiners[lvl]["conv0"].cin
+        guide = [torch.rand(2, 3, rows, cols, generator=g).to(DEV)]
+        if cin > 4:
+            guide.append(torch.rand(2, cin - 4, rows, cols, generator=g).to(DEV))
+        prior = (torch.rand(2, 1, rows, cols, generator=g) * 0.5).to(DEV)
+        fx = torch.tensor([300.0 / 2 ** lvl, 260.0 / 2 ** lvl], device=DEV)
+        a = eng.idepth_refiner(lvl, guide, prior, fx)
+        eng.cat_free_heads = False
+        b = eng.idepth_refiner(lvl, guide, prior, fx)
+        eng.cat_free_heads = True
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("dims,depth,rows,cols,dil,n", [(2, 1, 16, 32, 1, 2), (2, 1, 37, 70, 1, 1), (2, 1, 24, 40, 2, 1),
