@@ -883,7 +883,7 @@ extern "C" int mvsn_conv_num_tiles(const mvsn_conv_desc *desc) {
   // number of GroupNorm partial records per sample: one per (tile, wave), 4 waves per workgroup tile
   if (desc && desc->precision == MVSN_CONV_FP32_WINO) {
     mvsn::WinoGeom wg;
-    return mvsn::wino_geom(desc, &wg) ? wg.tiles * 8 : 0;   // 8 waves per workgroup tile
+    return mvsn::wino_geom(desc, &wg) ? wg.D * wg.tiles * 8 : 0;   // 8 waves per workgroup tile (per plane)
   }
   if (desc && (desc->precision == MVSN_CONV_BF16X3 || desc->precision == MVSN_CONV_BF16)) {
     mvsn::Bf16x3Geom bg;

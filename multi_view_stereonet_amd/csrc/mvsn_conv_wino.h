@@ -9,6 +9,8 @@ namespace mvsn {
 
 struct WinoGeom {
   int n, cin, H, W, dil;
+  int D;      // planes per sample (1 for the 2-D layers)
+  bool vol;   // 3 x 3 x 3 layer (volume form)
   int nty, ntx, tiles, nchunks;
   size_t packed_floats;
 };

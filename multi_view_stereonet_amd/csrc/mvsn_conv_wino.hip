@@ -77,19 +77,24 @@ struct WinoArgs {
   // [cb0, cb0 + cb1) from in1, the rest from in2.  One block: cb0 = cin.
   int cb0, cb1;
   const float *in1, *in2;
+  int D;   // planes per sample (volume form; 1 for the 2-D layers)
 };
 
 // U = G g G^T per (cout, cin), packed [chunk of 4 cin][xi = 4i + j][cout tile][lane]; lane = k*16 + c holds
 // U_xi[cin = chunk*4 + k][cout = t*16 + c] (the B fragment of the MFMA), zero outside (c_in, 32).
-__global__ void wino_pack_kernel(const float *__restrict__ w, int cin, int cout, int nchunks, float *__restrict__ out) {
+// Volume form (kd = 3, weight (cout, cin, 3, 3, 3)): the chunks of depth tap kz follow those of kz - 1
+// (chunk = kz * cin/4 + cin chunk), each the 2-D transform of the tap's 3 x 3 slice.
+__global__ void wino_pack_kernel(const float *__restrict__ w, int cin, int cout, int nchunks, int kd,
+                                 float *__restrict__ out) {
   const int total = nchunks * WN_UFLOATS;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int lane = idx & 63, t = (idx >> 6) & 1, xi = (idx >> 7) & 15, chunk = idx >> 11;
-  const int co = t * 16 + (lane & 15), ci = chunk * 4 + (lane >> 4);
+  const int per_kz = nchunks / kd, kz = chunk / per_kz;
+  const int co = t * 16 + (lane & 15), ci = (chunk - kz * per_kz) * 4 + (lane >> 4);
   float u = 0.0f;
   if (co < cout && ci < cin) {
-    const float *g = w + ((size_t)co * cin + ci) * 9;
+    const float *g = w + (((size_t)co * cin + ci) * kd + kz) * 9;
     const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
     const int i = xi >> 2, j = xi & 3;
     for (int a = 0; a < 3; ++a)
@@ -103,7 +108,12 @@ __global__ void wino_pack_kernel(const float *__restrict__ w, int cin, int cout,
 // NSTAGE  depth of the raw-tile ring (KS = 2: 4 x 23 KB next to the 64 KB of U; a step is ~2 us, a DMA round
 //         trip under load longer)
 // DIL     dilation (1, 2, 4, 8)
-template <int MODE, int KS, int NSTAGE, int DIL>
+// VOL     volume form: 3 x 3 x 3 layer on (n, 32, D, H, W) as the sum over the depth tap kz of the 2-D Winograd
+//         products of plane z + kz - 1 (12 multiplies per output instead of 27).  A work item is (sample, plane,
+//         tile); its 3 x 4 steps accumulate into one set of registers.  The 192 KB of transformed weights do not
+//         fit next to the raw ring, so each step's 16 KB of U travel through a second ring one step behind the
+//         raw tiles (the slot of step s is free once every wave has passed the barrier of step s + 1).
+template <int MODE, int KS, int NSTAGE, int DIL, bool VOL = false>
 __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, const float *__restrict__ in,
                                                                   const float *__restrict__ upk,
                                                                   const float *__restrict__ bias,
@@ -116,13 +126,16 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   constexpr int PA = wn_pa(DIL), XS = wn_xs(DIL), DQ = XS / 4, GROUPS = wn_groups(DIL), PIECES = wn_pieces(DIL);
   constexpr int RCST = wn_rcst(DIL);
   constexpr int STAGE = KS * 4 * RCST;               // ring stage (floats)
-  float *U = smem + NSTAGE * STAGE;                  // nchunks * WN_UFLOATS, resident
+  float *U = smem + NSTAGE * STAGE;                  // nchunks * WN_UFLOATS, resident (VOL: ring of NSTAGE steps)
+  constexpr int UST = KS * WN_UFLOATS;               // U of one step (floats)
+  static_assert(!VOL || (KS == 2 && DIL == 1), "volume form: 32 channels in steps of 8, dilation 1");
   const int nsteps = (g.nchunks + KS - 1) / KS;      // steps per tile
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t plane = (size_t)g.H * g.W;
-  const int total = g.n * g.tiles;                   // work items in (image, tile) order
+  const int ptiles = g.D * g.tiles;                  // tiles per sample (VOL: planes x tiles)
+  const int total = g.n * ptiles;                    // work items in (image, [plane,] tile) order
   const int G = gridDim.x;
   // item of this workgroup in round r: r * G + an XCD-contiguous slot (neighbouring tiles share halo lines in one L2)
   const int slot = xcd_tile_index(blockIdx.x, G);
@@ -133,7 +146,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   WN_STAMP();   // entry
 
   // ---- resident U: wave w fetches 1 KB runs w, w + 8, ...
-  {
+  if constexpr (!VOL) {
     const int runs = g.nchunks * (WN_UFLOATS / 256);
     for (int run = wave; run < runs; run += WN_WAVES)
       __builtin_amdgcn_global_load_lds(WN_GPTR(upk + (size_t)run * 256 + lane * 4), WN_LPTR(U + run * 256), 16, 0, 0);
@@ -153,11 +166,16 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   const float *zero = reinterpret_cast<const float *>(&g_wn_zero16);
   int pf_round = 0, pf_chunk = 0, pf_stage = 0;
   int pf_goff[PER];
-  int pf_n = 0;
+  int pf_n = 0, pf_z = 0;
   bool pf_live = slot < total;
   auto pf_plan = [&]() {   // DMA plan of the prefetcher's current item
     const int flat = pf_round * G + slot;
-    const int n = flat / g.tiles, tile = flat - n * g.tiles;
+    const int n = flat / ptiles;
+    int tile = flat - n * ptiles;
+    if constexpr (VOL) {
+      pf_z = tile / g.tiles;
+      tile -= pf_z * g.tiles;
+    }
     const int tyi = wdiv(tile, g.fd_ntx), txi = tile - tyi * g.ntx;
     const int y0 = tyi * WN_TY, x0 = txi * WN_TX;
     pf_n = n;
@@ -171,12 +189,20 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   };
   auto pf_issue = [&]() {   // issue the DMA of the prefetcher's step and advance it
     if (!pf_live) return;
-    const int c = pf_chunk * (KS * 4) + dch;
-    const bool cok = c < g.cin;
-    const int cc = cok ? c : 0, c1 = cc - g.cb0, c2 = c1 - g.cb1;   // wave-uniform: the block select is scalar work
-    const float *src = c1 < 0 ? in + ((size_t)pf_n * g.cb0 + cc) * plane
-                     : c2 < 0 ? g.in1 + ((size_t)pf_n * g.cb1 + c1) * plane
-                              : g.in2 + ((size_t)pf_n * (g.cin - g.cb0 - g.cb1) + c2) * plane;
+    bool cok;
+    const float *src;
+    if constexpr (VOL) {   // step = (depth tap, 8 channels): plane pf_z + kz - 1 of channel c, zeros outside the volume
+      const int kz = pf_chunk >> 2, c = (pf_chunk & 3) * 8 + dch, zz = pf_z + kz - 1;
+      cok = zz >= 0 && zz < g.D;
+      src = in + (((size_t)pf_n * 32 + c) * g.D + (cok ? zz : 0)) * plane;
+    } else {
+      const int c = pf_chunk * (KS * 4) + dch;
+      cok = c < g.cin;
+      const int cc = cok ? c : 0, c1 = cc - g.cb0, c2 = c1 - g.cb1;   // wave-uniform: the block select is scalar work
+      src = c1 < 0 ? in + ((size_t)pf_n * g.cb0 + cc) * plane
+          : c2 < 0 ? g.in1 + ((size_t)pf_n * g.cb1 + c1) * plane
+                   : g.in2 + ((size_t)pf_n * (g.cin - g.cb0 - g.cb1) + c2) * plane;
+    }
     float *dst = smem + pf_stage * STAGE + dch * RCST;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -194,9 +220,27 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       if (pf_live) pf_plan();
     }
   };
+  // VOL: the U of the steps, two 1 KB pieces per wave, one step behind the raw ring
+  int uq_chunk = 0, uq_stage = 0, uq_left = 0;
+  auto uq_issue = [&]() {
+    if constexpr (VOL) {
+      if (uq_left <= 0) return;
+      --uq_left;
+      const float *src = upk + (size_t)uq_chunk * UST + wave * 512 + lane * 4;
+      float *dst = U + uq_stage * UST + wave * 512;
+      __builtin_amdgcn_global_load_lds(WN_GPTR(src), WN_LPTR(dst), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(WN_GPTR(src + 256), WN_LPTR(dst + 256), 16, 0, 0);
+      uq_stage = uq_stage + 1 == NSTAGE ? 0 : uq_stage + 1;
+      uq_chunk = uq_chunk + 1 == nsteps ? 0 : uq_chunk + 1;
+    }
+  };
   if (pf_live) pf_plan();
+  if constexpr (VOL) uq_left = slot < total ? ((total - slot + G - 1) / G) * nsteps : 0;
 #pragma unroll
-  for (int i = 0; i < NSTAGE; ++i) pf_issue();
+  for (int i = 0; i < NSTAGE; ++i) {
+    pf_issue();
+    if (i < NSTAGE - 1) uq_issue();
+  }
   WN_STAMP();   // prologue
 
   const int pcol = lane & 15, kc = lane >> 4;   // this lane's patch column / channel within the chunk; patch row = wave
@@ -207,10 +251,12 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
 
   // wait until this wave's DMA pieces of a step have landed, `younger` later steps having been issued since
   // (vmcnt retires in order; waves 0-3 issue two pieces per step, waves 4-7 one)
+  constexpr int PERV = PER + (VOL ? 2 : 0);   // + the step's two U pieces
+  static_assert(!VOL || EVEN, "volume form: every wave issues the same number of pieces");
   auto wait_landed = [&](int younger) {
 #define WN_WAIT_CASE(K)                                                              \
   case K:                                                                            \
-    if (EVEN) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER * (K)) : "memory");         \
+    if (EVEN) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PERV * (K)) : "memory");        \
     else if (wave < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (K)) : "memory"); \
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory");                       \
     break;
@@ -225,7 +271,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     }
 #undef WN_WAIT_CASE
   };
-  static_assert(NSTAGE - 1 <= 5 && PER * 5 <= 63, "wait_landed covers up to 5 younger steps within the vmcnt range");
+  static_assert(NSTAGE - 1 <= 5 && PERV * 5 <= 63, "wait_landed covers up to 5 younger steps within the vmcnt range");
 
   // ---- MODE 1: the previous layer's LeakyReLU(GroupNorm(.)) is applied IN LDS by the wave that fetched a piece,
   // once per element, between the piece's arrival and the barrier that publishes the step (the patches overlap
@@ -240,7 +286,12 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       const int flat = xf_round * G + slot;
       xf_on = flat < total;
       if (!xf_on) return;
-      const int n = flat / g.tiles, tile = flat - n * g.tiles;
+      const int n = flat / ptiles;
+      int tile = flat - n * ptiles, z = 0;
+      if constexpr (VOL) {
+        z = tile / g.tiles;
+        tile -= z * g.tiles;
+      }
       if (xf_chunk == 0) {
         const int tyi = wdiv(tile, g.fd_ntx), txi = tile - tyi * g.ntx;
         const int y0 = tyi * WN_TY, x0 = txi * WN_TX;
@@ -253,8 +304,14 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
           if (i < dpn && e < GROUPS && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) xf_mask |= 1u << i;
         }
       }
-      const int c = xf_chunk * (KS * 4) + dch;   // wave-uniform: scalar loads
-      if (c < g.cin) {
+      int c = xf_chunk * (KS * 4) + dch;   // wave-uniform: scalar loads
+      bool live = c < g.cin;
+      if constexpr (VOL) {   // planes outside the volume keep their zeros
+        const int zz = z + (xf_chunk >> 2) - 1;
+        c = (xf_chunk & 3) * 8 + dch;
+        live = zz >= 0 && zz < g.D;
+      }
+      if (live) {
         const float mean = in_stats[((size_t)n * 4 + (c >> 3)) * 2 + 0];
         const float rstd = in_stats[((size_t)n * 4 + (c >> 3)) * 2 + 1];
         xf_sc = rstd * in_gamma[c];
@@ -358,7 +415,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
 
   // ---- a finished tile: output transform, bias, stores, GroupNorm partials
   floatx4 acc[16][2];
-  auto finish_tile = [&](int n, int tile_id, int y0, int x0) {
+  auto finish_tile = [&](int n, int z, int tile_id, int y0, int x0) {
     // lane: cout t*16 + (lane&15); patches p = 4*(lane>>4) + r of patch row `wave`: output rows ya, ya + DIL and
     // columns xa(p), xa(p) + DIL.  Whatever the dilation, the eight columns of a lane's four patches form two
     // aligned groups of four consecutive columns: element (r, second) goes to slot k of group h.
@@ -371,7 +428,8 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     const int xg1 = xg0 + (DIL == 8 ? 8 : 4);
     const bool row0 = oy < g.H, row1 = oy + DIL < g.H;
     const bool q0 = x0 + xg0 < g.W, q1 = x0 + xg1 < g.W;   // W % 4 == 0: each float4 is all inside or all outside
-    float *outn = out + (size_t)n * 32 * plane;
+    const size_t cstride = VOL ? (size_t)g.D * plane : plane;   // output channel stride
+    float *outn = out + (size_t)n * 32 * cstride + (size_t)z * plane;
     const int cnt = ((row0 ? 1 : 0) + (row1 ? 1 : 0)) * ((q0 ? 4 : 0) + (q1 ? 4 : 0));
     float s[2] = {0.f, 0.f};
     float y[2][2][8];   // [t][row][group * 4 + slot]
@@ -391,7 +449,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         y[t][1][slot_h(r, 0) * 4 + slot_k(r, 0)] = s1[0] + s1[1] + s1[2] + bv;
         y[t][1][slot_h(r, 1) * 4 + slot_k(r, 1)] = s1[1] - s1[2] - s1[3] + bv;
       }
-      float *oc = outn + (size_t)(t * 16 + cl) * plane + (size_t)oy * g.W + x0;
+      float *oc = outn + (size_t)(t * 16 + cl) * cstride + (size_t)oy * g.W + x0;
 #pragma unroll
       for (int rr = 0; rr < 2; ++rr) {
         const bool rok = rr ? row1 : row0;
@@ -444,7 +502,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
 #pragma unroll
       for (int t = 0; t < 2; ++t) qv[t] = group_sum(qv[t]);
       if ((lane & 0x37) == 0) {   // lanes 0 and 8
-        float *rec = out_partials + (((size_t)n * g.tiles + tile_id) * WN_WAVES + wave) * 12;
+        float *rec = out_partials + (((size_t)n * ptiles + (size_t)z * g.tiles + tile_id) * WN_WAVES + wave) * 12;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           rec[(t * 2 + hi) * 3 + 0] = npos;
@@ -455,10 +513,15 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     }
   };
 
-  int step = 0;
+  int step = 0, mm_stage = 0;   // mm_stage: U ring slot of `step` (VOL)
   for (int round = 0; round < my_items; ++round) {
     const int flat = round * G + slot;
-    const int n = flat / g.tiles, tile_id = flat - n * g.tiles;
+    const int n = flat / ptiles;
+    int tile_id = flat - n * ptiles, z = 0;
+    if constexpr (VOL) {
+      z = tile_id / g.tiles;
+      tile_id -= z * g.tiles;
+    }
     const int tyi = wdiv(tile_id, g.fd_ntx), txi = tile_id - tyi * g.ntx;
     const int y0 = tyi * WN_TY, x0 = txi * WN_TX;
 
@@ -484,7 +547,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       auto multiply = [&](auto first, auto hc) {   // one k-step: 16 coefficient GEMMs x 2 cout tiles
         constexpr bool FIRST = decltype(first)::value;
         constexpr int h = decltype(hc)::value;
-        const float *ub = U + (chunk * KS + h) * WN_UFLOATS + lane;
+        const float *ub = U + (VOL ? mm_stage : chunk) * UST + h * WN_UFLOATS + lane;
         float fb[2][2];
         fb[0][0] = ub[0], fb[0][1] = ub[64];
 #pragma unroll
@@ -501,7 +564,10 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
             acc[xi][0] = mfma16x16x4(v[h][xi], fb[cur][0], acc[xi][0]);
             acc[xi][1] = mfma16x16x4(v[h][xi], fb[cur][1], acc[xi][1]);
           }
-          if (h == 0 && xi == 1 && has_next) pf_issue();   // step + NSTAGE into the stage `step` released, behind the first MFMAs
+          if (h == 0 && xi == 1 && has_next) {   // behind the first MFMAs:
+            pf_issue();   // raw tile of step + NSTAGE into the stage `step` released
+            uq_issue();   // VOL: U of step + NSTAGE - 1 into the slot step - 1 released
+          }
         }
       };
       if (chunk == 0) multiply(std::true_type{}, std::integral_constant<int, 0>{});   // uniform
@@ -511,22 +577,32 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
           multiply(std::false_type{}, std::integral_constant<int, 1>{});
       }
       if (has_next) tr_finish(dna, dnb, v);   // v: A fragments of step + 1 (written after the last MFMA read it)
+      if constexpr (VOL) mm_stage = mm_stage + 1 == NSTAGE ? 0 : mm_stage + 1;
       WN_STAMP();   // MFMAs issued + next transform
     }
-    finish_tile(n, tile_id, y0, x0);
+    finish_tile(n, z, tile_id, y0, x0);
   }
 }
 
 bool wino_geom(const mvsn_conv_desc *d, WinoGeom *g) {
   if (!d || d->precision != MVSN_CONV_FP32_WINO) return false;
-  if (d->n <= 0 || d->c_in <= 0 || d->c_out != 32 || d->depth != 1 || d->rows <= 0 || d->cols <= 0) return false;
-  if (d->kd != 1 || d->kh != 3 || d->kw != 3 || d->stride != 1) return false;
+  if (d->n <= 0 || d->c_in <= 0 || d->c_out != 32 || d->depth < 1 || d->rows <= 0 || d->cols <= 0) return false;
+  if ((d->kd != 1 && d->kd != 3) || d->kh != 3 || d->kw != 3 || d->stride != 1) return false;
+  if (d->kd == 1 && d->depth != 1) return false;
   if (d->dilation != 1 && d->dilation != 2 && d->dilation != 4 && d->dilation != 8) return false;
   if (d->cols % 4 != 0) return false;
   g->n = d->n, g->cin = d->c_in, g->H = d->rows, g->W = d->cols, g->dil = d->dilation;
+  g->D = d->depth, g->vol = d->kd == 3;
   g->nty = (d->rows + WN_TY - 1) / WN_TY;
   g->ntx = (d->cols + WN_TX - 1) / WN_TX;
   g->tiles = g->nty * g->ntx;
+  if (g->vol) {   // volume form: 32 -> 32 channels, dilation 1; U streams, 3 x 8 chunks
+    if (d->c_in != 32 || d->dilation != 1) return false;
+    if ((long)d->depth * g->tiles > 1L << 24) return false;
+    g->nchunks = 24;
+    g->packed_floats = (size_t)g->nchunks * WN_UFLOATS;
+    return true;
+  }
   g->nchunks = (d->c_in + 3) / 4;
   if (g->nchunks > WN_MAX_CHUNKS) return false;   // U must stay resident in LDS
   if (g->nchunks > 8 && d->dilation > 2) return false;   // ... next to the (larger) raw-tile ring of dilation 4 / 8
@@ -540,7 +616,7 @@ int wino_pack(const mvsn_conv_desc *d, const float *weight, float *packed, hipSt
   if (!wino_geom(d, &g)) return MVSN_E_BADARG;
   const int total = g.nchunks * WN_UFLOATS;
   hipLaunchKernelGGL(wino_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, weight, g.cin, 32, g.nchunks,
-                     packed);
+                     g.vol ? 3 : 1, packed);
   return check_launch("mvsn_conv_pack_weights(winograd)");
 }
 
@@ -551,6 +627,7 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   a.n = g.n, a.cin = g.cin, a.H = g.H, a.W = g.W, a.ntx = g.ntx, a.tiles = g.tiles, a.nchunks = g.nchunks;
   a.fd_ntx = wino_div((unsigned)g.ntx);
   a.cb0 = g.cin, a.cb1 = 0, a.in1 = a.in2 = in;
+  a.D = g.D;
   if (blocks) a.cb0 = blocks->cb0, a.cb1 = blocks->cb1, a.in1 = blocks->in1, a.in2 = blocks->in2;
   static int cus = 0;
   if (cus == 0) {
@@ -561,10 +638,12 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   }
   // (k-steps per step, ring depth) by what fits next to the resident U: the raw tile grows with the dilation
   //   dilation 1: 2 k-steps x 4 stages (94 KB); 2, 4: 2 x 3 (78 / 94 KB); 8: 1 x 3 (74 KB); 4-channel head: 1 x 6
+  //   volume form: 2 x 3 raw stages + 3 stages of U (118 KB)
   const bool head = g.nchunks == 1;
   const int ks = (head || g.dil == 8) ? 1 : 2;
   const int nstage = head ? 6 : ((g.dil == 1 && g.nchunks <= 8) ? 4 : 3);
-  const size_t lds = ((size_t)nstage * ks * 4 * wn_rcst(g.dil) + (size_t)g.nchunks * WN_UFLOATS) * sizeof(float);
+  const size_t lds = ((size_t)nstage * ks * 4 * wn_rcst(g.dil) +
+                      (g.vol ? (size_t)nstage * ks : (size_t)g.nchunks) * WN_UFLOATS) * sizeof(float);
   if (head && g.dil != 1) {
     set_error("mvsn_conv_forward(winograd): dilated 4-channel layers are not instantiated");
     return MVSN_E_BADARG;
@@ -574,11 +653,11 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
     return MVSN_E_TOOLARGE;
   }
   dim3 grid(1);
-#define WN_CASE(M, K, N, D)                                                                                        \
+#define WN_CASE(M, K, N, D, ...)                                                                                   \
   do {                                                                                                             \
     static size_t opted = 0;                                                                                       \
     if (lds > opted) {                                                                                             \
-      hipError_t e = hipFuncSetAttribute((const void *)conv_wino_kernel<M, K, N, D>,                               \
+      hipError_t e = hipFuncSetAttribute((const void *)conv_wino_kernel<M, K, N, D, ##__VA_ARGS__>,                \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
       if (e != hipSuccess) {                                                                                       \
         set_error("mvsn_conv_forward(winograd): LDS opt-in of %zu bytes failed: %s", lds, hipGetErrorString(e));   \
@@ -586,13 +665,15 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
       }                                                                                                            \
       opted = lds;                                                                                                 \
     }                                                                                                              \
-    hipLaunchKernelGGL((conv_wino_kernel<M, K, N, D>), grid, dim3(WN_THREADS), lds, stream, a, in, upk, bias,      \
+    hipLaunchKernelGGL((conv_wino_kernel<M, K, N, D, ##__VA_ARGS__>), grid, dim3(WN_THREADS), lds, stream, a, in,  \
+                       upk, bias,                                                                                  \
                        in_stats, in_gamma, in_beta, out, out_partials);                                            \
   } while (0)
-  const long total = (long)g.n * g.tiles;
+  const long total = (long)g.n * g.D * g.tiles;
   grid = dim3((unsigned)(total < cus ? total : cus));   // persistent: one workgroup per CU walks items grid-strided
   const bool xf = in_stats != nullptr;
-  if (head) { if (xf) WN_CASE(1, 1, 6, 1); else WN_CASE(0, 1, 6, 1); }
+  if (g.vol) { if (xf) WN_CASE(1, 2, 3, 1, true); else WN_CASE(0, 2, 3, 1, true); }
+  else if (head) { if (xf) WN_CASE(1, 1, 6, 1); else WN_CASE(0, 1, 6, 1); }
   else if (g.dil == 1 && g.nchunks > 8) { if (xf) WN_CASE(1, 2, 3, 1); else WN_CASE(0, 2, 3, 1); }
   else if (g.dil == 1) { if (xf) WN_CASE(1, 2, 4, 1); else WN_CASE(0, 2, 4, 1); }
   else if (g.dil == 2) { if (xf) WN_CASE(1, 2, 3, 2); else WN_CASE(0, 2, 3, 2); }

@@ -66,7 +66,7 @@ class _Conv:
         # third packing: Winograd F(2x2,3x3) coefficients for the 2-D 3x3 stride-1 dilation-1 layers
         self.packed_wino = None
         dwn = self.desc(1, 1, 8, 32, _native.CONV_FP32_WINO)
-        if self.dims == 2 and lib.mvsn_conv_winograd_supported(ctypes.byref(dwn)):
+        if lib.mvsn_conv_winograd_supported(ctypes.byref(dwn)):
             nwn = lib.mvsn_conv_packed_floats(ctypes.byref(dwn))
             self.packed_wino = torch.empty(nwn, dtype=torch.float32, device=weight.device)
             _native.check(lib.mvsn_conv_pack_weights(ctypes.byref(dwn), _native.ptr(w), _native.ptr(self.packed_wino),
@@ -103,6 +103,8 @@ class PlaneSweepEngine:
         self.winograd = True
         # ... also where the previous layer's LeakyReLU(GN(.)) is applied on load (in LDS, by the fetching wave)
         self.winograd_with_input_transform = True
+        # ... and the 3x3x3 layers of the cost-volume regulariser as 2-D Winograd products summed over the depth tap
+        self.winograd_volume = True
         # Skip the stand-alone normalise/activate pass at both ends of a refiner tower (see
         # residual_tower_unfused); False keeps one pass per block (tests compare the two).
         self.trim_tower_ends = True
@@ -177,7 +179,8 @@ class PlaneSweepEngine:
             if lib.mvsn_conv_bf16x3_supported(ctypes.byref(dbx)):
                 d, packed = dbx, c.packed_bx
         elif self.winograd and c.packed_wino is not None and in_residual is None and not write_staged and \
-                (in_stats is None or self.winograd_with_input_transform):
+                (in_stats is None or self.winograd_with_input_transform) and \
+                (c.dims == 2 or self.winograd_volume):
             dwn = c.desc(n, depth, rows, cols, _native.CONV_FP32_WINO)
             if lib.mvsn_conv_winograd_supported(ctypes.byref(dwn)):
                 d, packed = dwn, c.packed_wino

@@ -188,6 +188,41 @@ def test_conv_winograd_form(cin, rows, cols, n, dil):
         close(out2, ref2, rtol=1e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("depth,rows,cols,n", [(8, 16, 32, 2), (5, 9, 36, 1), (64, 16, 32, 1), (3, 37, 68, 2), (1, 16, 32, 2),
+                                               (2, 8, 12, 3), (16, 16, 32, 20)])
+def test_conv_winograd_volume_form(depth, rows, cols, n):
+    """3x3x3 32->32 layers as 2-D Winograd products summed over the depth tap (MVSN_CONV_FP32_WINO with kd = 3):
+    values and GroupNorm statistics against ATen and the direct fp32 kernel, plus the fused input transform."""
+    from multi_view_stereonet_amd.multi_view_stereonet import _Conv, _Norm
+    eng = net_for("gta_sfm_150epochs").engine()
+    g = torch.Generator().manual_seed(depth * 100 + rows)
+    w = torch.randn(32, 32, 3, 3, 3, generator=g) * 0.06
+    b = torch.randn(32, generator=g) * 0.1
+    x = torch.randn(n, 32, depth, rows, cols, generator=g)
+    c = _Conv(eng.lib, w.to(DEV), b.to(DEV))
+    assert c.packed_wino is not None
+    eng.winograd_volume = True
+    out, stats = eng.conv(c, x.to(DEV), want_stats=True)
+    eng.winograd_volume = False
+    out_d, stats_d = eng.conv(c, x.to(DEV), want_stats=True)
+    eng.winograd_volume = True
+    ref = F.conv3d(x, w, b, padding=1)
+    close(out, ref, rtol=1e-4, atol=1e-4)
+    assert rel_err(out.cpu(), out_d.cpu())[0] < 2e-6      # mean-rel vs the direct kernel: rounding only
+    rg = ref.reshape(n, 4, -1).double()
+    close(stats[:, :, 0], rg.mean(2), rtol=1e-4, atol=1e-5)
+    close(stats[:, :, 1], 1.0 / (rg.var(2, unbiased=False) + 1e-5).sqrt(), rtol=1e-4, atol=1e-5)
+    gamma, beta = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.1
+
+    class P:
+        weight, bias = gamma.to(DEV), beta.to(DEV)
+    xg = x.reshape(n, 4, -1).double()
+    st_in = torch.stack([xg.mean(2), 1.0 / (xg.var(2, unbiased=False) + 1e-5).sqrt()], 2).float().contiguous()
+    out2, _ = eng.conv(c, x.to(DEV), in_stats=st_in.to(DEV), in_norm=_Norm(P))
+    ref2 = F.conv3d(F.leaky_relu(F.group_norm(x, 4, gamma, beta, 1e-5), 0.2), w, b, padding=1)
+    close(out2, ref2, rtol=1e-4, atol=2e-4)
+
+
 @pytest.mark.parametrize("split,rows,cols,n", [((3, 32, 1), 40, 72, 2), ((3, 1), 64, 128, 3), ((35, 1), 16, 32, 2),
                                                ((3, 32, 1), 128, 256, 5), ((36,), 24, 40, 1), ((4, 4, 4), 33, 52, 2)])
 def test_conv_channel_blocks(split, rows, cols, n):
