@@ -137,8 +137,10 @@ typedef struct {
  *   MVSN_CONV_FP32_WINO  the same fp32 MFMA arithmetic on the Winograd F(2x2,3x3) form of the layer: 16
  *                     products per 2x2 outputs and (cin, cout) pair instead of 36; every operand and
  *                     accumulation is fp32, the result differs from MVSN_CONV_FP32 by rounding only (~1e-6
- *                     relative).  Only 2-D 3x3 stride-1 dilation-1 layers with 32 output channels and
- *                     cols % 4 == 0 (mvsn_conv_winograd_supported); weights are packed per form.
+ *                     relative).  2-D 3x3 stride-1 layers with 32 output channels, dilation 1/2/4/8, and the
+ *                     3x3x3 32 -> 32 layers (volume form: 2-D Winograd products summed over the depth tap, 12
+ *                     multiplies per output instead of 27), cols % 4 == 0 (mvsn_conv_winograd_supported);
+ *                     weights are packed per form.
  *   MVSN_CONV_BF16    plain bf16 operands (the hi halves only), fp32 accumulation, on the same kernels and packed
  *                     weights as MVSN_CONV_BF16X3: BASELINE config 5's speed tier.  ~2^-9 relative per operand:
  *                     the final depth lands OUTSIDE the 1e-3 parity contract (measured ~2e-3 mean-rel). */

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Tuning aid: s_memtime phase stamps of one mid-launch wave of the Winograd conv kernel
-(build with MVSN_HIPCC_FLAGS=-DMVSN_WN_STAMPS).  Usage: wino_phases.py [batch]"""
+(build with MVSN_HIPCC_FLAGS=-DMVSN_WN_STAMPS).  Usage: wino_phases.py [batch] [vol]
+(vol: the 3x3x3 regulariser layer on (2*batch, 32, 64, 16, 32) instead of the level-0 refiner layer)"""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multi_view_stereonet_amd import MultiViewStereoNet
@@ -11,8 +12,12 @@ eng = net.engine()
 dbg = torch.zeros(64, dtype=torch.int64, device="cuda")
 eng.lib.mvsn_debug_set_wino_stamps.argtypes = [ctypes.c_void_p]
 assert eng.lib.mvsn_debug_set_wino_stamps(dbg.data_ptr()) == 0
-conv, norm = eng.refiners[0]["res"][0]
-x = torch.randn(B, 32, 256, 512, device="cuda")
+if len(sys.argv) > 2 and sys.argv[2] == "vol":
+    conv = eng.vf_convs[1]
+    x = torch.randn(2 * B, 32, 64, 16, 32, device="cuda")
+else:
+    conv, norm = eng.refiners[0]["res"][0]
+    x = torch.randn(B, 32, 256, 512, device="cuda")
 for it in range(3):
     dbg.zero_()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -22,5 +27,5 @@ for it in range(3):
     d = [t[i + 1] - t[i] for i in range(n - 1)]
     print("launch %.3f ms, wave total %d cycles; prologue %d; per step [landed, barrier, mfma + DMA issue + next transform]; epilogue %d" %
           (a.elapsed_time(b), t[n - 1] - t[0], d[0], d[-1]))
-    for i in range(1, min(len(d) - 1, 34), 3):
+    for i in range(1, min(len(d) - 1, 58), 3):
         print("   ", d[i:i + 3])
