@@ -52,6 +52,14 @@ __device__ floatx4 g_wn_zero16 = {0.f, 0.f, 0.f, 0.f};
 #define WN_GPTR(p) ((const __attribute__((address_space(1))) void *)(p))
 #define WN_LPTR(p) ((__attribute__((address_space(3))) void *)(p))
 
+#ifndef MVSN_WN_ABLATE   // tuning aid: bit 0 no input transform, 1 no U fragment reads, 2 no DMA in the loop, 3 no barrier, 4 no epilogue, 5 no raw reads
+#define MVSN_WN_ABLATE 0
+#endif
+
+#ifndef MVSN_WN_SHIFT
+#define MVSN_WN_SHIFT 1
+#endif
+
 #ifdef MVSN_WN_STAMPS   // tuning aid (tools/wino_phases.py): s_memtime stamps of one mid-launch wave
 __device__ unsigned long long *g_wn_stamps = nullptr;
 #define WN_STAMP() do { if (dbg && dbg_i < 60) dbg[dbg_i++] = __builtin_readcyclecounter(); } while (0)
@@ -127,6 +135,8 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   constexpr int RCST = wn_rcst(DIL);
   constexpr int STAGE = KS * 4 * RCST;               // ring stage (floats)
   float *U = smem + NSTAGE * STAGE;                  // nchunks * WN_UFLOATS, resident (VOL: ring of NSTAGE steps)
+  // dilation 1: raw tiles stored one float further (4-byte-aligned DMA destination), see tr_load
+  constexpr int SHIFT = (DIL == 1 && MVSN_WN_SHIFT) ? 1 : 0;
   constexpr int UST = KS * WN_UFLOATS;               // U of one step (floats)
   static_assert(!VOL || (KS == 2 && DIL == 1), "volume form: 32 channels in steps of 8, dilation 1");
   const int nsteps = (g.nchunks + KS - 1) / KS;      // steps per tile
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
           : c2 < 0 ? g.in1 + ((size_t)pf_n * g.cb1 + c1) * plane
                    : g.in2 + ((size_t)pf_n * (g.cin - g.cb0 - g.cb1) + c2) * plane;
     }
-    float *dst = smem + pf_stage * STAGE + dch * RCST;
+    float *dst = smem + pf_stage * STAGE + dch * RCST + SHIFT;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       if (i < dpn) {   // uniform
@@ -324,14 +334,22 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   auto xf_apply = [&]() {          // ... applied to this wave's landed pieces; then the side moves on one step
     if constexpr (MODE == 1) {
       if (xf_on) {
-        float *dst = smem + xf_stage * STAGE + dch * RCST + lane * 4;
+        float *dst = smem + xf_stage * STAGE + dch * RCST + lane * 4 + SHIFT;
 #pragma unroll
         for (int i = 0; i < PER; ++i)
           if ((xf_mask >> i) & 1u) {
-            floatx4 v = *reinterpret_cast<floatx4 *>(dst + (dp0 + i) * 256);
+            float *q = dst + (dp0 + i) * 256;
+            if constexpr (SHIFT) {   // the shifted tile is only 4-byte aligned: dword pairs
+              float e[4] = {q[0], q[1], q[2], q[3]};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = lrelu02(v[r] * xf_sc + xf_sh);
-            *reinterpret_cast<floatx4 *>(dst + (dp0 + i) * 256) = v;
+              for (int r = 0; r < 4; ++r) e[r] = lrelu02(e[r] * xf_sc + xf_sh);
+              q[0] = e[0], q[1] = e[1], q[2] = e[2], q[3] = e[3];
+            } else {
+              floatx4 v = *reinterpret_cast<floatx4 *>(q);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = lrelu02(v[r] * xf_sc + xf_sh);
+              *reinterpret_cast<floatx4 *>(q) = v;
+            }
           }
       }
       xf_stage = xf_stage + 1 == NSTAGE ? 0 : xf_stage + 1;
@@ -344,13 +362,24 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   auto tr_setup = [&]() {};   // (nothing per tile on this side: MODE 1 is applied in LDS by the fetching wave)
   // the 4 x 4 patch of (channel kc, patch pcol of patch row wave) of the transform side's step, transformed:
   // the result IS the A fragment of the 16 coefficient GEMMs
-  // raw patch as loaded: da = columns (0, 2), db = columns (1, 3) of each row -- the register pairs the
-  // ds_read2_b32 produce, consumed in place (no re-interleaving moves)
-  auto tr_load = [&](float (&da)[KS][4][2], float (&db)[KS][4][2]) {
+  // raw patch as loaded, d[h][row][slot]:
+  //   SHIFT (dilation 1): the tile sits one float further in LDS, so a patch starts at an even column and a row is
+  //   two aligned 8-byte reads (one ds_read2_b64, all 32 banks busy); slot = column;
+  //   otherwise: slots (0, 1) = columns (0, 2), slots (2, 3) = columns (1, 3) -- the register pairs two
+  //   ds_read2_b32 produce, consumed in place (no re-interleaving moves).
+  auto dslot = [](int j) { return SHIFT ? j : (j & 1) * 2 + (j >> 1); };
+  auto tr_load = [&](float (&d)[KS][4][4]) {
 #pragma unroll
     for (int h = 0; h < KS; ++h) {
-      const float *raw = smem + tr_stage * STAGE + (h * 4 + kc) * RCST + ya * XS + xa + (PA - DIL);
-      if constexpr (DIL == 1) {
+      const float *raw = smem + tr_stage * STAGE + (h * 4 + kc) * RCST + ya * XS + xa + (PA - DIL) + SHIFT;
+      if constexpr (SHIFT) {
+        const float2 *r2 = reinterpret_cast<const float2 *>(raw);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float2 lo = r2[i * (XS / 2)], hi = r2[i * (XS / 2) + 1];
+          d[h][i][0] = lo.x, d[h][i][1] = lo.y, d[h][i][2] = hi.x, d[h][i][3] = hi.y;
+        }
+      } else if constexpr (DIL == 1) {
         // columns (0, 2) and (1, 3) from two bases the compiler cannot relate: it would otherwise fuse the
         // middle pair into a ds_read_b64 (three LDS instructions per row instead of two ds_read2_b32)
         int oa = 0, ob = 1;
@@ -358,26 +387,25 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         const float *ra = raw + oa, *rb = raw + ob;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          da[h][i][0] = ra[i * XS], da[h][i][1] = ra[i * XS + 2];
-          db[h][i][0] = rb[i * XS], db[h][i][1] = rb[i * XS + 2];
+          d[h][i][0] = ra[i * XS], d[h][i][1] = ra[i * XS + 2];
+          d[h][i][2] = rb[i * XS], d[h][i][3] = rb[i * XS + 2];
         }
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          da[h][i][0] = raw[i * DIL * XS], da[h][i][1] = raw[i * DIL * XS + 2 * DIL];
-          db[h][i][0] = raw[i * DIL * XS + DIL], db[h][i][1] = raw[i * DIL * XS + 3 * DIL];
+          d[h][i][0] = raw[i * DIL * XS], d[h][i][1] = raw[i * DIL * XS + 2 * DIL];
+          d[h][i][2] = raw[i * DIL * XS + DIL], d[h][i][3] = raw[i * DIL * XS + 3 * DIL];
         }
       }
     }
   };
-  auto tr_finish = [&](float (&da)[KS][4][2], float (&db)[KS][4][2], float (&v)[KS][16]) {
+  auto tr_finish = [&](float (&d)[KS][4][4], float (&v)[KS][16]) {
 #pragma unroll
     for (int h = 0; h < KS; ++h) {
       float t[4][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float d0 = (j & 1) ? db[h][0][j >> 1] : da[h][0][j >> 1], d1 = (j & 1) ? db[h][1][j >> 1] : da[h][1][j >> 1];
-        const float d2 = (j & 1) ? db[h][2][j >> 1] : da[h][2][j >> 1], d3 = (j & 1) ? db[h][3][j >> 1] : da[h][3][j >> 1];
+        const float d0 = d[h][0][dslot(j)], d1 = d[h][1][dslot(j)], d2 = d[h][2][dslot(j)], d3 = d[h][3][dslot(j)];
         t[0][j] = d0 - d2;
         t[1][j] = d1 + d2;
         t[2][j] = d2 - d1;
@@ -408,9 +436,9 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     xf_apply();        // step 0
     xf_prepare();      // step 1
     __syncthreads();   // step 0 (and U) visible to everyone
-    float a0[KS][4][2], b0[KS][4][2];
-    tr_load(a0, b0);
-    tr_finish(a0, b0, v);
+    float d0[KS][4][4];
+    tr_load(d0);
+    tr_finish(d0, v);
   }
 
   // ---- a finished tile: output transform, bias, stores, GroupNorm partials
@@ -537,13 +565,13 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         wait_landed(rest < 0 ? 0 : (rest < NSTAGE - 2 ? rest : NSTAGE - 2));   // step + 1 has landed
         xf_apply();        // step + 1
         WN_STAMP();   // landed
-        __syncthreads();   // ... for everyone; everyone has read the raw tile of `step`
+        if (!(MVSN_WN_ABLATE & 8)) __syncthreads();   // ... for everyone; everyone has read the raw tile of `step`
         WN_STAMP();   // barrier
         xf_prepare();      // step + 2: its scalar loads travel behind this step's multiplies
       }
       // multiplies of `step` with the transform of `step + 1` slotted between them
-      float dna[KS][4][2], dnb[KS][4][2];
-      if (has_next) tr_load(dna, dnb);
+      float dn[KS][4][4];
+      if (has_next && !(MVSN_WN_ABLATE & 32)) tr_load(dn);
       auto multiply = [&](auto first, auto hc) {   // one k-step: 16 coefficient GEMMs x 2 cout tiles
         constexpr bool FIRST = decltype(first)::value;
         constexpr int h = decltype(hc)::value;
@@ -553,7 +581,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {   // next coefficient's U fragments in flight behind this one's MFMAs
           const int cur = xi & 1;
-          if (xi + 1 < 16) {
+          if (xi + 1 < 16 && !(MVSN_WN_ABLATE & 2)) {
             fb[cur ^ 1][0] = ub[(xi + 1) * 128];
             fb[cur ^ 1][1] = ub[(xi + 1) * 128 + 64];
           }
@@ -564,7 +592,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
             acc[xi][0] = mfma16x16x4(v[h][xi], fb[cur][0], acc[xi][0]);
             acc[xi][1] = mfma16x16x4(v[h][xi], fb[cur][1], acc[xi][1]);
           }
-          if (h == 0 && xi == 1 && has_next) {   // behind the first MFMAs:
+          if (h == 0 && xi == 1 && has_next && !(MVSN_WN_ABLATE & 4)) {   // behind the first MFMAs:
             pf_issue();   // raw tile of step + NSTAGE into the stage `step` released
             uq_issue();   // VOL: U of step + NSTAGE - 1 into the slot step - 1 released
           }
@@ -576,11 +604,11 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         if (chunk * KS + 1 < g.nchunks)   // uniform: odd chunk count, nothing in the second half
           multiply(std::false_type{}, std::integral_constant<int, 1>{});
       }
-      if (has_next) tr_finish(dna, dnb, v);   // v: A fragments of step + 1 (written after the last MFMA read it)
+      if (has_next && !(MVSN_WN_ABLATE & 1)) tr_finish(dn, v);   // v: A fragments of step + 1 (written after the last MFMA read it)
       if constexpr (VOL) mm_stage = mm_stage + 1 == NSTAGE ? 0 : mm_stage + 1;
       WN_STAMP();   // MFMAs issued + next transform
     }
-    finish_tile(n, z, tile_id, y0, x0);
+    if (!(MVSN_WN_ABLATE & 16) || n < 0) finish_tile(n, z, tile_id, y0, x0);
   }
 }
 

@@ -21,7 +21,12 @@ else:
 for it in range(3):
     dbg.zero_()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record(); r, st = eng.conv(conv, x, want_stats=True); b.record(); torch.cuda.synchronize()
+    if "xf" in sys.argv:   # with the fused input transform (MODE 1)
+        st_in = torch.zeros(x.shape[0], 4, 2, device="cuda"); st_in[:, :, 1] = 1
+        a.record(); r, st = eng.conv(conv, x, in_stats=st_in, in_norm=eng.vf_norms[0], want_stats=True); b.record()
+    else:
+        a.record(); r, st = eng.conv(conv, x, want_stats=True); b.record()
+    torch.cuda.synchronize()
     t = dbg.cpu().tolist()
     n = sum(1 for v in t if v)
     d = [t[i + 1] - t[i] for i in range(n - 1)]
