@@ -137,6 +137,9 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   float *U = smem + NSTAGE * STAGE;                  // nchunks * WN_UFLOATS, resident (VOL: ring of NSTAGE steps)
   // dilation 1: raw tiles stored one float further (4-byte-aligned DMA destination), see tr_load
   constexpr int SHIFT = (DIL == 1 && MVSN_WN_SHIFT) ? 1 : 0;
+  // dilated layers: a half-wave reads two channels whose strided columns fall on the same half of the banks;
+  // odd channels are stored DIL floats further, which moves them to the other half (conflict-free)
+  constexpr int CSHIFT = (DIL > 1 && MVSN_WN_SHIFT) ? DIL : 0;
   constexpr int UST = KS * WN_UFLOATS;               // U of one step (floats)
   static_assert(!VOL || (KS == 2 && DIL == 1), "volume form: 32 channels in steps of 8, dilation 1");
   const int nsteps = (g.nchunks + KS - 1) / KS;      // steps per tile
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
           : c2 < 0 ? g.in1 + ((size_t)pf_n * g.cb1 + c1) * plane
                    : g.in2 + ((size_t)pf_n * (g.cin - g.cb0 - g.cb1) + c2) * plane;
     }
-    float *dst = smem + pf_stage * STAGE + dch * RCST + SHIFT;
+    float *dst = smem + pf_stage * STAGE + dch * RCST + SHIFT + CSHIFT * (dch & 1);
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       if (i < dpn) {   // uniform
@@ -334,12 +337,12 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   auto xf_apply = [&]() {          // ... applied to this wave's landed pieces; then the side moves on one step
     if constexpr (MODE == 1) {
       if (xf_on) {
-        float *dst = smem + xf_stage * STAGE + dch * RCST + lane * 4 + SHIFT;
+        float *dst = smem + xf_stage * STAGE + dch * RCST + lane * 4 + SHIFT + CSHIFT * (dch & 1);
 #pragma unroll
         for (int i = 0; i < PER; ++i)
           if ((xf_mask >> i) & 1u) {
             float *q = dst + (dp0 + i) * 256;
-            if constexpr (SHIFT) {   // the shifted tile is only 4-byte aligned: dword pairs
+            if constexpr (SHIFT || CSHIFT % 4 != 0) {   // the shifted tile is only 4- / 8-byte aligned: dword pairs
               float e[4] = {q[0], q[1], q[2], q[3]};
 #pragma unroll
               for (int r = 0; r < 4; ++r) e[r] = lrelu02(e[r] * xf_sc + xf_sh);
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   auto tr_load = [&](float (&d)[KS][4][4]) {
 #pragma unroll
     for (int h = 0; h < KS; ++h) {
-      const float *raw = smem + tr_stage * STAGE + (h * 4 + kc) * RCST + ya * XS + xa + (PA - DIL) + SHIFT;
+      const float *raw = smem + tr_stage * STAGE + (h * 4 + kc) * RCST + ya * XS + xa + (PA - DIL) + SHIFT + CSHIFT * (kc & 1);
       if constexpr (SHIFT) {
         const float2 *r2 = reinterpret_cast<const float2 *>(raw);
 #pragma unroll
