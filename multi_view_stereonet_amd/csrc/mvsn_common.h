@@ -36,6 +36,12 @@ __device__ __forceinline__ floatx4 mfma16x16x4(float a, float b, floatx4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// v from the lane a DPP control selects (quad_perm 0x00-0xFF, row_half_mirror 0x141, row_mirror 0x140, ...)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
 // LeakyReLU(0.2) as max(v, 0.2 v): two VALU instructions (multiply, max) instead of multiply / compare / select.
 // Identical for every finite v (0.2 v < v exactly when v > 0); -0.0 maps to -0.0 either way.
 __device__ __forceinline__ float lrelu02(float v) { return fmaxf(v, 0.2f * v); }

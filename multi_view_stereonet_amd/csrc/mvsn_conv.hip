@@ -719,44 +719,54 @@ __global__ __launch_bounds__(CV_THREADS, MODE <= 1 ? 4 : 2) void conv_dma_kernel
 #endif
 }
 
-// Chan et al. combination of per-tile (count, mean, M2) in double; one workgroup per (n, group).
+// Combination of the per-record (count, mean, M2) in double; one workgroup per sample, a thread reads whole 48-byte
+// records (all four groups), one pass:  N = sum c,  S = sum c*mean,  Q = sum (M2 + c*mean^2)  ->  var = Q/N - (S/N)^2
+// (the subtraction is done in double on sums of fp32 data: ~1e-16 relative, far below the fp32 inputs' own rounding).
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restrict__ partials, int tiles,
                                                           float *__restrict__ stats) {
-  const int n = blockIdx.x >> 2, grp = blockIdx.x & 3;
-  const int tid = threadIdx.x;
-  __shared__ double s_a[256], s_b[256];
-  const float *p = partials + ((size_t)n * tiles * 4 + grp) * 3;
-  double cnt = 0.0, sum = 0.0;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const floatx4 *p = reinterpret_cast<const floatx4 *>(partials + (size_t)n * tiles * 12);
+  double acc[4][3];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) acc[g][0] = acc[g][1] = acc[g][2] = 0.0;
   for (int t = tid; t < tiles; t += 256) {
-    const float *e = p + (size_t)t * 12;
-    cnt += (double)e[0];
-    sum += (double)e[0] * (double)e[1];
+    const floatx4 a = p[(size_t)t * 3], b = p[(size_t)t * 3 + 1], c = p[(size_t)t * 3 + 2];
+    const float e[12] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3]};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const double cnt = (double)e[g * 3], mean = (double)e[g * 3 + 1];
+      acc[g][0] += cnt;
+      acc[g][1] += cnt * mean;
+      acc[g][2] += (double)e[g * 3 + 2] + cnt * mean * mean;
+    }
   }
-  s_a[tid] = cnt, s_b[tid] = sum;
+  __shared__ double red[4][12];   // per wave
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      double v = acc[g][k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      acc[g][k] = v;
+    }
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) red[tid >> 6][g * 3 + k] = acc[g][k];
+  }
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) s_a[tid] += s_a[tid + s], s_b[tid] += s_b[tid + s];
-    __syncthreads();
-  }
-  const double N = s_a[0];
-  const double mean = s_b[0] / N;
-  __syncthreads();
-  double m2 = 0.0;
-  for (int t = tid; t < tiles; t += 256) {
-    const float *e = p + (size_t)t * 12;
-    const double dm = (double)e[1] - mean;
-    m2 += (double)e[2] + (double)e[0] * dm * dm;
-  }
-  s_a[tid] = m2;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) s_a[tid] += s_a[tid + s];
-    __syncthreads();
-  }
-  if (tid == 0) {
-    const double var = s_a[0] / N;
-    stats[((size_t)n * 4 + grp) * 2 + 0] = (float)mean;
-    stats[((size_t)n * 4 + grp) * 2 + 1] = (float)(1.0 / sqrt(var + (double)CV_EPS));
+  if (tid < 4) {
+    const int g = tid;
+    const double N = red[0][g * 3] + red[1][g * 3] + red[2][g * 3] + red[3][g * 3];
+    const double S = red[0][g * 3 + 1] + red[1][g * 3 + 1] + red[2][g * 3 + 1] + red[3][g * 3 + 1];
+    const double Q = red[0][g * 3 + 2] + red[1][g * 3 + 2] + red[2][g * 3 + 2] + red[3][g * 3 + 2];
+    const double mean = S / N;
+    double var = Q / N - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[((size_t)n * 4 + g) * 2 + 0] = (float)mean;
+    stats[((size_t)n * 4 + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)CV_EPS));
   }
 }
 
@@ -883,7 +893,7 @@ extern "C" int mvsn_conv_num_tiles(const mvsn_conv_desc *desc) {
   // number of GroupNorm partial records per sample: one per (tile, wave), 4 waves per workgroup tile
   if (desc && desc->precision == MVSN_CONV_FP32_WINO) {
     mvsn::WinoGeom wg;
-    return mvsn::wino_geom(desc, &wg) ? wg.D * wg.tiles * 8 : 0;   // 8 waves per workgroup tile (per plane)
+    return mvsn::wino_geom(desc, &wg) ? wg.D * wg.tiles * 32 : 0;   // per (plane,) tile: 8 waves x 4 lane rows
   }
   if (desc && (desc->precision == MVSN_CONV_BF16X3 || desc->precision == MVSN_CONV_BF16)) {
     mvsn::Bf16x3Geom bg;
@@ -1083,7 +1093,7 @@ extern "C" int mvsn_debug_set_dma_stamps(void *buf) {
 
 extern "C" int mvsn_groupnorm_finalize(const float *partials, int n, int tiles, float *stats, mvsn_stream_t stream) {
   MVSN_REQUIRE(partials && stats && n > 0 && tiles > 0, MVSN_E_BADARG, "mvsn_groupnorm_finalize: bad argument");
-  hipLaunchKernelGGL(mvsn::gn_finalize_kernel, dim3(n * 4), dim3(256), 0, (hipStream_t)stream, partials, tiles, stats);
+  hipLaunchKernelGGL(mvsn::gn_finalize_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, partials, tiles, stats);
   return mvsn::check_launch("mvsn_groupnorm_finalize");
 }
 

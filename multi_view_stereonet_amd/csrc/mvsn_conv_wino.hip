@@ -498,24 +498,24 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     }
     WN_STAMP();   // output transform + stores issued
     if (out_partials != nullptr) {   // uniform
-      auto pixel_sum = [&](float v) {
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
+      // One record per (wave, 16-lane row): the 8 lanes of a half row hold the 8 couts of one GroupNorm group for
+      // the same 16 outputs, so their validity is identical, the block count is a power of two and the whole
+      // reduction is three DPP adds (no LDS round trips; cross-row shuffles cost ~10 % of the layer).  The records
+      // carry (count, mean, M2) of their 128 values; mvsn_groupnorm_finalize combines them (Chan et al.).
+      auto sum8 = [](float v) {
+        v += dpp_mov<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+        v += dpp_mov<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+        v += dpp_mov<0x141>(v);   // row_half_mirror
         return v;
       };
-      auto group_sum = [&](float v) {
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
-        return pixel_sum(v);
-      };
       const int hi = (lane >> 3) & 1;
-      const float npos = pixel_sum((float)cnt) * 8.0f;
+      const float npos = 8.0f * (float)cnt;
+      const float rn = cnt == 16 ? 0.0078125f : (cnt == 8 ? 0.015625f : (cnt == 4 ? 0.03125f : 0.0f));   // 1 / npos, exact
       float m[2], qv[2] = {0.f, 0.f};
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        s[t] = group_sum(s[t]);
-        m[t] = npos > 0.0f ? s[t] / npos : 0.0f;
+        s[t] = sum8(s[t]);
+        m[t] = s[t] * rn;
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -531,9 +531,10 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
               }
             }
 #pragma unroll
-      for (int t = 0; t < 2; ++t) qv[t] = group_sum(qv[t]);
-      if ((lane & 0x37) == 0) {   // lanes 0 and 8
-        float *rec = out_partials + (((size_t)n * ptiles + (size_t)z * g.tiles + tile_id) * WN_WAVES + wave) * 12;
+      for (int t = 0; t < 2; ++t) qv[t] = sum8(qv[t]);
+      if ((lane & 7) == 0) {   // lanes 0 and 8 of every row
+        float *rec = out_partials +
+                     ((((size_t)n * ptiles + (size_t)z * g.tiles + tile_id) * WN_WAVES + wave) * 4 + gq) * 12;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           rec[(t * 2 + hi) * 3 + 0] = npos;
