@@ -222,24 +222,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvGeom &g, floatx4 (&acc)[
         }
   }
   if (out_partials == nullptr || CT != 2) return;  // uniform; partials need all 32 channels (host-checked)
-  auto pixel_sum = [&](float v) {   // over the lanes holding the same cout: bits 4, 5
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
+  // One record per (wave, 16-lane row): the 8 lanes of a half row hold the 8 couts of one GroupNorm group for the
+  // same pixels (identical validity), so the reduction is three DPP adds -- no LDS shuffles across rows; the
+  // records carry (count, mean, M2) and mvsn_groupnorm_finalize combines them.
+  auto sum8 = [](float v) {
+    v += dpp_mov<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror
     return v;
   };
-  auto group_sum = [&](float v) {   // over the 8 couts of a group (bits 0-2) and all pixels (bits 4, 5)
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    return pixel_sum(v);
-  };
   const int hi = (lane >> 3) & 1;
-  const float npos = pixel_sum((float)cnt) * 8.0f;
+  const float npos = 8.0f * (float)cnt;
+  const float rn = cnt > 0 ? 1.0f / npos : 0.0f;
   float m[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    s[t] = group_sum(s[t]);
-    m[t] = npos > 0.0f ? s[t] / npos : 0.0f;
+    s[t] = sum8(s[t]);
+    m[t] = s[t] * rn;
   }
   float q[2] = {0.f, 0.f};
 #pragma unroll
@@ -253,9 +252,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvGeom &g, floatx4 (&acc)[
           q[t] += dv * dv;
         }
 #pragma unroll
-  for (int t = 0; t < 2; ++t) q[t] = group_sum(q[t]);
-  if ((lane & 0x37) == 0) {   // lanes 0 and 8
-    float *rec = out_partials + (((size_t)n * g.tiles + tile_id) * 4 + (tid >> 6)) * 12;
+  for (int t = 0; t < 2; ++t) q[t] = sum8(q[t]);
+  if ((lane & 7) == 0) {   // lanes 0 and 8 of every row
+    float *rec = out_partials + ((((size_t)n * g.tiles + tile_id) * 4 + (tid >> 6)) * 4 + (lane >> 4)) * 12;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       rec[(t * 2 + hi) * 3 + 0] = npos;
@@ -890,7 +889,7 @@ extern "C" size_t mvsn_conv_packed_floats(const mvsn_conv_desc *desc) {
 }
 
 extern "C" int mvsn_conv_num_tiles(const mvsn_conv_desc *desc) {
-  // number of GroupNorm partial records per sample: one per (tile, wave), 4 waves per workgroup tile
+  // number of GroupNorm partial records per sample: one per (tile, wave, 16-lane row)
   if (desc && desc->precision == MVSN_CONV_FP32_WINO) {
     mvsn::WinoGeom wg;
     return mvsn::wino_geom(desc, &wg) ? wg.D * wg.tiles * 32 : 0;   // per (plane,) tile: 8 waves x 4 lane rows
@@ -901,7 +900,7 @@ extern "C" int mvsn_conv_num_tiles(const mvsn_conv_desc *desc) {
   }
   mvsn::ConvGeom g;
   if (!mvsn::make_geom(desc, &g)) return 0;
-  return g.tiles * 4;
+  return g.tiles * 16;   // per tile: 4 waves x 4 lane rows
 }
 
 extern "C" int mvsn_conv_pack_weights(const mvsn_conv_desc *desc, const float *weight, float *packed,
