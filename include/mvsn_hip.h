@@ -168,7 +168,8 @@ int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, const float *
 int mvsn_conv_forward_blocks(const mvsn_conv_desc *desc, const float *const *in_blocks, const int *block_channels,
                              int num_blocks, const float *weight_packed, const float *bias, float *out,
                              float *out_partials, mvsn_stream_t stream);
-/* partials (N,tiles,4,3) -> stats (N,4,2) = {mean, rstd}, eps 1e-5, biased variance */
+/* partials (N,R,4,3) {count, mean, M2} per record and group (R = mvsn_conv_num_tiles records per sample, passed as
+ * `tiles`) -> stats (N,4,2) = {mean, rstd}, eps 1e-5, biased variance; records are 48 bytes, 16-byte aligned */
 int mvsn_groupnorm_finalize(const float *partials, int n, int tiles, float *stats, mvsn_stream_t stream);
 /* out = [residual +] LeakyReLU_0.2(GroupNorm(x)) on (N,32,spatial); residual may be NULL; out may alias x */
 int mvsn_groupnorm_lrelu_apply(const float *x, const float *stats, const float *gamma, const float *beta,
