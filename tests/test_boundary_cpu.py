@@ -58,7 +58,11 @@ def test_library_exports_every_declared_symbol():
 def test_conv_planning_is_host_side_and_validates():
     lib = _native.load()
     d = _native.ConvDesc(2, 32, 32, 64, 16, 32, 3, 3, 3, 1, 1)
-    assert lib.mvsn_conv_num_tiles(ctypes.byref(d)) == 32 * 2 * 1 * 4      # partial records: tiles x 4 waves
+    assert lib.mvsn_conv_num_tiles(ctypes.byref(d)) == 32 * 2 * 1 * 16     # partial records: tiles x 4 waves x 4 lane rows
+    dw = _native.ConvDesc(2, 32, 32, 64, 16, 32, 3, 3, 3, 1, 1, _native.CONV_FP32_WINO)
+    assert lib.mvsn_conv_winograd_supported(ctypes.byref(dw)) == 1          # volume form: planes x tiles x 8 waves x 4 rows
+    assert lib.mvsn_conv_num_tiles(ctypes.byref(dw)) == 64 * 1 * 32
+    assert lib.mvsn_conv_packed_floats(ctypes.byref(dw)) == 3 * 8 * 16 * 128
     assert lib.mvsn_conv_packed_floats(ctypes.byref(d)) == 4 * 27 * 256
     bad = _native.ConvDesc(2, 32, 33, 1, 16, 32, 1, 3, 3, 1, 1)      # c_out > 32
     assert lib.mvsn_conv_packed_floats(ctypes.byref(bad)) == 0
