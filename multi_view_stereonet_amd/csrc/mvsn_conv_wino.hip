@@ -402,9 +402,10 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       }
     }
   };
-  auto tr_finish = [&](float (&d)[KS][4][4], float (&v)[KS][16]) {
+  auto tr_finish = [&](float (&d)[KS][4][4], float (&v)[KS][16], int h0 = 0, int h1 = KS) {
 #pragma unroll
     for (int h = 0; h < KS; ++h) {
+      if (h < h0 || h >= h1) continue;
       float t[4][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -422,7 +423,8 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         v[h][i * 4 + 3] = t[i][1] - t[i][3];
       }
     }
-    // advance the transform side
+  };
+  auto tr_advance = [&]() {   // the transform side moves on one step
     tr_stage = tr_stage + 1 == NSTAGE ? 0 : tr_stage + 1;
     if (++tr_chunk == nsteps) {
       tr_chunk = 0;
@@ -442,6 +444,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     float d0[KS][4][4];
     tr_load(d0);
     tr_finish(d0, v);
+    tr_advance();
   }
 
   // ---- a finished tile: output transform, bias, stores, GroupNorm partials
@@ -562,7 +565,10 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi) asm volatile("" : "=v"(acc[xi][0]), "=v"(acc[xi][1]));
 
-    for (int chunk = 0; chunk < nsteps; ++chunk, ++step) {
+    // The tile's first step is peeled (its first multiplies run with C = 0): as a branch inside the loop the two
+    // multiply variants would meet in a join of 128 accumulators + 32 coefficients, which the allocator spills.
+    int chunk = 0;
+    auto do_step = [&](auto firstc) {
       const bool has_next = step + 1 < total_steps;   // uniform
       if (has_next) {
         const int rest = total_steps - (step + 2);     // steps issued after step + 1 so far
@@ -582,9 +588,19 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         const float *ub = U + (VOL ? mm_stage : chunk) * UST + h * WN_UFLOATS + lane;
         float fb[2][2];
         fb[0][0] = ub[0], fb[0][1] = ub[64];
+        // The input transform of step + 1 (B^T d B of the patch tr_load fetched) is interleaved with the multiplies,
+        // two VALU instructions per coefficient: a row of the column transform t one row ahead, and -- right after
+        // the MFMAs that read v[h][xi] for the last time -- the coefficient of step + 1 that replaces it.  Issued
+        // after the burst the 64 instructions of the SIMD's two waves ran with the matrix pipe idle.
+        auto tcol = [&](int i, int j) {
+          const float d0 = dn[h][0][dslot(j)], d1 = dn[h][1][dslot(j)], d2 = dn[h][2][dslot(j)], d3 = dn[h][3][dslot(j)];
+          return i == 0 ? d0 - d2 : (i == 1 ? d1 + d2 : (i == 2 ? d2 - d1 : d1 - d3));
+        };
+        float tc[4] = {tcol(0, 0), tcol(0, 1), tcol(0, 2), tcol(0, 3)}, tn[4];
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {   // next coefficient's U fragments in flight behind this one's MFMAs
-          const int cur = xi & 1;
+          const int cur = xi & 1, ti = xi >> 2, tj = xi & 3;
+          if (ti < 3) tn[tj] = tcol(ti + 1, tj);
           if (xi + 1 < 16 && !(MVSN_WN_ABLATE & 2)) {
             fb[cur ^ 1][0] = ub[(xi + 1) * 128];
             fb[cur ^ 1][1] = ub[(xi + 1) * 128 + 64];
@@ -600,18 +616,29 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
             pf_issue();   // raw tile of step + NSTAGE into the stage `step` released
             uq_issue();   // VOL: U of step + NSTAGE - 1 into the slot step - 1 released
           }
+          if (!(MVSN_WN_ABLATE & 1))   // (without a next step dn is undefined and v is never read again)
+            v[h][xi] = tj == 0 ? tc[0] - tc[2] : (tj == 1 ? tc[1] + tc[2] : (tj == 2 ? tc[2] - tc[1] : tc[1] - tc[3]));
+          if (tj == 3) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tc[k] = tn[k];
+          }
+          __builtin_amdgcn_sched_barrier(0);   // keep the interleaving as written (and the live ranges short)
         }
       };
-      if (chunk == 0) multiply(std::true_type{}, std::integral_constant<int, 0>{});   // uniform
-      else multiply(std::false_type{}, std::integral_constant<int, 0>{});
+      multiply(firstc, std::integral_constant<int, 0>{});
       if constexpr (KS == 2) {
         if (chunk * KS + 1 < g.nchunks)   // uniform: odd chunk count, nothing in the second half
           multiply(std::false_type{}, std::integral_constant<int, 1>{});
+        else
+          tr_finish(dn, v, 1, 2);
       }
-      if (has_next && !(MVSN_WN_ABLATE & 1)) tr_finish(dn, v);   // v: A fragments of step + 1 (written after the last MFMA read it)
+      tr_advance();
       if constexpr (VOL) mm_stage = mm_stage + 1 == NSTAGE ? 0 : mm_stage + 1;
       WN_STAMP();   // MFMAs issued + next transform
-    }
+      ++step;
+    };
+    do_step(std::true_type{});
+    for (chunk = 1; chunk < nsteps; ++chunk) do_step(std::false_type{});
     if (!(MVSN_WN_ABLATE & 16) || n < 0) finish_tile(n, z, tile_id, y0, x0);
   }
 }
