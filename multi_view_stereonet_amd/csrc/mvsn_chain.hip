@@ -179,10 +179,10 @@ __device__ __forceinline__ void block_group_sum(float (&v)[2], float *red_slab, 
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     float s = v[t];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    s += __shfl_xor(s, 8, 64);
+    s += dpp_mov<0xB1>(s);    // quad_perm [1, 0, 3, 2]
+    s += dpp_mov<0x4E>(s);    // quad_perm [2, 3, 0, 1]
+    s += dpp_mov<0x141>(s);   // row_half_mirror: the other quad of the half row
+    s += dpp_mov<0x140>(s);   // row_mirror: the other half of the 16-lane row
     s += __shfl_xor(s, 16, 64);
     v[t] = s;
   }
