@@ -105,6 +105,7 @@ class PlaneSweepEngine:
         self.winograd_with_input_transform = True
         # ... and the 3x3x3 layers of the cost-volume regulariser as 2-D Winograd products summed over the depth tap
         self.winograd_volume = True
+        self.volume_materialise = True     # LReLU(GN(.)) of the regulariser layers as one in-place pass (see cost_volume_filter)
         # Skip the stand-alone normalise/activate pass at both ends of a refiner tower (see
         # residual_tower_unfused); False keeps one pass per block (tests compare the two).
         self.trim_tower_ends = True
@@ -374,7 +375,13 @@ class PlaneSweepEngine:
     def cost_volume_filter(self, cost: torch.Tensor) -> torch.Tensor:
         x, st = self.conv(self.vf_convs[0], cost, want_stats=True)
         for i in range(1, 4):
-            x, st = self.conv(self.vf_convs[i], x, in_stats=st, in_norm=self.vf_norms[i - 1], want_stats=True)
+            if self.volume_materialise and self.winograd and self.winograd_volume and self.conv_precision == "fp32":
+                # the volume Winograd kernel fetches every plane for three output planes: normalising it once in
+                # place (one HBM pass) is cheaper than three in-LDS passes inside the convolution
+                x = self.gn_lrelu(x, st, self.vf_norms[i - 1], out=x)
+                x, st = self.conv(self.vf_convs[i], x, want_stats=True)
+            else:
+                x, st = self.conv(self.vf_convs[i], x, in_stats=st, in_norm=self.vf_norms[i - 1], want_stats=True)
         last = self.vf_convs[4]
         if self.lib.mvsn_conv_to1_supported(x.shape[-2], x.shape[-1]):
             x = self.gn_lrelu(x, st, self.vf_norms[3], out=x)     # materialise once, then the HBM-bound 32->1 pass
