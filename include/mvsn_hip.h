@@ -214,7 +214,7 @@ int mvsn_soft_argmin(const float *cost, const float *idepth_samples, int n, int 
 /* ---------------------------------------------------------------------------------------------
  * Bilinear resize, align_corners=False, to an arbitrary target size (Upsampler :372-380), and
  * the boolean-mask variant float -> bilinear -> (> 0.5) (MaskUpsampler :389-396).
- *   in (N,C,h,w) -> out (N,C,H,W)
+ *   in (N,C,h,w) -> out (N,C,H,W); mask bytes are 0 or 1 (torch.bool)
  * ------------------------------------------------------------------------------------------- */
 int mvsn_upsample_bilinear(const float *in, int n, int channels, int rows_in, int cols_in, int rows_out,
                            int cols_out, float *out, mvsn_stream_t stream);

@@ -102,48 +102,27 @@ __global__ __launch_bounds__(256) void upsample_mask16_kernel(const uint8_t *__r
   }
 }
 
-// Exact x2 case (every level of an even-sized pyramid): output column 2i takes taps (i-1, i) with
-// weights (0.25, 0.75), column 2i+1 taps (i, i+1) with (0.75, 0.25), edges clamped -- exactly what
-// resize_tap() yields, so the result is bit-identical to the generic kernel.  One thread makes 16
-// output bytes from two 12-byte input windows read as 32-bit words (8 loads instead of 64).
+// Exact 2x mask upsampling.  The masks are boolean (bytes 0 / 1): with the 2x bilinear weights an output pixel is
+// (9 a + 3 b + 3 c + d) / 16 of its nearest input pixel a and three neighbours, and "> 0.5" of that is a itself
+// (a = 1: at least 9/16; a = 0: at most 7/16), also where the clamped edge taps coincide -- so the float -> bilinear
+// -> threshold of MaskUpsampler (:389-396) is a 2 x 2 replication.  One thread: 8 input bytes -> 2 rows x 16 bytes.
 __global__ __launch_bounds__(256) void upsample_mask2x_kernel(const uint8_t *__restrict__ in, int hin, int win,
                                                               int groups_per_row, size_t total_groups,
                                                               uint8_t *__restrict__ out) {
-  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // (plane, input row, 8-column group)
   if (gid >= total_groups) return;
-  const int hout = hin * 2, wout = win * 2;
   const int gx = (int)(gid % groups_per_row);
-  const size_t rowid = gid / groups_per_row;
-  const int y = (int)(rowid % hout);
-  const size_t plane = rowid / hout;
-  const int i0 = gx * 8;  // first input column of this group's 8-column core
-  ResizeTap ty = resize_tap(y, hin, hout);
-  const uint8_t *r0 = in + (plane * hin + ty.i0) * win;
-  const uint8_t *r1 = in + (plane * hin + ty.i1) * win;
-  // columns i0-1 .. i0+8 of both rows (edges clamped); win % 8 == 0 so the 32-bit words are aligned
-  const uint32_t *w0 = reinterpret_cast<const uint32_t *>(r0 + i0);
-  const uint32_t *w1 = reinterpret_cast<const uint32_t *>(r1 + i0);
-  const uint32_t a0 = w0[0], a1 = w0[1], b0 = w1[0], b1 = w1[1];
-  const int il = i0 > 0 ? i0 - 1 : 0, ir = i0 + 8 < win ? i0 + 8 : win - 1;
-  float top[10], bot[10];
-  top[0] = (float)r0[il], bot[0] = (float)r1[il], top[9] = (float)r0[ir], bot[9] = (float)r1[ir];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    top[1 + k] = (float)((a0 >> (8 * k)) & 0xff);
-    top[5 + k] = (float)((a1 >> (8 * k)) & 0xff);
-    bot[1 + k] = (float)((b0 >> (8 * k)) & 0xff);
-    bot[5 + k] = (float)((b1 >> (8 * k)) & 0xff);
-  }
-  // same association as the generic kernel: ty.l0*(l0*v00 + l1*v01) + ty.l1*(l0*v10 + l1*v11)
-  uint32_t w[4] = {0, 0, 0, 0};
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int a = (k >> 1) + (k & 1), b = a + 1;              // window-relative taps (static)
-    const float l0 = (k & 1) ? 0.75f : 0.25f, l1 = (k & 1) ? 0.25f : 0.75f;
-    const float v = ty.l0 * (l0 * top[a] + l1 * top[b]) + ty.l1 * (l0 * bot[a] + l1 * bot[b]);
-    w[k >> 2] |= (uint32_t)(v > 0.5f ? 1 : 0) << (8 * (k & 3));
-  }
-  *reinterpret_cast<uint4 *>(out + rowid * wout + gx * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+  const size_t rowid = gid / groups_per_row;                           // plane * hin + y
+  const uint2 w = *reinterpret_cast<const uint2 *>(in + rowid * win + gx * 8);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 o;
+  o[0] = __builtin_amdgcn_perm(w.x, w.x, 0x01010000u);   // bytes b0 b0 b1 b1
+  o[1] = __builtin_amdgcn_perm(w.x, w.x, 0x03030202u);   //       b2 b2 b3 b3
+  o[2] = __builtin_amdgcn_perm(w.y, w.y, 0x01010000u);
+  o[3] = __builtin_amdgcn_perm(w.y, w.y, 0x03030202u);
+  uint8_t *dst = out + (rowid * 2) * (size_t)(win * 2) + gx * 16;
+  __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(dst));
+  __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(dst + win * 2));
 }
 
 // ---- area (adaptive average) downsample: one pyramid level ---------------------------------
@@ -235,8 +214,9 @@ extern "C" int mvsn_upsample_mask(const uint8_t *in, int n, int channels, int ro
   const size_t total = (size_t)n * channels * rows_out * groups_per_row;
   MVSN_REQUIRE((total + 255) / 256 < 2147483647ull, MVSN_E_TOOLARGE, "mvsn_upsample_mask: grid");
   if (rows_out == 2 * rows_in && cols_out == 2 * cols_in && cols_in % 8 == 0 && (((size_t)in | (size_t)out) & 15) == 0) {
-    hipLaunchKernelGGL(mvsn::upsample_mask2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, in, rows_in, cols_in, groups_per_row, total, out);
+    const size_t groups = (size_t)n * channels * rows_in * (cols_in / 8);
+    hipLaunchKernelGGL(mvsn::upsample_mask2x_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, in, rows_in, cols_in, cols_in / 8, groups, out);
     return mvsn::check_launch("mvsn_upsample_mask(2x)");
   }
   hipLaunchKernelGGL(mvsn::upsample_mask16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,

@@ -535,7 +535,7 @@ def test_upsamplers_golden_units():
     g = torch.Generator().manual_seed(8)
     m = torch.rand(1, 64, 16, 32, generator=g) > 0.45
     assert torch.equal(eng.upsample_mask(m.to(DEV), (32, 64)).cpu(), oracle.upsample_mask(m, (32, 64)))
-    for (h, w, H, W) in ((30, 40, 60, 80), (8, 12, 15, 23), (4, 6, 8, 12), (5, 7, 9, 13)):
+    for (h, w, H, W) in ((30, 40, 60, 80), (8, 12, 15, 23), (4, 6, 8, 12), (5, 7, 9, 13), (64, 128, 128, 256), (1, 8, 2, 16)):
         m = torch.rand(2, 12, h, w, generator=g) > 0.5
         assert torch.equal(eng.upsample_mask(m.to(DEV), (H, W)).cpu(), oracle.upsample_mask(m, (H, W)))
 
