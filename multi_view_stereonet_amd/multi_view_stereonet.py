@@ -221,7 +221,8 @@ class PlaneSweepEngine:
         lib = self.lib
         x0 = blocks[0]
         if not (self.winograd and self.cat_free_heads and c.packed_wino is not None and 1 <= len(blocks) <= 3
-                and self.conv_precision == "fp32" and all(b.dtype == torch.float32 for b in blocks)):
+                and (self.conv_precision == "fp32" or c.packed_bx is None)     # (the heads have no bf16 form)
+                and all(b.dtype == torch.float32 for b in blocks)):
             return None
         n, rows, cols = x0.shape[0], x0.shape[-2], x0.shape[-1]
         d = c.desc(n, 1, rows, cols, _native.CONV_FP32_WINO)
