@@ -62,7 +62,8 @@ __device__ floatx4 g_wn_zero16 = {0.f, 0.f, 0.f, 0.f};
 
 #ifdef MVSN_WN_STAMPS   // tuning aid (tools/wino_phases.py): s_memtime stamps of one mid-launch wave
 __device__ unsigned long long *g_wn_stamps = nullptr;
-#define WN_STAMP() do { if (dbg && dbg_i < 60) dbg[dbg_i++] = __builtin_readcyclecounter(); } while (0)
+// (kept in LDS and copied out at the end: a global store per stamp would sit in the vmcnt queue the kernel waits on)
+#define WN_STAMP() do { if (dbg && dbg_on && dbg_i < 120) dbg_lds[dbg_i++] = __builtin_readcyclecounter(); } while (0)
 #else
 #define WN_STAMP() do { } while (0)
 #endif
@@ -154,7 +155,10 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   const int slot = xcd_tile_index(blockIdx.x, G);
 #ifdef MVSN_WN_STAMPS
   unsigned long long *dbg = (blockIdx.x == gridDim.x / 3 && tid == 0) ? g_wn_stamps : nullptr;
+  unsigned long long *dbg_lds =
+      reinterpret_cast<unsigned long long *>(U + (VOL ? NSTAGE * UST : g.nchunks * WN_UFLOATS));
   int dbg_i = 0;
+  bool dbg_on = true;
 #endif
   WN_STAMP();   // entry
 
@@ -550,6 +554,9 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
 
   int step = 0, mm_stage = 0;   // mm_stage: U ring slot of `step` (VOL)
   for (int round = 0; round < my_items; ++round) {
+#ifdef MVSN_WN_STAMPS
+    dbg_on = round >= 3;   // steady state: skip the first tiles
+#endif
     const int flat = round * G + slot;
     const int n = flat / ptiles;
     int tile_id = flat - n * ptiles, z = 0;
@@ -641,6 +648,10 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     for (chunk = 1; chunk < nsteps; ++chunk) do_step(std::false_type{});
     if (!(MVSN_WN_ABLATE & 16) || n < 0) finish_tile(n, z, tile_id, y0, x0);
   }
+#ifdef MVSN_WN_STAMPS
+  if (dbg)
+    for (int i = 0; i < dbg_i; ++i) dbg[i] = dbg_lds[i];
+#endif
 }
 
 bool wino_geom(const mvsn_conv_desc *d, WinoGeom *g) {
@@ -701,8 +712,11 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   const bool head = g.nchunks == 1;
   const int ks = (head || g.dil == 8) ? 1 : 2;
   const int nstage = head ? 6 : ((g.dil == 1 && g.nchunks <= 8) ? 4 : 3);
-  const size_t lds = ((size_t)nstage * ks * 4 * wn_rcst(g.dil) +
-                      (g.vol ? (size_t)nstage * ks : (size_t)g.nchunks) * WN_UFLOATS) * sizeof(float);
+  size_t lds = ((size_t)nstage * ks * 4 * wn_rcst(g.dil) +
+                (g.vol ? (size_t)nstage * ks : (size_t)g.nchunks) * WN_UFLOATS) * sizeof(float);
+#ifdef MVSN_WN_STAMPS
+  lds += 1024;   // stamp area
+#endif
   if (head && g.dil != 1) {
     set_error("mvsn_conv_forward(winograd): dilated 4-channel layers are not instantiated");
     return MVSN_E_BADARG;

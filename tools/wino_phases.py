@@ -9,7 +9,7 @@ from multi_view_stereonet_amd.weights import load_weights
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 net = MultiViewStereoNet(); net.load_state_dict(load_weights("gta_sfm_150epochs")); net = net.cuda().eval()
 eng = net.engine()
-dbg = torch.zeros(64, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(128, dtype=torch.int64, device="cuda")
 eng.lib.mvsn_debug_set_wino_stamps.argtypes = [ctypes.c_void_p]
 assert eng.lib.mvsn_debug_set_wino_stamps(dbg.data_ptr()) == 0
 if len(sys.argv) > 2 and sys.argv[2] == "vol":
@@ -30,7 +30,12 @@ for it in range(3):
     t = dbg.cpu().tolist()
     n = sum(1 for v in t if v)
     d = [t[i + 1] - t[i] for i in range(n - 1)]
-    print("launch %.3f ms, wave total %d cycles; prologue %d; per step [landed, barrier, mfma + DMA issue + next transform]; epilogue %d" %
-          (a.elapsed_time(b), t[n - 1] - t[0], d[0], d[-1]))
-    for i in range(1, min(len(d) - 1, 58), 3):
-        print("   ", d[i:i + 3])
+    nsteps = 12 if (len(sys.argv) > 2 and sys.argv[2] == "vol") else 4
+    print("launch %.3f ms; stamps from the workgroup's 4th tile on (kept in LDS, copied out at the end)" % a.elapsed_time(b))
+    per = 3 * nsteps + 1   # (landed, barrier, multiplies + next transform) per step, then the tile's epilogue
+    for k in range(2, len(d), per):
+        tile = d[k:k + per]
+        if len(tile) < per:
+            break
+        steps = [tile[i:i + 3] for i in range(0, 3 * nsteps, 3)]
+        print("  tile: total %d cycles; epilogue %d; steps [landed, barrier, multiply]:" % (sum(tile), tile[-1]), steps)
