@@ -1,5 +1,6 @@
-// Winograd F(2x2, 3x3) form of the 2-D 3x3 stride-1 convolutions with 32 output channels
-// (mvsn_conv_forward with desc.precision = MVSN_CONV_FP32_WINO).
+// Winograd F(2x2, 3x3) form of the 2-D 3x3 stride-1 convolutions with 32 output channels and of the 3x3x3
+// 32 -> 32 layers (template VOL: 2-D Winograd products summed over the depth tap)
+// (mvsn_conv_forward / mvsn_conv_forward_blocks with desc.precision = MVSN_CONV_FP32_WINO).
 //
 // The fp32 matrix pipe is the ceiling of the refiner layers (v_mfma_f32_16x16x4_f32 at 1/16 of the bf16 rate,
 // and the direct kernels already keep it ~85 % busy at the sustained clock), so the remaining lever is fewer
@@ -27,6 +28,10 @@
 //     GroupNorm partials.
 // MODE 1: the previous layer's LeakyReLU(GroupNorm(.)) is applied in LDS, once per element, by the wave that
 // fetched the piece (out-of-image pieces keep their zeros, as the padding of the materialised tensor would be).
+// LDS layout details that matter: dilation-1 tiles sit one float further (patches start at even columns: a row is
+// one ds_read2_b64 over all banks), odd channels of dilated tiles DIL floats further (conflict-free strided reads);
+// GroupNorm partials are one record per (wave, 16-lane row), reduced with DPP adds.  DESIGN.md sections 3.2b / 3.2c
+// have the measurements behind each of these choices, section 3.6 the variants that lost.
 #include <type_traits>
 
 #include "mvsn_common.h"
