@@ -106,6 +106,102 @@ def cpu_baseline(budget_s=15.0):
                       f"{threads} threads of {cores} host cpus), mean {mean * 1e3:.1f} ms"}, out
 
 
+def self_launch(n):
+    """Re-execute this command line under torch.distributed.run with n local ranks (one per GPU)."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def timed_steps(step, steps, warmup, world, sync, reduce_device):
+    """The timing protocol: `warmup` untimed steps, then exactly `steps` steps between barrier + device sync on
+    both sides; returns (max over ranks, per-rank list) of the elapsed seconds."""
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    out = None
+    for _ in range(warmup):
+        out = step()
+    sync()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
+    if world > 1:
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(every, mine)
+        per_rank = [float(e.item()) for e in every]
+    return max(per_rank), per_rank, out
+
+
+def launcher_selftest(args, rank, world):
+    """`--launcher-selftest`: the launch / barrier / max-over-ranks / all-gather plumbing of this file on CPU
+    ranks over gloo, with a stand-in step (NO forward, NO GPU).  Its line is labelled as such and is not a
+    measurement; tests/test_bench_launcher_cpu.py runs it with --gpus 2."""
+    B = args.batch
+
+    def step():
+        return torch.full((B, 3), float(rank))
+
+    elapsed, per_rank, rows = timed_steps(step, args.steps, args.warmup, world, lambda: None, torch.device("cpu"))
+    idx = torch.arange(rank * B, (rank + 1) * B)
+    all_rows, all_idx = mdist.gather_metric_rows(rows, idx)
+    assert all_rows.shape[0] == B * world and all_idx.tolist() == list(range(B * world))
+    if rank == 0:
+        print(json.dumps({"metric": "launcher self-test (no forward, not a measurement)", "value": 0.0,
+                          "unit": "none", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "world_size": torch.distributed.get_world_size() if world > 1 else 1,
+                          "backend": torch.distributed.get_backend() if world > 1 else "none",
+                          "per_rank_ms_per_step": [e / args.steps * 1e3 for e in per_rank],
+                          "rows_gathered": int(all_rows.shape[0]), "rank_sum": float(all_rows[:, 0].sum()),
+                          "data": "none"}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def batch_latency(net, batches=(1, 2, 4, 8), reps=20):
+    """Single-stream latency at the batch sizes an evaluation loop uses (test.py:38 runs batch 1): ms per forward
+    and depthmaps/s, inputs resident, with the whole forward replayed from a hipGraph (the default at small B)."""
+    from multi_view_stereonet_amd.graphed import GraphedForward
+    res = {}
+    dev = next(net.parameters()).device
+    for b in batches:
+        _, inp = make_inputs(b, GOLDEN_SEED, dev)
+        pack = (inp["left_image_pyr"], inp["K_pyr"], inp["T_right_in_left"], inp["right_image_pyr"])
+        entry = {}
+        for mode in ("eager", "graph"):
+            fn = (lambda: run_forward(net, inp)) if mode == "eager" else None
+            if mode == "graph":
+                g = GraphedForward(net, *pack, D)
+                fn = lambda: g(*pack)   # noqa: E731
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / reps * 1e3
+            entry[mode] = {"ms_per_forward": round(ms, 3), "depthmaps_per_s": round(b / ms * 1e3, 1)}
+        res[f"B={b}"] = entry
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,11 +215,20 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16"], default=os.environ.get("MVSN_BENCH_PRECISION", "fp32"),
                     help="arithmetic of the 32->32 3x3 layers: exact fp32 MFMA, or the 3 x bf16 split tier")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tiers", action="store_true", help="skip the bf16x3 / bf16 tier legs and the batch-latency leg")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="CPU ranks over gloo with a stand-in step: checks the launch/timing/gather plumbing only")
     args = ap.parse_args()
 
-    rank, world, local = mdist.init_from_env()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run on
+        # the loopback address; rank 0 of the children prints the JSON line on the inherited stdout
+        sys.exit(self_launch(args.gpus))
+    rank, world, local = mdist.init_from_env(backend="gloo" if args.launcher_selftest else None)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree")
+    if args.launcher_selftest:
+        return launcher_selftest(args, rank, world)
     torch.set_grad_enabled(False)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -132,33 +237,17 @@ def main():
     net.load_state_dict(load_weights(WEIGHTS), strict=True)
     net = net.to(dev).eval()
     net.stream_lanes = args.lanes
-    net.engine().fold_residual_blocks = args.fold
-    net.engine().conv_precision = args.precision
+    net.options.fold_residual_blocks = args.fold
+    net.options.conv_precision = args.precision
     B = args.batch
     _, inp = make_inputs(B, GOLDEN_SEED + rank * B, dev)
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
 
     # set-up, outside the warm-up / timed protocol and reported as "setup_forwards": the first forward packs the
     # weights, opts the kernels into their LDS sizes and grows the allocator pools (one-time work per process)
     run_forward(net, inp)
     torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        out = run_forward(net, inp)
-    torch.cuda.synchronize()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = run_forward(net, inp)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, per_rank, out = timed_steps(lambda: run_forward(net, inp), args.steps, args.warmup, world,
+                                         torch.cuda.synchronize, dev)
 
     # per-image metric rows, all-gathered (the path's only exchange step)
     idepth = out["left_idepthmap_pyr"][0]
@@ -173,6 +262,9 @@ def main():
                 "value": B * world * args.steps / elapsed, "unit": "depthmaps/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "setup_forwards": 1,
                 "ms_per_step": elapsed / args.steps * 1e3,
+                "per_rank_ms_per_step": [e / args.steps * 1e3 for e in per_rank],
+                "world_size": torch.distributed.get_world_size() if world > 1 else 1,
+                "backend": torch.distributed.get_backend() if world > 1 else "none",
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                 "data": "synthetic (seeded uniform frames, pretrained gta_sfm_150epochs weights)",
                 "config": {"workload": "GTA-SfM-shaped 512x256, D=64 hypotheses, 2 source views, "
@@ -227,7 +319,9 @@ def main():
                                         "share_of_step": ch["ms"] / total_ms}
             line["kernel_ms_per_step"] = {k: round(v["ms"], 3) for k, v in
                                           sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]}
-            if args.precision == "fp32":
+            if not args.no_tiers:
+                line["batch_latency"] = batch_latency(net)
+            if args.precision == "fp32" and not args.no_tiers:
                 # the two bf16-matrix-core tiers on the same resident inputs, reported beside the fp32 headline, never
                 # as it: the 3 x bf16 split (fp32-equivalent arithmetic) and plain bf16 operands
                 # (BASELINE config 5's speed tier -- outside the 1e-3 parity contract, its error is reported)

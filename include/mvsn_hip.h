@@ -212,6 +212,20 @@ int mvsn_soft_argmin(const float *cost, const float *idepth_samples, int n, int 
                      int pixels, float *idepth, mvsn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The three elementwise steps the flag branches of forward() leave outside the fused kernels:
+ *   mvsn_channel_l2_norm      do_cost_volume_filter = False: cost = ||cost_volume||_2 over the channel axis
+ *                             (torch.norm(.., dim=1), multi_view_stereonet.py:598).  x (N,C,P) -> out (N,P)
+ *   mvsn_idepth_scale         out = prior * fx[n]: the refiner's input channel in the gain trick (:607-611 etc.)
+ *   mvsn_refiner_epilogue     out = relu(prior * fx[n] + delta) / fx[n] (:482 + the division that follows), for the
+ *                             shapes whose 32 -> 1 layer does not take the fused form of mvsn_conv_to1
+ *   prior, delta, out (N,P)   fx (N)
+ * ------------------------------------------------------------------------------------------- */
+int mvsn_channel_l2_norm(const float *x, int n, int channels, long pixels, float *out, mvsn_stream_t stream);
+int mvsn_idepth_scale(const float *prior, const float *fx, int n, long pixels, float *out, mvsn_stream_t stream);
+int mvsn_refiner_epilogue(const float *prior, const float *fx, const float *delta, int n, long pixels, float *out,
+                          mvsn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Bilinear resize, align_corners=False, to an arbitrary target size (Upsampler :372-380), and
  * the boolean-mask variant float -> bilinear -> (> 0.5) (MaskUpsampler :389-396).
  *   in (N,C,h,w) -> out (N,C,H,W); mask bytes are 0 or 1 (torch.bool)

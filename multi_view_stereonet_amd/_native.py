@@ -48,6 +48,9 @@ SIGNATURES = {
     "mvsn_conv_to1_supported": (c_int, [c_int, c_int]),
     "mvsn_conv_to1": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p, c_void_p]),
     "mvsn_soft_argmin": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p, c_void_p]),
+    "mvsn_channel_l2_norm": (c_int, [c_void_p, c_int, c_int, c_long, c_void_p, c_void_p]),
+    "mvsn_idepth_scale": (c_int, [c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p]),
+    "mvsn_refiner_epilogue": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p]),
     "mvsn_upsample_bilinear": (c_int, [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
     "mvsn_upsample_mask": (c_int, [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
     "mvsn_area_downsample": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p, c_void_p]),

@@ -568,6 +568,14 @@ extern "C" size_t mvsn_incremental_cost_volume_workspace_bytes(int n_chains, int
   return (size_t)n_chains * act_floats * sizeof(float);
 }
 
+#ifdef MVSN_CHAIN_STAMPS
+static unsigned long long *g_chain_stamps = nullptr;
+extern "C" int mvsn_debug_set_chain_stamps(void *buf) {
+  g_chain_stamps = (unsigned long long *)buf;
+  return 0;
+}
+#endif
+
 extern "C" int mvsn_incremental_cost_volume(const float *src_image_lvl4, const float *H_lvl4, const float *H_inc,
                                             const float *plane0_features, const float *left_features,
                                             const float *refiner_packed, int n_chains, int batch,
@@ -601,10 +609,9 @@ extern "C" int mvsn_incremental_cost_volume(const float *src_image_lvl4, const f
   a.cols = cols;
   a.CS = chain_cs(rows, cols);
   a.dbg = nullptr;
-  {
-    const char *e = getenv("MVSN_CHAIN_DEBUG_PTR");  // tuning hook: device pointer to 64 x u64
-    if (e) a.dbg = (unsigned long long *)strtoull(e, nullptr, 0);
-  }
+#ifdef MVSN_CHAIN_STAMPS   // tuning builds only (tools/chain_phases.py): device pointer to 64 x u64 cycle stamps
+  a.dbg = g_chain_stamps;
+#endif
   const int act_floats = (cols + 2) + 36 * a.CS;
   const bool lds_act = chain_lds_bytes(P, act_floats, true) <= 160 * 1024;
   const size_t need = lds_act ? 0 : (size_t)n_chains * act_floats * sizeof(float);
@@ -619,15 +626,8 @@ extern "C" int mvsn_incremental_cost_volume(const float *src_image_lvl4, const f
 #define MVSN_CHAIN_LAUNCH(TPV, LDSV)                                                                           \
   do {                                                                                                         \
     auto kern = chain_kernel<TPV, LDSV>;                                                                       \
-    static size_t opted = 0;                                                                                   \
-    if (lds > opted) {                                                                                         \
-      hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      if (e != hipSuccess) {                                                                                   \
-        set_error("mvsn_incremental_cost_volume: LDS opt-in of %zu bytes failed: %s", lds, hipGetErrorString(e)); \
-        return (int)e;                                                                                         \
-      }                                                                                                        \
-      opted = lds;                                                                                             \
-    }                                                                                                          \
+    static LdsOptIn opt;                                                                                       \
+    if (int rc = ensure_lds(opt, (const void *)kern, lds, "mvsn_incremental_cost_volume")) return rc;          \
     hipLaunchKernelGGL(kern, dim3(n_chains), dim3(CH_THREADS), lds, (hipStream_t)stream, a);                   \
   } while (0)
 

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "../../include/mvsn_hip.h"
 
 namespace mvsn {
@@ -18,6 +20,44 @@ inline int check_launch(const char *what) {
     return (int)e;
   }
   return 0;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device setting: the largest size opted in so far is
+// remembered per (launch site, device) under a lock, so a second GPU in the same process -- or a second host
+// thread -- never launches a large-LDS kernel that only another device was opted in for.
+struct LdsOptIn {
+  static constexpr int kMaxDevices = 64;
+  std::mutex lock;
+  size_t opted[kMaxDevices] = {};
+};
+
+inline int ensure_lds(LdsOptIn &state, const void *kernel, size_t lds_bytes, const char *what) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  const bool cached = dev < LdsOptIn::kMaxDevices;
+  std::lock_guard<std::mutex> guard(state.lock);
+  if (cached && lds_bytes <= state.opted[dev]) return 0;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) {
+    set_error("%s: LDS opt-in of %zu bytes failed: %s", what, lds_bytes, hipGetErrorString(e));
+    return (int)e;
+  }
+  if (cached) state.opted[dev] = lds_bytes;
+  return 0;
+}
+
+// compute units of the current device (per device, cached)
+inline int device_cus() {
+  static std::mutex lock;
+  static int cus[LdsOptIn::kMaxDevices] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  std::lock_guard<std::mutex> guard(lock);
+  if (dev < LdsOptIn::kMaxDevices && cus[dev] > 0) return cus[dev];
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  if (dev < LdsOptIn::kMaxDevices) cus[dev] = n;
+  return n;
 }
 
 #define MVSN_REQUIRE(cond, code, ...)   \

@@ -770,6 +770,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
 }
 
 // out = [residual +] LeakyReLU(GroupNorm(x)), (N,32,spatial), float4 per thread.
+constexpr int GN_APPLY_MAX_N = 65535 / 32;   // samples per launch (grid.y = sample * 32 + channel)
+
 // RRAW: the residual is itself a raw conv output whose LeakyReLU(GroupNorm(.)) was never materialised
 // (the head of a refiner): out = LReLU(GN(x)) + LReLU(GN_r(residual)).
 template <bool RRAW>
@@ -1000,15 +1002,8 @@ extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, co
 #define MVSN_DMA_LAUNCH(...)                                                                                      \
   do {                                                                                                            \
     auto kern = conv_dma_kernel<__VA_ARGS__>;                                                                     \
-    static size_t opted = 0;                                                                                      \
-    if (lds > opted) {                                                                                            \
-      hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      if (e != hipSuccess) {                                                                                      \
-        set_error("mvsn_conv_forward: LDS opt-in of %zu bytes failed: %s", lds, hipGetErrorString(e));            \
-        return (int)e;                                                                                            \
-      }                                                                                                           \
-      opted = lds;                                                                                                \
-    }                                                                                                             \
+    static LdsOptIn opt;                                                                                          \
+    if (int rc = ensure_lds(opt, (const void *)kern, lds, "mvsn_conv_forward(dma)")) return rc;                   \
     hipLaunchKernelGGL(kern, grid, dim3(CV_THREADS), lds, (hipStream_t)stream, g, in, weight_packed, bias, in_stats, \
                        in_gamma, in_beta, in_residual, out_staged, out, out_partials);                            \
     return check_launch("mvsn_conv_forward(dma)");                                                                \
@@ -1040,16 +1035,8 @@ extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, co
 #define MVSN_CONV_LAUNCH(...)                                                                                    \
   do {                                                                                                           \
     auto kern = conv_mfma_kernel<__VA_ARGS__>;                                                                   \
-    static size_t opted = 0;                                                                                     \
-    if (g.lds_bytes > opted) {                                                                                   \
-      hipError_t e =                                                                                             \
-          hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes); \
-      if (e != hipSuccess) {                                                                                     \
-        set_error("mvsn_conv_forward: LDS opt-in of %zu bytes failed: %s", g.lds_bytes, hipGetErrorString(e));   \
-        return (int)e;                                                                                           \
-      }                                                                                                          \
-      opted = g.lds_bytes;                                                                                       \
-    }                                                                                                            \
+    static LdsOptIn opt;                                                                                         \
+    if (int rc = ensure_lds(opt, (const void *)kern, g.lds_bytes, "mvsn_conv_forward")) return rc;               \
     hipLaunchKernelGGL(kern, grid, dim3(CV_THREADS), g.lds_bytes, (hipStream_t)stream, g, in, weight_packed, bias, \
                        in_stats, in_gamma, in_beta, in_residual, out_staged, out, out_partials);                 \
   } while (0)
@@ -1101,12 +1088,15 @@ extern "C" int mvsn_groupnorm_lrelu_apply(const float *x, const float *stats, co
                                           mvsn_stream_t stream) {
   MVSN_REQUIRE(x && stats && gamma && beta && out && n > 0 && spatial > 0, MVSN_E_BADARG,
                "mvsn_groupnorm_lrelu_apply: bad argument");
-  MVSN_REQUIRE((long)n * 32 <= 65535, MVSN_E_TOOLARGE, "mvsn_groupnorm_lrelu_apply: batch too large for one launch");
   long per = (spatial + 4095) / 4096;   // 4 float4 per thread per pass
   int gx = (int)(per < 1 ? 1 : (per > 32 ? 32 : per));
-  hipLaunchKernelGGL(mvsn::gn_apply_kernel<false>, dim3(gx, n * 32), dim3(256), 0, (hipStream_t)stream, x, stats, gamma,
-                     beta, residual, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, spatial,
-                     out);
+  for (int n0 = 0; n0 < n; n0 += mvsn::GN_APPLY_MAX_N) {   // grid.y carries (sample, channel): 2047 samples per launch
+    const int nn = n - n0 < mvsn::GN_APPLY_MAX_N ? n - n0 : mvsn::GN_APPLY_MAX_N;
+    const long off = (long)n0 * 32 * spatial;
+    hipLaunchKernelGGL(mvsn::gn_apply_kernel<false>, dim3(gx, nn * 32), dim3(256), 0, (hipStream_t)stream, x + off,
+                       stats + (long)n0 * 8, gamma, beta, residual ? residual + off : residual, (const float *)nullptr,
+                       (const float *)nullptr, (const float *)nullptr, spatial, out + off);
+  }
   return mvsn::check_launch("mvsn_groupnorm_lrelu_apply");
 }
 
@@ -1115,11 +1105,15 @@ extern "C" int mvsn_groupnorm_lrelu_add2(const float *x, const float *stats, con
                                          const float *r_beta, int n, long spatial, float *out, mvsn_stream_t stream) {
   MVSN_REQUIRE(x && stats && gamma && beta && r && r_stats && r_gamma && r_beta && out && n > 0 && spatial > 0,
                MVSN_E_BADARG, "mvsn_groupnorm_lrelu_add2: bad argument");
-  MVSN_REQUIRE((long)n * 32 <= 65535, MVSN_E_TOOLARGE, "mvsn_groupnorm_lrelu_add2: batch too large for one launch");
   long per = (spatial + 4095) / 4096;
   int gx = (int)(per < 1 ? 1 : (per > 32 ? 32 : per));
-  hipLaunchKernelGGL(mvsn::gn_apply_kernel<true>, dim3(gx, n * 32), dim3(256), 0, (hipStream_t)stream, x, stats, gamma,
-                     beta, r, r_stats, r_gamma, r_beta, spatial, out);
+  for (int n0 = 0; n0 < n; n0 += mvsn::GN_APPLY_MAX_N) {
+    const int nn = n - n0 < mvsn::GN_APPLY_MAX_N ? n - n0 : mvsn::GN_APPLY_MAX_N;
+    const long off = (long)n0 * 32 * spatial;
+    hipLaunchKernelGGL(mvsn::gn_apply_kernel<true>, dim3(gx, nn * 32), dim3(256), 0, (hipStream_t)stream, x + off,
+                       stats + (long)n0 * 8, gamma, beta, r + off, r_stats + (long)n0 * 8, r_gamma, r_beta, spatial,
+                       out + off);
+  }
   return mvsn::check_launch("mvsn_groupnorm_lrelu_add2");
 }
 

@@ -420,27 +420,25 @@ int bf16x3_pack(const mvsn_conv_desc *d, const float *weight, void *packed, hipS
   return check_launch("mvsn_conv_pack_weights(bf16x3)");
 }
 
+#ifdef MVSN_BX_STAMPS
+static unsigned long long *g_bx_stamps = nullptr;
+#endif
+
 int bf16x3_launch(const Bf16x3Geom &g, const float *in, const void *wpk, const float *bias, const float *in_stats,
                   const float *in_gamma, const float *in_beta, float *out, float *out_partials, hipStream_t stream) {
 #define MVSN_BX_LAUNCH(...)                                                                                       \
   do {                                                                                                            \
     auto kern = conv_bf16x3_kernel<__VA_ARGS__>;                                                                  \
-    static size_t opted = 0;                                                                                      \
-    if (g.lds_bytes > opted) {                                                                                    \
-      hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,          \
-                                         (int)g.lds_bytes);                                                       \
-      if (e != hipSuccess) {                                                                                      \
-        set_error("mvsn_conv_forward(bf16x3): LDS opt-in of %zu bytes failed: %s", g.lds_bytes,                   \
-                  hipGetErrorString(e));                                                                          \
-        return (int)e;                                                                                            \
-      }                                                                                                           \
-      opted = g.lds_bytes;                                                                                        \
-    }                                                                                                             \
+    static LdsOptIn opt;                                                                                          \
+    if (int rc = ensure_lds(opt, (const void *)kern, g.lds_bytes, "mvsn_conv_forward(bf16x3)")) return rc;        \
     hipLaunchKernelGGL(kern, grid, dim3(BX_THREADS), g.lds_bytes, stream, g, in, (const uintx4 *)wpk, bias, in_stats, \
                        in_gamma, in_beta, out, out_partials, dbgp);                                               \
   } while (0)
   const bool xf = in_stats != nullptr;
-  static unsigned long long *dbgp = getenv("MVSN_BX_DEBUG_PTR") ? (unsigned long long *)strtoull(getenv("MVSN_BX_DEBUG_PTR"), nullptr, 0) : nullptr;
+  unsigned long long *dbgp = nullptr;
+#ifdef MVSN_BX_STAMPS      // tuning builds only (tools/bx_phases.py)
+  dbgp = g_bx_stamps;
+#endif
   constexpr int TPW2D = 8;
   const dim3 grid(g.kd == 3 ? g.tiles : (g.tiles + TPW2D - 1) / TPW2D, g.n);
 #define MVSN_BX_BOTH(...)                                                         \
@@ -465,3 +463,10 @@ int bf16_selftest(hipStream_t stream, int *dbad) {
 }
 
 }  // namespace mvsn
+
+#ifdef MVSN_BX_STAMPS
+extern "C" int mvsn_debug_set_bx_stamps(void *buf) {
+  mvsn::g_bx_stamps = (unsigned long long *)buf;
+  return 0;
+}
+#endif

@@ -704,13 +704,7 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   a.cb0 = g.cin, a.cb1 = 0, a.in1 = a.in2 = in;
   a.D = g.D;
   if (blocks) a.cb0 = blocks->cb0, a.cb1 = blocks->cb1, a.in1 = blocks->in1, a.in2 = blocks->in2;
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
-  }
+  const int cus = device_cus();
   // (k-steps per step, ring depth) by what fits next to the resident U: the raw tile grows with the dilation
   //   dilation 1: 2 k-steps x 4 stages (94 KB); 2, 4: 2 x 3 (78 / 94 KB); 8: 1 x 3 (74 KB); 4-channel head: 1 x 6
   //   volume form: 2 x 3 raw stages + 3 stages of U (118 KB)
@@ -733,16 +727,10 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   dim3 grid(1);
 #define WN_CASE(M, K, N, D, ...)                                                                                   \
   do {                                                                                                             \
-    static size_t opted = 0;                                                                                       \
-    if (lds > opted) {                                                                                             \
-      hipError_t e = hipFuncSetAttribute((const void *)conv_wino_kernel<M, K, N, D, ##__VA_ARGS__>,                \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
-      if (e != hipSuccess) {                                                                                       \
-        set_error("mvsn_conv_forward(winograd): LDS opt-in of %zu bytes failed: %s", lds, hipGetErrorString(e));   \
-        return (int)e;                                                                                             \
-      }                                                                                                            \
-      opted = lds;                                                                                                 \
-    }                                                                                                              \
+    static LdsOptIn opt;                                                                                           \
+    if (int rc = ensure_lds(opt, (const void *)conv_wino_kernel<M, K, N, D, ##__VA_ARGS__>, lds,                   \
+                            "mvsn_conv_forward(winograd)"))                                                        \
+      return rc;                                                                                                   \
     hipLaunchKernelGGL((conv_wino_kernel<M, K, N, D, ##__VA_ARGS__>), grid, dim3(WN_THREADS), lds, stream, a, in,  \
                        upk, bias,                                                                                  \
                        in_stats, in_gamma, in_beta, out, out_partials);                                            \

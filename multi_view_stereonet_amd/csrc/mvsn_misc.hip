@@ -26,6 +26,34 @@ __global__ __launch_bounds__(256) void soft_argmin_kernel(const float *__restric
   out[(size_t)n * P + p] = num / den;
 }
 
+// ---- elementwise steps of the flag branches -----------------------------------------------------
+__global__ __launch_bounds__(256) void channel_l2_norm_kernel(const float *__restrict__ x, int channels, long P,
+                                                              float *__restrict__ out) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const float *xp = x + (size_t)blockIdx.y * channels * P + p;
+  float acc = 0.0f;
+  for (int c = 0; c < channels; ++c) {
+    const float v = xp[(size_t)c * P];
+    acc += v * v;
+  }
+  out[(size_t)blockIdx.y * P + p] = sqrtf(acc);
+}
+
+// EPI false: out = prior * fx;  EPI true: out = relu(prior * fx + delta) / fx
+template <bool EPI>
+__global__ __launch_bounds__(256) void idepth_gain_kernel(const float *__restrict__ prior, const float *__restrict__ fx,
+                                                          const float *__restrict__ delta, long P,
+                                                          float *__restrict__ out) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const float f = fx[blockIdx.y];
+  const size_t i = (size_t)blockIdx.y * P + p;
+  const float scaled = prior[i] * f;
+  if constexpr (EPI) out[i] = fmaxf(scaled + delta[i], 0.0f) / f;
+  else out[i] = scaled;
+}
+
 // ---- bilinear resize, align_corners=False ------------------------------------------------
 // src = (dst + 0.5) * (in/out) - 0.5, clamped at 0; the +1 tap is clamped to the last index
 // (ATen upsample_bilinear2d, area_pixel_compute_source_index).
@@ -191,6 +219,33 @@ extern "C" int mvsn_soft_argmin(const float *cost, const float *idepth_samples, 
   hipLaunchKernelGGL(mvsn::soft_argmin_kernel, dim3((pixels + 255) / 256, n), dim3(256), 0, (hipStream_t)stream,
                      cost, idepth_samples, D, pixels, idepth);
   return mvsn::check_launch("mvsn_soft_argmin");
+}
+
+extern "C" int mvsn_channel_l2_norm(const float *x, int n, int channels, long pixels, float *out,
+                                    mvsn_stream_t stream) {
+  MVSN_REQUIRE(x && out, MVSN_E_BADARG, "mvsn_channel_l2_norm: null pointer");
+  MVSN_REQUIRE(n > 0 && n <= 65535 && channels > 0 && pixels > 0, MVSN_E_BADARG, "mvsn_channel_l2_norm: bad sizes");
+  hipLaunchKernelGGL(mvsn::channel_l2_norm_kernel, dim3((unsigned)((pixels + 255) / 256), n), dim3(256), 0,
+                     (hipStream_t)stream, x, channels, pixels, out);
+  return mvsn::check_launch("mvsn_channel_l2_norm");
+}
+
+extern "C" int mvsn_idepth_scale(const float *prior, const float *fx, int n, long pixels, float *out,
+                                 mvsn_stream_t stream) {
+  MVSN_REQUIRE(prior && fx && out, MVSN_E_BADARG, "mvsn_idepth_scale: null pointer");
+  MVSN_REQUIRE(n > 0 && n <= 65535 && pixels > 0, MVSN_E_BADARG, "mvsn_idepth_scale: bad sizes");
+  hipLaunchKernelGGL(mvsn::idepth_gain_kernel<false>, dim3((unsigned)((pixels + 255) / 256), n), dim3(256), 0,
+                     (hipStream_t)stream, prior, fx, (const float *)nullptr, pixels, out);
+  return mvsn::check_launch("mvsn_idepth_scale");
+}
+
+extern "C" int mvsn_refiner_epilogue(const float *prior, const float *fx, const float *delta, int n, long pixels,
+                                     float *out, mvsn_stream_t stream) {
+  MVSN_REQUIRE(prior && fx && delta && out, MVSN_E_BADARG, "mvsn_refiner_epilogue: null pointer");
+  MVSN_REQUIRE(n > 0 && n <= 65535 && pixels > 0, MVSN_E_BADARG, "mvsn_refiner_epilogue: bad sizes");
+  hipLaunchKernelGGL(mvsn::idepth_gain_kernel<true>, dim3((unsigned)((pixels + 255) / 256), n), dim3(256), 0,
+                     (hipStream_t)stream, prior, fx, delta, pixels, out);
+  return mvsn::check_launch("mvsn_refiner_epilogue");
 }
 
 extern "C" int mvsn_upsample_bilinear(const float *in, int n, int channels, int rows_in, int cols_in, int rows_out,
@@ -523,16 +578,8 @@ extern "C" int mvsn_conv_to1(const float *in, const float *weight, const float *
     const int nz = (depth + zslab - 1) / zslab;
     MVSN_REQUIRE(n <= 65535 && nz <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_to1: grid");
     const size_t lds = (size_t)T3_LDS_FLOATS * sizeof(float);
-    static bool opted = false;
-    if (!opted) {
-      hipError_t e = hipFuncSetAttribute((const void *)conv_to1_3d_mfma_kernel,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) {
-        set_error("mvsn_conv_to1: LDS opt-in of %zu bytes failed: %s", lds, hipGetErrorString(e));
-        return (int)e;
-      }
-      opted = true;
-    }
+    static LdsOptIn opt;
+    if (int rc = ensure_lds(opt, (const void *)conv_to1_3d_mfma_kernel, lds, "mvsn_conv_to1")) return rc;
     hipLaunchKernelGGL(conv_to1_3d_mfma_kernel, dim3(nty * ntx, nz, n), dim3(256), lds, (hipStream_t)stream, in, weight,
                        bias, depth, rows, cols, ntx, zslab, out);
   } else {

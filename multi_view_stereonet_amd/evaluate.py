@@ -45,11 +45,13 @@ def main(argv=None):
     else:
         data = datasets.GTASfMMultiViewStereoDataset(args.data_dir, args.test_file, transform=tf,
                                                      load_groundtruth_depthmaps=True, shuffle_on_read=False)
-    loader = torch.utils.data.DataLoader(data, batch_size=args.batch_size, shuffle=False)
+    # shard at the dataset level: each rank reads, decodes and resizes only its own images
+    mine = mdist.shard_indices(len(data), rank, world)
+    loader = torch.utils.data.DataLoader(torch.utils.data.Subset(data, mine), batch_size=args.batch_size, shuffle=False)
     net = MultiViewStereoNet()
     net.load_state_dict(load_weights(args.weights), strict=True)
     net = net.to(dev).eval()
-    avg = metrics.evaluate(net, loader, params, split, dev, rank=rank, world=world)
+    avg = metrics.evaluate(net, loader, params, split, dev, rank=rank, world=world, image_indices=mine)
     if rank == 0:
         os.makedirs(args.output_dir, exist_ok=True)
         with open(os.path.join(args.output_dir, "avg_depth_metrics.txt"), "w") as f:

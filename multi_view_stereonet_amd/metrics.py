@@ -73,11 +73,17 @@ def compute_avg_metrics(rows: Sequence[Dict[str, float]]) -> Dict[str, float]:
 
 
 def evaluate(stereo_network, batches: Iterable[dict], params: dict, split: str, device,
-             rank: int = 0, world: int = 1) -> Dict[str, float]:
+             rank: int = 0, world: int = 1, image_indices: Optional[Sequence[int]] = None) -> Dict[str, float]:
     """Run the network over ``batches`` (DataLoader-style dicts carrying ``left_depthmap_true`` in
     metric units), one metric row per image, averaged over all ranks' rows.
 
-    Batch i is processed by rank i % world; rows (+ runtime) are all-gathered at the end.
+    Sharding, two forms:
+      * ``image_indices`` given: ``batches`` already holds only THIS rank's images (the dataset was sharded, e.g.
+        ``Subset(data, distributed.shard_indices(len(data), rank, world))``), and ``image_indices[k]`` is the global
+        index of the k-th image it yields -- each rank reads and decodes only its own files (evaluate.py does this);
+      * otherwise every rank iterates the same ``batches`` and processes batch i when i % world == rank (fine for
+        in-memory batches; with a file-backed loader it makes every rank read everything).
+    Rows (+ per-image runtime = batch time / batch size) are all-gathered at the end.
     """
     min_depth, max_depth = depth_range(split)
     rows: List[List[float]] = []
@@ -85,7 +91,7 @@ def evaluate(stereo_network, batches: Iterable[dict], params: dict, split: str, 
     image_index = 0
     for bi, batch in enumerate(batches):
         bsz = batch["left_image"].shape[0]
-        if bi % world == rank:
+        if image_indices is not None or bi % world == rank:
             inputs = snu.multi_view_unpack_batch(batch, device, stereo_network.num_levels)
             outputs = snu.multi_view_forward(stereo_network, inputs, params)
             depth_est = idepth_to_depth(outputs["left_idepthmap_pyr"][0], inputs["baseline"])
@@ -94,8 +100,8 @@ def evaluate(stereo_network, batches: Iterable[dict], params: dict, split: str, 
                 row = image_metric_row(depth_true[b, 0].cpu().numpy(), depth_est[b, 0].cpu().numpy(), min_depth,
                                        max_depth)
                 if row is not None:
-                    rows.append([row[k] for k in METRIC_KEYS] + [outputs["stereo_time_ms"]])
-                    idx.append(image_index + b)
+                    rows.append([row[k] for k in METRIC_KEYS] + [outputs["stereo_time_ms"] / bsz])
+                    idx.append(int(image_indices[image_index + b]) if image_indices is not None else image_index + b)
         image_index += bsz
     dev = device if (world > 1 and torch.distributed.get_backend() == "nccl") else torch.device("cpu")
     rt = torch.tensor(rows, dtype=torch.float64, device=dev).reshape(-1, len(METRIC_KEYS) + 1)

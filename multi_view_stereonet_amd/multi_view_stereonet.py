@@ -83,14 +83,11 @@ class _Norm:
         self.beta = p.bias.detach().contiguous().float()
 
 
-class PlaneSweepEngine:
-    """Packed weights + the launch sequence.  Built lazily from the module's parameters."""
+class EngineOptions:
+    """Tuning switches of the launch sequence.  Owned by the MultiViewStereoNet, shared with whatever
+    PlaneSweepEngine is current, copied with the module."""
 
-    def __init__(self, net: "MultiViewStereoNet"):
-        self.lib = lib = _native.load()
-        # When set to a list, every library call is bracketed by device events on the current
-        # stream and appended as (kernel, start, end, algorithmic_flops, algorithmic_bytes).
-        self.timeline: Optional[list] = None
+    def __init__(self):
         # Residual blocks can be folded into the next convolution's tile load (no stand-alone
         # normalise/activate/add pass, 1/3 fewer launches).  Measured on MI355X the folded form is
         # 3 % slower end to end (the doubled staging loads are exposed), so it is off by default.
@@ -110,6 +107,34 @@ class PlaneSweepEngine:
         # residual_tower_unfused); False keeps one pass per block (tests compare the two).
         self.trim_tower_ends = True
         self.cat_free_heads = True         # refiner heads read [image, features, idepth] in place (no torch.cat)
+
+    NAMES = ("fold_residual_blocks", "conv_precision", "winograd", "winograd_with_input_transform",
+             "winograd_volume", "volume_materialise", "trim_tower_ends", "cat_free_heads")
+
+
+class PlaneSweepEngine:
+    """Packed weights + the launch sequence.  Built lazily from the module's parameters."""
+
+    def __getattr__(self, name):            # only reached when normal lookup fails: the option switches
+        if name in EngineOptions.NAMES:
+            return getattr(self.__dict__["opt"], name)
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if name in EngineOptions.NAMES:
+            setattr(self.__dict__["opt"], name, value)
+        else:
+            object.__setattr__(self, name, value)
+
+
+    def __init__(self, net: "MultiViewStereoNet"):
+        self.lib = lib = _native.load()
+        # tuning switches live on the module (EngineOptions), so they survive every rebuild of this object
+        # (.to(), load_state_dict, in-place parameter updates); `engine.<switch>` reads and writes through
+        object.__setattr__(self, "opt", net.options)
+        # When set to a list, every library call is bracketed by device events on the current
+        # stream and appended as (kernel, start, end, algorithmic_flops, algorithmic_bytes).
+        self.timeline: Optional[list] = None
         fe = net.left_feature_extractor
         self.fe_down = [_Conv(lib, getattr(fe, f"conv{i}").weight, None, stride=2) for i in range(4)]
         self.fe_res = [(_Conv(lib, getattr(fe, f"res{i}").conv1.weight, None), _Norm(getattr(fe, f"res{i}").bn1))
@@ -394,8 +419,11 @@ class PlaneSweepEngine:
         """`guide` is a tensor or a list of channel blocks (image, features): the refiner input
         [guide..., prior * fx] is assembled with ONE concatenation."""
         p = self.refiners[level]
-        scale = fx.view(-1, 1, 1, 1)
-        scaled = prior * scale
+        prior, fx = prior.contiguous(), fx.contiguous()
+        n, pixels = prior.shape[0], prior[0].numel()
+        scaled = torch.empty_like(prior)
+        self._call("mvsn_idepth_scale", self.lib.mvsn_idepth_scale, _native.ptr(prior), _native.ptr(fx), n, pixels,
+                   _native.ptr(scaled), _native.stream(), nbytes=8.0 * prior.numel())
         x_in = (list(guide) if isinstance(guide, (list, tuple)) else [guide]) + [scaled]
         if self.fold_residual_blocks or len(x_in) > 3:
             x_in = torch.cat(x_in, 1)       # those towers take one tensor
@@ -403,10 +431,14 @@ class PlaneSweepEngine:
             delta, done = self.residual_tower(x_in, (p["conv0"], p["bn0"]), p["res"], p["final"]), False
         else:
             delta, done = self.residual_tower_unfused(x_in, (p["conv0"], p["bn0"]), p["res"], p["final"],
-                                                      prior=prior.contiguous(), fx=fx.contiguous())
+                                                      prior=prior, fx=fx)
         if done:
             return delta            # epilogue relu(prior*fx + delta)/fx already applied in the kernel
-        return torch.relu(scaled + delta) / scale
+        out = torch.empty_like(prior)
+        self._call("mvsn_refiner_epilogue", self.lib.mvsn_refiner_epilogue, _native.ptr(prior), _native.ptr(fx),
+                   _native.ptr(delta.contiguous()), n, pixels, _native.ptr(out), _native.stream(),
+                   nbytes=12.0 * prior.numel())
+        return out
 
     def homography_warp(self, image: torch.Tensor, H: torch.Tensor, out: Optional[torch.Tensor] = None):
         B, C, rows, cols = image.shape
@@ -518,7 +550,10 @@ class PlaneSweepEngine:
         if do_filter:
             filtered = self.cost_volume_filter(cost)
         else:
-            filtered = torch.linalg.vector_norm(cost, dim=1)
+            filtered = torch.empty((cost.shape[0],) + tuple(cost.shape[2:]), dtype=torch.float32, device=cost.device)
+            self._call("mvsn_channel_l2_norm", self.lib.mvsn_channel_l2_norm, _native.ptr(cost), cost.shape[0],
+                       cost.shape[1], cost[0, 0].numel(), _native.ptr(filtered), _native.stream(),
+                       nbytes=4.0 * (cost.numel() + filtered.numel()))
         raw = self.soft_argmin(filtered, samples)
 
         # 6. level-4 refinement per chain, then fuse the sources
@@ -562,10 +597,26 @@ class MultiViewStereoNet(nn.Module):
         super().__init__()
         self.min_idepth = 0.0
         build_parameter_tree(self)
+        self.options = EngineOptions()
         self._engine: Optional[PlaneSweepEngine] = None
         self._engine_key = None
         self.stream_lanes = 1          # >1: cut the batch into that many slices on separate HIP streams
         self._lane_streams: List[torch.cuda.Stream] = []
+
+    # The engine holds ctypes function pointers and device-side packed weights, the lanes HIP streams:
+    # neither can be pickled or deep-copied.  Copies drop them and rebuild lazily on their first forward.
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_engine"], state["_engine_key"], state["_lane_streams"] = None, None, []
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__getstate__().items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
     # parameters changed -> packed copies are stale
     def _invalidate(self):

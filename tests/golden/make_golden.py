@@ -20,6 +20,11 @@ Fixtures:
   g6_flags_128x64.npz           do_cost_volume_filter=False / refiners off variants
   g7_depth_metrics.npz          test.py's depth metrics on a synthetic truth/estimate pair
   g8_two_view_128x64_d12.npz    2-view twins (unpack_batch / forward) with the right-view estimate
+  gc2_gta_512x256_d64_s1.npz    BASELINE config 2 (one source view): outputs only
+  gc3_gta_512x256_d64_s5.npz    BASELINE config 3 (five source views): outputs only
+  gc5_gta_1024x512_d128_s4.npz  BASELINE config 5 geometry (fp32 reference): idepth_0 (fp32), idepth_4, mask_4
+
+    python tests/golden/make_golden.py [name-prefix ...]     # e.g. "gc" regenerates only the gc* fixtures
 """
 import os
 import sys
@@ -174,7 +179,8 @@ def full_capture(name, weights, rows, cols, D, S, B=1, seed=1, jitter=0.0, init_
     print(name, "ok", sum(v.nbytes for v in d.values()) // 1024, "KiB raw")
 
 
-def outputs_only(name, weights, rows, cols, D, S, seed, smooth=False):
+def outputs_only(name, weights, rows, cols, D, S, seed, smooth=False, slim=False):
+    """`slim` (large configs): no per-source filtered cost / feature planes, only the output pins."""
     net = ref_net(weights)
     batch = synthetic.make_batch(rows, cols, S, batch=1, seed=seed, smooth=smooth)
     inputs, out, rec = run_reference(net, batch, D)
@@ -183,8 +189,10 @@ def outputs_only(name, weights, rows, cols, D, S, seed, smooth=False):
     for s in range(S):
         d[f"idepth_samples_{s}"] = npy(rec["samples"][s])
         d[f"H_{s}"] = npy(rec["H"][2 * s + 1])
-        d[f"filtered_cost_{s}"] = npy(rec["vf_out"][s]).astype(np.float32)
         d[f"mask_volume_count_{s}"] = np.int64(rec["rfe_out"][s][1].sum().item())
+        if slim:
+            continue
+        d[f"filtered_cost_{s}"] = npy(rec["vf_out"][s]).astype(np.float32)
         fv = rec["rfe_out"][s][0]
         d[f"feature_volume_last_plane_{s}"] = npy(fv[:, :, -1])
     for lvl in range(5):
@@ -193,7 +201,8 @@ def outputs_only(name, weights, rows, cols, D, S, seed, smooth=False):
     d["idepth_0"] = npy(out["left_idepthmap_pyr"][0])
     d["idepth_4"] = npy(out["left_idepthmap_pyr"][4])
     d["raw_4"] = npy(out["left_idepthmap_raw_pyr"][4])
-    d["raw_0"] = npy(out["left_idepthmap_raw_pyr"][0]).astype(np.float16)  # coarse pin only
+    if not slim:
+        d["raw_0"] = npy(out["left_idepthmap_raw_pyr"][0]).astype(np.float16)  # coarse pin only
     np.savez_compressed(os.path.join(HERE, name), **d)
     print(name, "ok", sum(v.nbytes for v in d.values()) // 1024, "KiB raw")
 
@@ -325,16 +334,27 @@ def two_view_pins(name):
 
 def main():
     torch.set_num_threads(8)
-    two_view_pins("g8_two_view_128x64_d12.npz")
-    metric_pins("g7_depth_metrics.npz")
-    full_capture("g1_gta_128x64_d16_s1.npz", "gta_sfm_150epochs", 64, 128, 16, 1, seed=1)
-    full_capture("g1_init_128x64_d16_s1.npz", None, 64, 128, 16, 1, seed=1, init_seed=0, store_weights=False)
-    full_capture("g1b_gta_96x80_d8_s2_b2.npz", "gta_sfm_150epochs", 80, 96, 8, 2, B=2, seed=2, jitter=0.3)
-    outputs_only("g2_gta_512x256_d64_s2.npz", "gta_sfm_150epochs", 256, 512, 64, 2, seed=7)
-    outputs_only("g2s_gta_512x256_d64_s2.npz", "gta_sfm_150epochs", 256, 512, 64, 2, seed=7, smooth=True)
-    outputs_only("g3_demon_640x480_d96_s1.npz", "demon_45epochs", 480, 640, 96, 1, seed=9)
-    flags_capture("g6_flags_128x64.npz")
-    unit_pins("g4_units.npz")
+    G = "gta_sfm_150epochs"
+    jobs = [
+        ("g8_two_view_128x64_d12.npz", lambda n: two_view_pins(n)),
+        ("g7_depth_metrics.npz", lambda n: metric_pins(n)),
+        ("g1_gta_128x64_d16_s1.npz", lambda n: full_capture(n, G, 64, 128, 16, 1, seed=1)),
+        ("g1_init_128x64_d16_s1.npz", lambda n: full_capture(n, None, 64, 128, 16, 1, seed=1, init_seed=0)),
+        ("g1b_gta_96x80_d8_s2_b2.npz", lambda n: full_capture(n, G, 80, 96, 8, 2, B=2, seed=2, jitter=0.3)),
+        ("g2_gta_512x256_d64_s2.npz", lambda n: outputs_only(n, G, 256, 512, 64, 2, seed=7)),
+        ("g2s_gta_512x256_d64_s2.npz", lambda n: outputs_only(n, G, 256, 512, 64, 2, seed=7, smooth=True)),
+        ("g3_demon_640x480_d96_s1.npz", lambda n: outputs_only(n, "demon_45epochs", 480, 640, 96, 1, seed=9)),
+        ("g6_flags_128x64.npz", lambda n: flags_capture(n)),
+        ("g4_units.npz", lambda n: unit_pins(n)),
+        # BASELINE configs 2, 3 and 5 at their stated sizes (reference loop multi_view_stereonet.py:564-627)
+        ("gc2_gta_512x256_d64_s1.npz", lambda n: outputs_only(n, G, 256, 512, 64, 1, seed=21, slim=True)),
+        ("gc3_gta_512x256_d64_s5.npz", lambda n: outputs_only(n, G, 256, 512, 64, 5, seed=23, slim=True)),
+        ("gc5_gta_1024x512_d128_s4.npz", lambda n: outputs_only(n, G, 512, 1024, 128, 4, seed=25, slim=True)),
+    ]
+    want = sys.argv[1:]
+    for name, job in jobs:
+        if not want or any(name.startswith(w) for w in want):
+            job(name)
 
 
 if __name__ == "__main__":

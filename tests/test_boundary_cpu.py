@@ -119,3 +119,31 @@ def test_multi_view_forward_wrapper_passes_params():
     snu.multi_view_forward(fake, inp, {"num_idepth_samples": 7, "cost_volume_filter": False,
                                        "refiners": [False, True, True, True, False]})
     assert seen == {"D": 7, "flt": False, "refs": [False, True, True, True, False]}
+
+
+def test_module_copies_and_pickles_with_a_live_engine():
+    """The cached engine holds ctypes function pointers (not picklable); copies drop it and keep the options."""
+    import copy
+    import io
+    import pickle
+    net = MultiViewStereoNet()
+    net.load_state_dict(load_weights("gta_sfm_150epochs"), strict=True)
+    net.options.conv_precision = "bf16x3"
+
+    class FakeEngine:                     # stands in for PlaneSweepEngine (which needs a device to pack weights)
+        def __init__(self):
+            self.lib = _native.load()
+            self.fn = self.lib.mvsn_abi_version
+
+    net._engine, net._engine_key = FakeEngine(), ("stale",)
+    with pytest.raises(Exception):
+        pickle.dumps(net._engine)
+    for dup in (copy.deepcopy(net), pickle.loads(pickle.dumps(net))):
+        assert dup._engine is None and dup._engine_key is None
+        assert dup.options.conv_precision == "bf16x3" and dup.options is not net.options
+        assert torch.equal(dup.refiner0.conv0.weight, net.refiner0.conv0.weight)
+        assert dup.left_feature_extractor.conv0.weight.data_ptr() == \
+            dup.right_feature_extractor.feature_extractor.conv0.weight.data_ptr()      # sharing survives the copy
+    buf = io.BytesIO()
+    torch.save(net, buf)
+    assert net._engine is not None        # the original keeps its engine

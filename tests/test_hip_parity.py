@@ -505,6 +505,52 @@ def test_forward_bf16_operand_tier_is_a_speed_tier(name, wname, smooth):
     assert errs["bf16"][0] > 5 * errs["bf16x3"][0]     # the split buys at least that much
 
 
+def test_flag_branch_elementwise_kernels():
+    """The three elementwise entry points behind the flag branches (no ATen compute left on the path):
+    channel L2 norm (torch.norm(.., dim=1), :598), prior*fx and relu(prior*fx + delta)/fx (:482, :607-611)."""
+    lib = _native.load()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 32, 5, 7, 9, generator=g)
+    out = torch.empty(3, 5, 7, 9, device=DEV)
+    _native.check(lib.mvsn_channel_l2_norm(_native.ptr(x.to(DEV)), 3, 32, 5 * 7 * 9, _native.ptr(out), _native.stream()),
+                  "l2")
+    close(out, torch.norm(x, dim=1), rtol=1e-6, atol=1e-7)
+    prior = torch.rand(4, 1, 11, 13, generator=g) * 2
+    delta = torch.randn(4, 1, 11, 13, generator=g) * 40
+    fx = torch.tensor([410.0, 25.6, 51.2, 102.4])
+    o1, o2 = torch.empty(4, 1, 11, 13, device=DEV), torch.empty(4, 1, 11, 13, device=DEV)
+    _native.check(lib.mvsn_idepth_scale(_native.ptr(prior.to(DEV)), _native.ptr(fx.to(DEV)), 4, 143, _native.ptr(o1),
+                                        _native.stream()), "scale")
+    _native.check(lib.mvsn_refiner_epilogue(_native.ptr(prior.to(DEV)), _native.ptr(fx.to(DEV)),
+                                            _native.ptr(delta.to(DEV)), 4, 143, _native.ptr(o2), _native.stream()), "epi")
+    sc = fx.view(-1, 1, 1, 1)
+    assert torch.equal(o1.cpu(), prior * sc)
+    assert torch.equal(o2.cpu(), torch.relu(prior * sc + delta) / sc)
+    assert (o2 == 0).any() and (o2 > 0).any()
+
+
+def test_groupnorm_apply_beyond_one_grid():
+    """More than 2047 samples: the wrappers walk the batch in grid-sized chunks."""
+    eng = net_for("gta_sfm_150epochs").engine()
+    from multi_view_stereonet_amd.multi_view_stereonet import _Norm
+    g = torch.Generator().manual_seed(5)
+    n = 2100
+    r = torch.randn(n, 32, 4, 8, generator=g)
+    res = torch.randn(n, 32, 4, 8, generator=g)
+    stats = torch.stack([torch.randn(n, 4, generator=g) * 0.1, torch.rand(n, 4, generator=g) + 0.5], -1)
+    P = type("P", (), {})()
+    P.weight, P.bias = torch.rand(32, generator=g).to(DEV) + 0.5, torch.randn(32, generator=g).to(DEV)
+    y = eng.gn_lrelu(r.to(DEV), stats.to(DEV), _Norm(P), residual=res.to(DEV))
+    mean = stats[..., 0].repeat_interleave(8, 1)[:, :, None, None]
+    rstd = stats[..., 1].repeat_interleave(8, 1)[:, :, None, None]
+    want = res + F.leaky_relu((r - mean) * rstd * P.weight.cpu()[None, :, None, None] + P.bias.cpu()[None, :, None, None], 0.2)
+    close(y, want, rtol=1e-5, atol=1e-5)
+    y2 = eng.gn_lrelu_add2(r.to(DEV), stats.to(DEV), _Norm(P), res.to(DEV), stats.to(DEV), _Norm(P))
+    want2 = want - res + F.leaky_relu((res - mean) * rstd * P.weight.cpu()[None, :, None, None] +
+                                      P.bias.cpu()[None, :, None, None], 0.2)
+    close(y2, want2, rtol=1e-5, atol=1e-5)
+
+
 def test_cost_volume_filter_and_soft_argmin_golden_unit():
     fix = load_golden("g4_units.npz")
     eng = net_for("gta_sfm_150epochs").engine()
@@ -643,6 +689,73 @@ def test_forward_headline_golden(name, wname, smooth):
     assert mean_rel < 2e-4 and max_rel < 1e-3
     for lvl in range(5):
         assert abs(int(out["left_idepthmap_mask_pyr"][lvl].sum()) - int(fix[f"mask_count_{lvl}"])) <= 2 * 4 ** (4 - lvl)
+    _check_mask4(name, out, fix)
+
+
+def _check_mask4(name, out, fix):
+    """The stored level-4 mask of the reference, voxel by voxel: mismatches are counted and printed, and only
+    voxels whose normalised coordinate sits within an ulp of the |n| > 1 predicate may differ."""
+    m = out["left_idepthmap_mask_pyr"][4].cpu().numpy()
+    ref = np.unpackbits(fix["mask_4"])[:m.size].reshape(m.shape).astype(bool)
+    bad = int((m != ref).sum())
+    print(f"{name}: level-4 mask mismatches {bad} of {m.size}")
+    assert bad == 0, (name, bad)
+
+
+CONFIG_FIXTURES = [("gc2_gta_512x256_d64_s1.npz", "config 2: 512x256, D=64, S=1"),
+                   ("gc3_gta_512x256_d64_s5.npz", "config 3: 512x256, D=64, S=5"),
+                   ("gc5_gta_1024x512_d128_s4.npz", "config 5: 1024x512, D=128, S=4")]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("name,what", CONFIG_FIXTURES)
+def test_forward_baseline_configs_golden(name, what, precision):
+    """BASELINE configs 2, 3 and 5 at their stated sizes against the reference's own outputs
+    (multi_view_stereonet.py:564-627: the per-source loop and the fusion), in exact fp32 and with the
+    3 x bf16 split tier -- both inside the 1e-3 contract."""
+    fix = load_golden(name)
+    net = net_for("gta_sfm_150epochs")
+    net.options.conv_precision = precision
+    try:
+        cap = {}
+        out = _forward(net, fix, capture=cap)
+    finally:
+        net.options.conv_precision = "fp32"
+    S = int(fix["meta"][3])
+    for s in range(S):
+        close(cap["idepth_samples"][s:s + 1], fix[f"idepth_samples_{s}"], rtol=2e-5, atol=1e-7)
+        close(cap["H"][s:s + 1], fix[f"H_{s}"], rtol=1e-4, atol=2e-5)
+        assert int(cap["mask_volume"][s].sum()) == int(fix[f"mask_volume_count_{s}"])
+    for lvl in (0, 4):
+        got = out["left_idepthmap_pyr"][lvl].cpu()
+        ref = t(fix[f"idepth_{lvl}"])
+        l1 = (got - ref).abs().mean().item()
+        mean_rel, max_rel = rel_err(got, ref)
+        print(f"{what} [{precision}] level {lvl}: L1 {l1:.3e} mean-rel {mean_rel:.3e} max-rel {max_rel:.3e}")
+        assert mean_rel < 2e-4 and max_rel < 1e-3, (what, precision, lvl, mean_rel, max_rel)
+    mean_rel, max_rel = rel_err(out["left_idepthmap_raw_pyr"][4].cpu(), fix["raw_4"])
+    assert mean_rel < 2e-4 and max_rel < 1e-3
+    for lvl in range(5):
+        assert abs(int(out["left_idepthmap_mask_pyr"][lvl].sum()) - int(fix[f"mask_count_{lvl}"])) <= 2 * 4 ** (4 - lvl)
+    _check_mask4(name, out, fix)
+
+
+def test_forward_config5_bf16_operand_tier_reported():
+    """BASELINE config 5 names a bf16 speed tier.  Plain bf16 operands on the 32->32 3x3[x3] layers are outside
+    the 1e-3 contract (SURVEY section 7 measured it), so the error against the reference is REPORTED here and only
+    bounded loosely; the masks do not depend on the tier and stay bit-exact."""
+    name = "gc5_gta_1024x512_d128_s4.npz"
+    fix = load_golden(name)
+    net = net_for("gta_sfm_150epochs")
+    net.options.conv_precision = "bf16"
+    try:
+        out = _forward(net, fix)
+    finally:
+        net.options.conv_precision = "fp32"
+    mean_rel, max_rel = rel_err(out["left_idepthmap_pyr"][0].cpu(), fix["idepth_0"])
+    print(f"config 5 [bf16 operands] level 0: mean-rel {mean_rel:.3e} max-rel {max_rel:.3e} (contract 1e-3: outside)")
+    assert mean_rel < 3e-2 and max_rel < 0.2
+    _check_mask4(name, out, fix)
 
 
 def test_forward_flag_variants_golden():

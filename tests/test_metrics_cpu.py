@@ -69,3 +69,39 @@ def test_evaluate_with_a_stand_in_network():
     out = metrics.evaluate(Net(), Feeder(), {"num_idepth_samples": 8}, "gta_sfm", torch.device("cpu"))
     assert out["num_samples"] == 2
     assert out["abs_rel"] < 1e-6 and out["a1"] == 1.0 and out["runtime_ms"] >= 0.0
+
+
+def test_evaluate_dataset_level_shards_cover_every_image_once():
+    """evaluate(image_indices=...): a rank that is handed only its shard reports global image indices, and the
+    two shards together reproduce the single-rank rows (no rank iterates the other's images)."""
+    from multi_view_stereonet_amd import distributed as mdist
+    seen = []
+
+    class Net:
+        num_levels = 5
+
+        def __call__(self, lp, kp, ts, rp, D, flt, refs):
+            z = [1.0 / (lp[0][:, :1] * 0 + 2.0)] * 5          # constant depth 2 at unit baseline
+            return {"left_idepthmap_pyr": z, "left_idepthmap_raw_pyr": z, "left_idepthmap_mask_pyr": z}
+
+    def batch(i):
+        b = synthetic.make_batch(16, 32, 1, batch=1, seed=i)
+        base = b["T_right_in_left"][0][:, 0, :3, 3].norm(dim=1).view(-1, 1, 1, 1)
+        b["left_depthmap_true"] = torch.full((1, 1, 16, 32), 2.0 + 0.1 * i) / base   # truth * baseline = 2 + 0.1 i
+        b["right_depthmap_true"] = [b["left_depthmap_true"].clone()]
+        seen.append(i)
+        return b
+
+    n, world = 5, 2
+    full = metrics.evaluate(Net(), (batch(i) for i in range(n)), {"num_idepth_samples": 8}, "gta_sfm",
+                            torch.device("cpu"))
+    parts = []
+    for rank in range(world):
+        mine = mdist.shard_indices(n, rank, world)
+        seen.clear()
+        out = metrics.evaluate(Net(), (batch(i) for i in mine), {"num_idepth_samples": 8}, "gta_sfm",
+                               torch.device("cpu"), image_indices=mine)
+        assert seen == mine                                   # this rank touched only its own images
+        parts.append((out, len(mine)))
+    merged = sum(o["abs_rel"] * k for o, k in parts) / n
+    assert abs(merged - full["abs_rel"]) < 1e-9 and full["num_samples"] == n

@@ -84,6 +84,25 @@ def test_headline_outputs(name, wname, smooth):
         assert abs(int(out["left_idepthmap_mask_pyr"][lvl].sum()) - int(fix[f"mask_count_{lvl}"])) <= 2 * 4 ** (4 - lvl)
 
 
+@pytest.mark.parametrize("name", ["gc2_gta_512x256_d64_s1.npz", "gc3_gta_512x256_d64_s5.npz",
+                                  "gc5_gta_1024x512_d128_s4.npz"])
+def test_baseline_config_outputs(name):
+    """BASELINE configs 2 (S=1), 3 (S=5) and 5 (1024x512, D=128, S=4) at their stated sizes."""
+    fix = load_golden(name)
+    cap = {}
+    _, _, out = _run(fix, load_weights("gta_sfm_150epochs"), capture=cap)
+    for s in range(int(fix["meta"][3])):
+        c = cap["sources"][s]
+        assert torch.allclose(c["idepth_samples"], t(fix[f"idepth_samples_{s}"]), rtol=1e-5, atol=1e-7)
+        assert torch.allclose(c["H"], t(fix[f"H_{s}"]), rtol=1e-4, atol=1e-5)
+        assert int(c["mask_volume"].sum()) == int(fix[f"mask_volume_count_{s}"])
+    for lvl, key in ((0, "idepth_0"), (4, "idepth_4")):
+        mean_rel, max_rel = rel_err(out["left_idepthmap_pyr"][lvl], fix[key])
+        assert mean_rel < 1e-4 and max_rel < 1e-3, (key, mean_rel, max_rel)
+    m = out["left_idepthmap_mask_pyr"][4].numpy()
+    assert np.array_equal(m, np.unpackbits(fix["mask_4"])[:m.size].reshape(m.shape).astype(bool))
+
+
 def test_flag_variants():
     fix = load_golden("g6_flags_128x64.npz")
     batch, D = batch_from_meta(fix["meta"])

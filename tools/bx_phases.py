@@ -2,8 +2,11 @@
 """Tuning aid: phase stamps of one workgroup of the bf16x3 conv kernel (3-D and 2-D)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# needs a tuning build: MVSN_HIPCC_FLAGS=-DMVSN_BX_STAMPS python -m multi_view_stereonet_amd.build --force
+import ctypes
+from multi_view_stereonet_amd import _native
 dbg = torch.zeros(64, dtype=torch.int64, device="cuda")
-os.environ["MVSN_BX_DEBUG_PTR"] = str(dbg.data_ptr())
+ctypes.CDLL(_native.library_path()).mvsn_debug_set_bx_stamps(ctypes.c_void_p(dbg.data_ptr()))
 from multi_view_stereonet_amd import MultiViewStereoNet
 from multi_view_stereonet_amd.multi_view_stereonet import _Conv
 from multi_view_stereonet_amd.weights import load_weights

@@ -5,8 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multi_view_stereonet_amd import MultiViewStereoNet, synthetic
 from multi_view_stereonet_amd import multi_view_stereonet_utils as snu
 from multi_view_stereonet_amd.weights import load_weights
+# needs a tuning build: MVSN_HIPCC_FLAGS=-DMVSN_CHAIN_STAMPS python -m multi_view_stereonet_amd.build --force
+import ctypes
+from multi_view_stereonet_amd import _native
 dbg = torch.zeros(64, dtype=torch.int64, device="cuda")
-os.environ["MVSN_CHAIN_DEBUG_PTR"] = str(dbg.data_ptr())
+ctypes.CDLL(_native.library_path()).mvsn_debug_set_chain_stamps(ctypes.c_void_p(dbg.data_ptr()))
 net = MultiViewStereoNet(); net.load_state_dict(load_weights("gta_sfm_150epochs")); net = net.cuda().eval()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 batch = synthetic.make_batch(256, 512, 2, batch=B, seed=7)
