@@ -45,6 +45,7 @@ template <bool EPI>
 __global__ __launch_bounds__(256) void idepth_gain_kernel(const float *__restrict__ prior, const float *__restrict__ fx,
                                                           const float *__restrict__ delta, long P,
                                                           float *__restrict__ out) {
+#pragma clang fp contract(off)   // prior*fx and the add are two separately rounded ATen ops in the reference
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   const float f = fx[blockIdx.y];
