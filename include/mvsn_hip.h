@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVSN_ABI_VERSION 1
+#define MVSN_ABI_VERSION 2
 
 #define MVSN_E_BADARG (-1)      /* null pointer, non-positive size, unsupported channel count */
 #define MVSN_E_TOOLARGE (-2)    /* shape exceeds what the kernel's LDS/global plan supports */
@@ -79,7 +79,14 @@ int mvsn_homography_warp(const float *image, const float *H, int batch, int chan
  *   cost_volume (N,32,D,rows,cols)   mask_volume (N,D,rows,cols) u8
  *   feature_volume: optional (N,32,D,rows,cols) masked source features, or NULL
  *   workspace: mvsn_incremental_cost_volume_workspace_bytes() bytes (may be 0 -> NULL allowed)
+ *   form: MVSN_CHAIN_AUTO picks per coarse grid (mvsn_incremental_cost_volume_form tells which);
+ *         MVSN_CHAIN_DIRECT = the three 3x3 convolutions as direct implicit GEMMs (any grid up to 2048 px);
+ *         MVSN_CHAIN_WINOGRAD = as Winograd F(2x2,3x3) products (fp32 throughout, 2.25x fewer multiplies; even
+ *         rows/cols whose planes + one layer of transformed weights fit LDS, e.g. 16x32), MVSN_E_TOOLARGE otherwise.
  * ------------------------------------------------------------------------------------------- */
+#define MVSN_CHAIN_AUTO 0
+#define MVSN_CHAIN_DIRECT 1
+#define MVSN_CHAIN_WINOGRAD 2
 size_t mvsn_feature_refiner_packed_floats(void);
 /* Pack the ten FeatureRefiner tensors (state_dict order: conv0.{weight,bias}, bn0.{weight,bias},
  * res0.conv1.{weight,bias}, res0.bn1.{weight,bias}, conv_final.{weight,bias}) into the MFMA
@@ -89,12 +96,13 @@ int mvsn_pack_feature_refiner(const float *conv0_w, const float *conv0_b, const 
                               const float *res0_bn_w, const float *res0_bn_b, const float *final_w,
                               const float *final_b, float *packed, mvsn_stream_t stream);
 size_t mvsn_incremental_cost_volume_workspace_bytes(int n_chains, int rows, int cols);
+int mvsn_incremental_cost_volume_form(int rows, int cols);   /* what MVSN_CHAIN_AUTO resolves to for this grid */
 int mvsn_incremental_cost_volume(const float *src_image_lvl4, const float *H_lvl4, const float *H_inc,
                                  const float *plane0_features, const float *left_features,
                                  const float *refiner_packed, int n_chains, int batch,
                                  int num_idepth_samples, int rows, int cols, float *cost_volume,
                                  uint8_t *mask_volume, float *feature_volume, void *workspace,
-                                 size_t workspace_bytes, mvsn_stream_t stream);
+                                 size_t workspace_bytes, int form, mvsn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Direct convolution on fp32 MFMA (implicit GEMM, weights = A, activations = B), 2-D or 3-D,

@@ -22,6 +22,8 @@ class ConvDesc(Structure):
 
 
 CONV_FP32, CONV_BF16X3, CONV_FP32_WINO, CONV_BF16 = 0, 1, 2, 3
+CHAIN_AUTO, CHAIN_DIRECT, CHAIN_WINOGRAD = 0, 1, 2
+ABI_VERSION = 2
 
 
 # name -> (restype, argtypes); mirrors include/mvsn_hip.h one to one
@@ -33,7 +35,8 @@ SIGNATURES = {
     "mvsn_feature_refiner_packed_floats": (c_size_t, []),
     "mvsn_pack_feature_refiner": (c_int, [c_void_p] * 11 + [c_void_p]),
     "mvsn_incremental_cost_volume_workspace_bytes": (c_size_t, [c_int] * 3),
-    "mvsn_incremental_cost_volume": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 4 + [c_size_t, c_void_p]),
+    "mvsn_incremental_cost_volume_form": (c_int, [c_int] * 2),
+    "mvsn_incremental_cost_volume": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 4 + [c_size_t, c_int, c_void_p]),
     "mvsn_conv_bf16x3_supported": (c_int, [POINTER(ConvDesc)]),
     "mvsn_conv_winograd_supported": (c_int, [POINTER(ConvDesc)]),
     "mvsn_conv_packed_floats": (c_size_t, [POINTER(ConvDesc)]),
@@ -78,7 +81,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the header and the binary disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.mvsn_abi_version() != 1:
+    if lib.mvsn_abi_version() != ABI_VERSION:
         raise RuntimeError("libmvsn_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmvsn_hip.so")
-SOURCES = ["mvsn_error.hip", "mvsn_setup.hip", "mvsn_warp.hip", "mvsn_chain.hip", "mvsn_conv.hip", "mvsn_conv_bf16x3.hip", "mvsn_conv_wino.hip", "mvsn_misc.hip"]
+SOURCES = ["mvsn_error.hip", "mvsn_setup.hip", "mvsn_warp.hip", "mvsn_chain.hip", "mvsn_chain_wino.hip", "mvsn_conv.hip", "mvsn_conv_bf16x3.hip", "mvsn_conv_wino.hip", "mvsn_misc.hip"]
 
 
 def hipcc() -> str:
@@ -22,7 +22,7 @@ def needs_build() -> bool:
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "mvsn_common.h"),
-                                                     os.path.join(CSRC, "mvsn_conv_bf16x3.h"), os.path.join(CSRC, "mvsn_conv_wino.h"),
+                                                     os.path.join(CSRC, "mvsn_conv_bf16x3.h"), os.path.join(CSRC, "mvsn_chain.h"), os.path.join(CSRC, "mvsn_conv_wino.h"),
                                                      os.path.join(HERE, "..", "include", "mvsn_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 

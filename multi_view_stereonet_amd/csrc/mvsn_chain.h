@@ -1,0 +1,40 @@
+// Internal interface between the C-ABI entry point of the fused chain (mvsn_chain.hip) and its two kernels:
+// the direct-form kernel (any coarse grid up to 2048 px) and the Winograd F(2x2,3x3) kernel (even grids whose
+// activation planes + one layer of transformed weights fit the 160 KB of LDS: 16x32 at 512x256 frames).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace mvsn {
+
+constexpr int CH_W0_FLOATS = 9 * 9 * 2 * 64;  // direct form, conv0: 35 -> 36 input channels = 9 k-steps per tap
+constexpr int CH_W1_FLOATS = 9 * 8 * 2 * 64;
+constexpr int CH_SP_FLOATS = 7 * 32;          // biases and GroupNorm affine
+constexpr int CH_DIRECT_FLOATS = CH_W0_FLOATS + 2 * CH_W1_FLOATS + CH_SP_FLOATS;
+// Winograd form: U = G g G^T per (cout, cin), [k-step of 4 cin][cout tile][xi quad][lane][4 xi] = 2048 floats per k-step
+constexpr int CW_UCHUNK = 2 * 4 * 64 * 4;
+constexpr int CW_U0_FLOATS = 9 * CW_UCHUNK;
+constexpr int CW_U1_FLOATS = 8 * CW_UCHUNK;
+constexpr int CH_PACKED_FLOATS = CH_DIRECT_FLOATS + CW_U0_FLOATS + 2 * CW_U1_FLOATS;
+
+struct ChainArgs {
+  const float *src;      // (N,3,P)
+  const float *H;        // (N,D,9)
+  const float *Hinc;     // (N,D,9)
+  const float *f0;       // (N,32,P)
+  const float *fl;       // (B,32,P)
+  const float *packed;   // CH_PACKED_FLOATS
+  float *cost;           // (N,32,D,P)
+  uint8_t *mask;         // (N,D,P)
+  float *fvol;           // (N,32,D,P) or null
+  float *workspace;      // global activation planes or null
+  int B, D, rows, cols, CS;
+  unsigned long long *dbg;  // optional: s_memtime stamps of block 0 / lane 0 at phase boundaries (tuning only)
+};
+
+// Winograd form: does this coarse grid have a plan (even rows / cols, <= 128 patches, LDS fits)?
+bool chain_wino_supported(int rows, int cols);
+int chain_wino_launch(const ChainArgs &a, int n_chains, hipStream_t stream);
+
+}  // namespace mvsn

@@ -20,35 +20,19 @@
 //                       ch 0..2 image plane d, ch 3..34 features, ch 35 zero (K padding).
 // When that exceeds 160 KiB the activation planes move to a per-chain global workspace
 // (L2-resident); the code path is otherwise identical.
-#include <stdlib.h>
-
+#include "mvsn_chain.h"
 #include "mvsn_common.h"
 
 namespace mvsn {
 
 constexpr int CH_THREADS = 1024;
 constexpr int CH_WAVES = 16;
-constexpr int W0_FLOATS = 9 * 9 * 2 * 64;  // conv0: 35 -> 36 input channels = 9 k-steps per tap
-constexpr int W1_FLOATS = 9 * 8 * 2 * 64;
-constexpr int SP_FLOATS = 7 * 32;
-constexpr int PACKED_FLOATS = W0_FLOATS + 2 * W1_FLOATS + SP_FLOATS;
+constexpr int W0_FLOATS = CH_W0_FLOATS;
+constexpr int W1_FLOATS = CH_W1_FLOATS;
+constexpr int SP_FLOATS = CH_SP_FLOATS;
+constexpr int PACKED_FLOATS = CH_PACKED_FLOATS;
 constexpr int RED_FLOATS = 4 * CH_WAVES * 4;
 constexpr float GN_EPS = 1e-5f;
-
-struct ChainArgs {
-  const float *src;      // (N,3,P)
-  const float *H;        // (N,D,9)
-  const float *Hinc;     // (N,D,9)
-  const float *f0;       // (N,32,P)
-  const float *fl;       // (B,32,P)
-  const float *packed;   // PACKED_FLOATS
-  float *cost;           // (N,32,D,P)
-  uint8_t *mask;         // (N,D,P)
-  float *fvol;           // (N,32,D,P) or null
-  float *workspace;      // global activation planes or null
-  int B, D, rows, cols, CS;
-  unsigned long long *dbg;  // optional: s_memtime stamps of block 0 / lane 0 at phase boundaries (tuning only)
-};
 
 // ---------------------------------------------------------------------------------------------
 // weight packing
@@ -58,7 +42,27 @@ __global__ void pack_refiner_kernel(const float *c0w, const float *c0b, const fl
                                     const float *c2w, const float *c2b, float *out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= PACKED_FLOATS) return;
-  if (i < W0_FLOATS + 2 * W1_FLOATS) {
+  if (i >= CH_DIRECT_FLOATS) {
+    // Winograd form (mvsn_chain_wino.hip): U = G g G^T, [conv][k-step][cout tile][xi quad][lane][4 xi];
+    // lane = k*16 + c holds U_xi[cout = t*16 + c][cin = 4*kstep + k] (the A fragment of the MFMA)
+    int rel = i - CH_DIRECT_FLOATS, cin_total = 35;
+    const float *w = c0w;
+    if (rel >= CW_U0_FLOATS) {
+      rel -= CW_U0_FLOATS, cin_total = 32, w = c1w;
+      if (rel >= CW_U1_FLOATS) rel -= CW_U1_FLOATS, w = c2w;
+    }
+    const int j = rel & 3, lane = (rel >> 2) & 63, xq = (rel >> 8) & 3, t = (rel >> 10) & 1, c4 = rel >> 11;
+    const int xi = xq * 4 + j, cout = t * 16 + (lane & 15), cin = c4 * 4 + (lane >> 4);
+    float u = 0.0f;
+    if (cin < cin_total) {
+      const float *g = w + ((size_t)cout * cin_total + cin) * 9;
+      const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+      const int gi = xi >> 2, gj = xi & 3;
+      for (int aa = 0; aa < 3; ++aa)
+        for (int bb = 0; bb < 3; ++bb) u += G[gi][aa] * g[aa * 3 + bb] * G[gj][bb];
+    }
+    out[i] = u;
+  } else if (i < W0_FLOATS + 2 * W1_FLOATS) {
     int conv, rel, cin_total, nc;
     const float *w;
     if (i < W0_FLOATS) {
@@ -560,6 +564,10 @@ extern "C" int mvsn_pack_feature_refiner(const float *conv0_w, const float *conv
   return mvsn::check_launch("mvsn_pack_feature_refiner");
 }
 
+extern "C" int mvsn_incremental_cost_volume_form(int rows, int cols) {
+  return mvsn::chain_wino_supported(rows, cols) ? MVSN_CHAIN_WINOGRAD : MVSN_CHAIN_DIRECT;
+}
+
 extern "C" size_t mvsn_incremental_cost_volume_workspace_bytes(int n_chains, int rows, int cols) {
   if (n_chains <= 0 || rows <= 0 || cols <= 0) return 0;
   const int CS = mvsn::chain_cs(rows, cols);
@@ -581,17 +589,21 @@ extern "C" int mvsn_incremental_cost_volume(const float *src_image_lvl4, const f
                                             const float *refiner_packed, int n_chains, int batch,
                                             int num_idepth_samples, int rows, int cols, float *cost_volume,
                                             uint8_t *mask_volume, float *feature_volume, void *workspace,
-                                            size_t workspace_bytes, mvsn_stream_t stream) {
+                                            size_t workspace_bytes, int form, mvsn_stream_t stream) {
   using namespace mvsn;
   MVSN_REQUIRE(src_image_lvl4 && H_lvl4 && H_inc && plane0_features && left_features && refiner_packed &&
                    cost_volume && mask_volume,
                MVSN_E_BADARG, "mvsn_incremental_cost_volume: null pointer");
   MVSN_REQUIRE(n_chains > 0 && batch > 0 && num_idepth_samples >= 1 && rows > 0 && cols > 0, MVSN_E_BADARG,
                "mvsn_incremental_cost_volume: bad sizes");
+  MVSN_REQUIRE(form >= 0 && form <= 2, MVSN_E_BADARG, "mvsn_incremental_cost_volume: form must be 0, 1 or 2");
+  MVSN_REQUIRE(form != MVSN_CHAIN_WINOGRAD || chain_wino_supported(rows, cols), MVSN_E_TOOLARGE,
+               "mvsn_incremental_cost_volume: no Winograd plan for a %dx%d coarse grid", rows, cols);
+  const bool wino = form == MVSN_CHAIN_WINOGRAD || (form == MVSN_CHAIN_AUTO && chain_wino_supported(rows, cols));
   const int P = rows * cols;
   const int tiles = (P + 15) / 16;
   const int TP = (tiles + CH_WAVES - 1) / CH_WAVES;
-  MVSN_REQUIRE(TP <= 8, MVSN_E_TOOLARGE,
+  MVSN_REQUIRE(wino || TP <= 8, MVSN_E_TOOLARGE,
                "mvsn_incremental_cost_volume: %dx%d coarse grid (%d px) exceeds the 2048 px plan", rows, cols, P);
   ChainArgs a;
   a.src = src_image_lvl4;
@@ -612,6 +624,10 @@ extern "C" int mvsn_incremental_cost_volume(const float *src_image_lvl4, const f
 #ifdef MVSN_CHAIN_STAMPS   // tuning builds only (tools/chain_phases.py): device pointer to 64 x u64 cycle stamps
   a.dbg = g_chain_stamps;
 #endif
+  if (wino) {
+    a.workspace = nullptr;
+    return chain_wino_launch(a, n_chains, (hipStream_t)stream);
+  }
   const int act_floats = (cols + 2) + 36 * a.CS;
   const bool lds_act = chain_lds_bytes(P, act_floats, true) <= 160 * 1024;
   const size_t need = lds_act ? 0 : (size_t)n_chains * act_floats * sizeof(float);

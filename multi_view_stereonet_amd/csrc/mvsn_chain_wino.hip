@@ -1,0 +1,490 @@
+// The fused incremental chain, Winograd form (see include/mvsn_hip.h: mvsn_incremental_cost_volume).
+//
+// Same contract and step structure as chain_kernel (mvsn_chain.hip): one persistent workgroup per (reference
+// image, source view) chain, previous-plane features resident in LDS, per step the homography gather, the three
+// 3x3 convolutions of FeatureRefiner (multi_view_stereonet.py:424-440) with two GroupNorms, and the cost slice.
+// The convolutions run as Winograd F(2x2,3x3): Y = A^T[(G g G^T) .* (B^T d B)]A, the sum over input channels taken
+// in the transformed domain as 16 small GEMMs M_xi[cout][patch] = sum_cin U_xi[cout][cin] V_xi[cin][patch] on
+// v_mfma_f32_16x16x4_f32 -- 16 products per 2x2 outputs and (cin, cout) pair instead of 36, all fp32.
+//
+//   * 512 threads = 8 waves (2 per SIMD, 256 VGPRs each).  Wave w owns patch tile w = 16 consecutive 2x2 patches
+//     (at 16x32: patch row w) and BOTH cout tiles: 2 x 16 accumulators of 4 = 128 VGPRs.
+//   * A = U_xi (16 couts x 4 cins), B = V_xi (4 cins x 16 patches).  Lane (k = lane>>4, p = lane&15) reads the 4x4
+//     input window of patch p, channel 4*c4 + k straight from the activation planes (four ds_read2_b64: data column
+//     x is stored at index x + 1, so a window starts on an even index) and computes B^T d B in registers (32 adds);
+//     the 16 coefficients it ends up with ARE its B-fragment values.  No transformed tile is ever stored.
+//   * D = couts x patches: a lane ends up with 4 consecutive couts of its own patch for all 16 xi, so the output
+//     transform A^T m A runs in registers and GroupNorm reduces over half-waves exactly as in the direct kernel.
+//   * Transformed weights: 72 / 64 / 64 KB per layer -- one layer fits next to the activation planes.  The U of the
+//     NEXT layer is fetched by LDS-DMA (global_load_lds, 1 KB per instruction, from L2) right after the barrier that
+//     ends the current layer's multiplies, and lands behind the GroupNorm / layout phase that follows.
+//   * GroupNorm: per-wave two-pass moments (count, mean, M2) by DPP reductions, combined across the 8 waves with
+//     Chan's formula behind ONE barrier.
+//
+// LDS plan (floats), RS = cols + 2, CS = (rows + 1) * RS:
+//   U       [9 * 2048]      transformed weights of the current layer, [k-step][cout tile][xi quad][lane][4 xi]
+//   sparams [224]           biases and GroupNorm affine
+//   red     [2][8][4][4]    per-wave GroupNorm moments
+//   maskb   [P]             out-of-image flag of the current plane
+//   act     36 * CS + RS    activation planes: channel c, row y (-1..rows), column x (-1..cols) at
+//                           c*CS + (y+1)*RS + (x+1); row -1 of channel c+1 doubles as row `rows` of channel c.
+//                           Halo rows / columns are zeroed once and never written.
+//                           ch 0..2 image plane d, ch 3..34 features, ch 35 zero (K padding).
+// 16x32: 18432 + 224 + 256 + 512 + 20842 floats = 161,064 bytes of the 163,840.
+#include "mvsn_chain.h"
+#include "mvsn_common.h"
+
+namespace mvsn {
+
+constexpr int CW_THREADS = 512;
+constexpr int CW_WAVES = 8;
+constexpr int CW_RED_FLOATS = 2 * CW_WAVES * 4 * 4;
+constexpr float CW_GN_EPS = 1e-5f;
+
+#define CW_GPTR(p) ((const __attribute__((address_space(1))) void *)(p))
+#define CW_LPTR(p) ((__attribute__((address_space(3))) void *)(p))
+
+static size_t chain_wino_lds_bytes(int rows, int cols) {
+  const int P = rows * cols, RS = cols + 2, CS = (rows + 1) * RS;
+  const size_t f = (size_t)CW_U0_FLOATS + CH_SP_FLOATS + CW_RED_FLOATS + ((P + 3) & ~3) + 36 * (size_t)CS + RS + 2;
+  return f * sizeof(float);
+}
+
+bool chain_wino_supported(int rows, int cols) {
+  if (rows < 2 || cols < 2 || (rows & 1) || (cols & 1)) return false;
+  const int patches = (rows / 2) * (cols / 2);
+  return patches <= CW_WAVES * 16 && rows * cols <= 2 * CW_THREADS && chain_wino_lds_bytes(rows, cols) <= 160 * 1024;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one 3x3 layer: acc[ct][xi] (+)= U_xi * V_xi over NC k-steps of 4 input channels, then the output transform
+// ---------------------------------------------------------------------------------------------
+// The 16 xi = (i, j) are walked in two halves by transform row i (i = 0,1 then i = 2,3): 64 accumulator registers
+// at a time instead of 128, each half's output transform folded into y as soon as its multiplies are done.  The
+// input transform costs the same (row i of B^T d B needs two rows of d), the window reads 3 rows per half.
+template <int NC>
+__device__ __forceinline__ void wino_layer(const float *__restrict__ act, const float *__restrict__ U, int CS, int RS,
+                                           int wb, int lane, float (&y)[2][4][4]) {
+  const float *wbase = act + (lane >> 4) * CS + wb;
+  const float *ub = U + lane * 4;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    floatx4 acc[2][8];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int xi = 0; xi < 8; ++xi) acc[ct][xi] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c4 = 0; c4 < NC; ++c4) {
+      // rows (half 0: 0,1,2; half 1: 1,2,3) of this lane's 4x4 window: rows 2pr-1 .. 2pr+2, columns 2pc-1 .. 2pc+2
+      float d[3][4];
+      const float *wp = wbase + c4 * 4 * CS + half * RS;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float2 lo = *reinterpret_cast<const float2 *>(wp + i * RS);
+        const float2 hi = *reinterpret_cast<const float2 *>(wp + i * RS + 2);
+        d[i][0] = lo.x, d[i][1] = lo.y, d[i][2] = hi.x, d[i][3] = hi.y;
+      }
+      // V = B^T d B,  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]; rows i = 2*half, 2*half + 1
+      float t[2][4], v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (half == 0) {
+          t[0][j] = d[0][j] - d[2][j];   // d0 - d2
+          t[1][j] = d[1][j] + d[2][j];   // d1 + d2
+        } else {
+          t[0][j] = d[1][j] - d[0][j];   // d2 - d1
+          t[1][j] = d[0][j] - d[2][j];   // d1 - d3
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        v[i * 4 + 0] = t[i][0] - t[i][2];
+        v[i * 4 + 1] = t[i][1] + t[i][2];
+        v[i * 4 + 2] = t[i][2] - t[i][1];
+        v[i * 4 + 3] = t[i][1] - t[i][3];
+      }
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int xq = 0; xq < 2; ++xq) {
+          const floatx4 u = *reinterpret_cast<const floatx4 *>(ub + ((c4 * 2 + ct) * 4 + half * 2 + xq) * 256);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[ct][xq * 4 + j] = mfma16x16x4(u[j], v[xq * 4 + j], acc[ct][xq * 4 + j]);
+        }
+    }
+    // Y = A^T m A,  A^T = [[1,1,1,0],[0,1,-1,-1]]: rows m0, m1 (half 0) / m2, m3 (half 1) of m enter
+    // s0 = m0 + m1 + m2 and s1 = m1 - m2 - m3; element r of acc[ct][xi] is cout ct*16 + (lane>>4)*4 + r
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s0[4], s1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (half == 0) {
+            s0[j] = acc[ct][j][r] + acc[ct][4 + j][r];
+            s1[j] = acc[ct][4 + j][r];
+          } else {
+            s0[j] = acc[ct][j][r];
+            s1[j] = -acc[ct][j][r] - acc[ct][4 + j][r];
+          }
+        }
+        const float y0 = s0[0] + s0[1] + s0[2], y1 = s0[1] - s0[2] - s0[3];
+        const float y2 = s1[0] + s1[1] + s1[2], y3 = s1[1] - s1[2] - s1[3];
+        if (half == 0) y[ct][r][0] = y0, y[ct][r][1] = y1, y[ct][r][2] = y2, y[ct][r][3] = y3;
+        else y[ct][r][0] += y0, y[ct][r][1] += y1, y[ct][r][2] += y2, y[ct][r][3] += y3;
+      }
+  }
+}
+
+// sum over the 32 lanes of a half-wave (lanes 0..31 hold the channels of GroupNorm group 2ct, 32..63 of 2ct+1)
+__device__ __forceinline__ float half_wave_sum(float s) {
+  s += dpp_mov<0xB1>(s);    // quad_perm [1, 0, 3, 2]
+  s += dpp_mov<0x4E>(s);    // quad_perm [2, 3, 0, 1]
+  s += dpp_mov<0x141>(s);   // row_half_mirror
+  s += dpp_mov<0x140>(s);   // row_mirror
+  s += __shfl_xor(s, 16, 64);
+  return s;
+}
+
+// y (+bias) -> LeakyReLU(GroupNorm(.)) in place.  `nw` = values of one group this wave holds (0 for an idle wave).
+__device__ __forceinline__ void wino_groupnorm_lrelu(float (&y)[2][4][4], bool pvalid, float nw,
+                                                     const float *__restrict__ bias, const float *__restrict__ gamma,
+                                                     const float *__restrict__ beta, float *red_slab, int lane,
+                                                     int wave) {
+  const int cbase = (lane >> 4) * 4;
+  const float inv_nw = nw > 0.f ? 1.0f / nw : 0.f;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float b = bias[ct * 16 + cbase + r];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        y[ct][r][e] += b;
+        s += y[ct][r][e];
+      }
+    }
+    s = half_wave_sum(pvalid ? s : 0.f);
+    const float mw = s * inv_nw;
+    float q = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dv = y[ct][r][e] - mw;
+        q += dv * dv;
+      }
+    q = half_wave_sum(pvalid ? q : 0.f);
+    if ((lane & 31) == 0) {
+      float *rec = red_slab + (wave * 4 + ct * 2 + (lane >> 5)) * 4;
+      rec[0] = nw, rec[1] = mw, rec[2] = q;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int g = ct * 2 + (lane >> 5);
+    float n = 0.f, sm = 0.f;
+#pragma unroll
+    for (int w = 0; w < CW_WAVES; ++w) {
+      const float *rec = red_slab + (w * 4 + g) * 4;
+      n += rec[0];
+      sm += rec[0] * rec[1];
+    }
+    const float mean = sm / n;
+    float m2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < CW_WAVES; ++w) {
+      const float *rec = red_slab + (w * 4 + g) * 4;
+      const float dm = rec[1] - mean;
+      m2 += rec[2] + rec[0] * dm * dm;
+    }
+    const float rstd = 1.0f / sqrtf(m2 / n + CW_GN_EPS);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = ct * 16 + cbase + r;
+      const float sc = rstd * gamma[c];
+      const float sh = beta[c] - mean * sc;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[ct][r][e] = lrelu02(y[ct][r][e] * sc + sh);
+    }
+  }
+}
+
+__global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = blockIdx.x;
+  const int rows = a.rows, cols = a.cols, P = rows * cols, RS = cols + 2, CS = (rows + 1) * RS, D = a.D;
+  const int pcols = cols >> 1, NPT = (rows >> 1) * pcols;
+
+  float *U = smem;
+  float *sparams = U + CW_U0_FLOATS;
+  float *red = sparams + CH_SP_FLOATS;
+  float *maskb = red + CW_RED_FLOATS;
+  const int Ppad = (P + 3) & ~3;
+  float *act = maskb + Ppad;
+  const int act_floats = 36 * CS + RS + 2;
+
+  const float *upk = a.packed + CH_DIRECT_FLOATS;
+  auto dma_u = [&](const float *src, int nchunks) {   // 1 KB runs, wave w takes runs w, w + 8, ...
+    const int runs = nchunks * (CW_UCHUNK / 256);
+    for (int run = wave; run < runs; run += CW_WAVES)
+      __builtin_amdgcn_global_load_lds(CW_GPTR(src + (size_t)run * 256 + lane * 4), CW_LPTR(U + run * 256), 16, 0, 0);
+  };
+  auto dma_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+  // ---- one-time set-up ---------------------------------------------------------------------
+  dma_u(upk, 9);
+  for (int i = tid; i < act_floats; i += CW_THREADS) act[i] = 0.0f;
+  for (int i = tid; i < CH_SP_FLOATS; i += CW_THREADS) sparams[i] = a.packed[CH_W0_FLOATS + 2 * CH_W1_FLOATS + i];
+  const float *bias0 = sparams, *gn0w = sparams + 32, *gn0b = sparams + 64, *bias1 = sparams + 96,
+              *gn1w = sparams + 128, *gn1b = sparams + 160, *bias2 = sparams + 192;
+
+  // this lane's patch: q = wave*16 + (lane & 15); its 2x2 outputs (2pr + a, 2pc + b), element e = a*2 + b
+  const int q = wave * 16 + (lane & 15);
+  const bool pvalid = q < NPT;
+  const int qq = pvalid ? q : 0;
+  const int pr = qq / pcols, pc = qq - pr * pcols;
+  const int wb = (2 * pr) * RS + 2 * pc;                 // window origin inside a channel plane
+  const int ob = wb + RS + 1;                            // output (0,0); (a,b) at ob + a*RS + b
+  const int cbase = (lane >> 4) * 4;                     // this lane's couts: ct*16 + cbase + r
+  const bool tile_live = wave * 16 < NPT;                // wave-uniform
+  const int nvalid = NPT - wave * 16 < 16 ? (NPT - wave * 16 < 0 ? 0 : NPT - wave * 16) : 16;
+  const float nw = (float)(nvalid * 32);                 // values per GroupNorm group held by this wave
+  __syncthreads();
+
+  const float *f0 = a.f0 + (size_t)n * 32 * P;
+  const float *flp = a.fl + (size_t)(n % a.B) * 32 * P;
+  for (int i = tid; i < 32 * P; i += CW_THREADS) {
+    const int c = i / P, p = i - c * P;
+    const int yy = p / cols, xx = p - yy * cols;
+    act[(3 + c) * CS + (yy + 1) * RS + xx + 1] = f0[i];
+  }
+
+  const float *Hn = a.H + (size_t)n * D * 9;
+  const float *Hin = a.Hinc + (size_t)n * D * 9;
+  const float *src = a.src + (size_t)n * 3 * P;
+  uint8_t *maskg = a.mask + (size_t)n * D * P;
+  float *costg = a.cost + (size_t)n * 32 * D * P;
+  float *fvolg = a.fvol ? a.fvol + (size_t)n * 32 * D * P : nullptr;
+
+  // ---- plane 0: mask from the plane's homography ------------------------------------------------
+  {
+    float Hl[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Hl[i] = Hn[i];
+    for (int p = tid; p < P; p += CW_THREADS) {
+      WarpCoord c = warp_coord(Hl, (float)(p % cols), (float)(p / cols), (float)rows, (float)cols);
+      maskb[p] = c.outside ? 1.0f : 0.0f;
+      maskg[p] = c.outside ? 1 : 0;
+    }
+  }
+  __syncthreads();
+
+  // Cost-volume slice of plane `dd` from the LDS-resident features: coalesced 16-byte HBM traffic (left features
+  // in, cost out; the stores are streaming so that the left features and the weights stay in L2).
+  auto write_cost_slice = [&](int dd) {
+    if ((cols & 3) == 0) {
+      const int quads = P >> 2;
+      for (int i = tid; i < 32 * quads; i += CW_THREADS) {
+        const int c = i / quads, p4 = (i - c * quads) * 4;
+        const int yy = p4 / cols, xx = p4 - yy * cols;
+        const float *fr = act + (3 + c) * CS + (yy + 1) * RS + xx + 1;
+        const floatx4 l = *reinterpret_cast<const floatx4 *>(flp + (size_t)c * P + p4);
+        const floatx4 m = *reinterpret_cast<const floatx4 *>(maskb + p4);
+        floatx4 cst, ftr;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float f = fr[k];
+          cst[k] = m[k] != 0.0f ? 0.0f : fabsf(l[k] - f);
+          ftr[k] = m[k] != 0.0f ? 0.0f : f;
+        }
+        __builtin_nontemporal_store(cst, reinterpret_cast<floatx4 *>(costg + ((size_t)c * D + dd) * P + p4));
+        if (fvolg) __builtin_nontemporal_store(ftr, reinterpret_cast<floatx4 *>(fvolg + ((size_t)c * D + dd) * P + p4));
+      }
+    } else {
+      for (int i = tid; i < 32 * P; i += CW_THREADS) {
+        const int c = i / P, p = i - c * P;
+        const int yy = p / cols, xx = p - yy * cols;
+        const float f = act[(3 + c) * CS + (yy + 1) * RS + xx + 1];
+        const bool out = maskb[p] != 0.0f;
+        costg[((size_t)c * D + dd) * P + p] = out ? 0.0f : fabsf(flp[(size_t)c * P + p] - f);
+        if (fvolg) fvolg[((size_t)c * D + dd) * P + p] = out ? 0.0f : f;
+      }
+    }
+  };
+
+  // ---- the recurrence ------------------------------------------------------------------------
+#define CW_STAMP(i)                                                                     \
+  do {                                                                                  \
+    if (a.dbg && blockIdx.x == 0 && tid == 0 && d <= 4) a.dbg[(d - 1) * 16 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
+  for (int d = 1; d < D; ++d) {
+    CW_STAMP(0);
+    write_cost_slice(d - 1);
+
+    // A1: image plane d and its mask (global gathers; the 6 KB source image stays in L1/L2)
+    float img[2][3], mk[2];
+    {
+      float Hl[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Hl[i] = Hn[d * 9 + i];
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int p = tid + it * CW_THREADS;
+        if (p < P) {
+          WarpCoord c = warp_coord(Hl, (float)(p % cols), (float)(p / cols), (float)rows, (float)cols);
+          Bilinear b = bilinear_taps(c.ix, c.iy, rows, cols);
+          const float keep = c.outside ? 0.0f : 1.0f;
+          mk[it] = c.outside ? 1.0f : 0.0f;
+          const int o00 = b.y0 * cols + b.x0, o01 = b.y0 * cols + b.x1, o10 = b.y1 * cols + b.x0,
+                    o11 = b.y1 * cols + b.x1;
+#pragma unroll
+          for (int ch = 0; ch < 3; ++ch) {
+            const float *ic = src + (size_t)ch * P;
+            img[it][ch] = keep * (ic[o00] * b.w00 + ic[o01] * b.w01 + ic[o10] * b.w10 + ic[o11] * b.w11);
+          }
+        }
+      }
+    }
+
+    // A2: previous plane's features moved by the incremental homography (gather from LDS).  The +1 taps are read
+    // unclamped: when the clamp would act their weight is exactly zero and the slot read is a zero halo.
+    float fp[2][4][4];
+    {
+      float Hl[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Hl[i] = Hin[d * 9 + i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float px = (float)(2 * pc + (e & 1)), py = (float)(2 * pr + (e >> 1));
+        WarpCoord c = warp_coord(Hl, px, py, (float)rows, (float)cols);
+        Bilinear b = bilinear_taps(c.ix, c.iy, rows, cols);
+        const float keep = c.outside ? 0.0f : 1.0f;
+        const float w00 = keep * b.w00, w01 = keep * b.w01, w10 = keep * b.w10, w11 = keep * b.w11;
+        const int o = (b.y0 + 1) * RS + b.x0 + 1;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float *fc = act + (3 + ct * 16 + cbase + r) * CS + o;
+            fp[ct][r][e] = fc[0] * w00 + fc[1] * w01 + fc[RS] * w10 + fc[RS + 1] * w11;
+          }
+      }
+    }
+    CW_STAMP(1);
+    __syncthreads();  // B1: every gather of plane d-1 is done
+    CW_STAMP(2);
+
+    // A3: lay out the refiner input [image(3) | moved features(32)]
+    if (pvalid) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float *dst = act + (3 + ct * 16 + cbase + r) * CS + ob;
+          dst[0] = fp[ct][r][0], dst[1] = fp[ct][r][1], dst[RS] = fp[ct][r][2], dst[RS + 1] = fp[ct][r][3];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int p = tid + it * CW_THREADS;
+      if (p < P) {
+        const int yy = p / cols, xx = p - yy * cols;
+        const int o = (yy + 1) * RS + xx + 1;
+        act[0 * CS + o] = img[it][0];
+        act[1 * CS + o] = img[it][1];
+        act[2 * CS + o] = img[it][2];
+        maskb[p] = mk[it];
+        maskg[(size_t)d * P + p] = mk[it] != 0.0f ? 1 : 0;
+      }
+    }
+    dma_landed();     // conv0's U (issued behind the previous step's conv2, or in the set-up)
+    __syncthreads();  // B2
+    CW_STAMP(3);
+
+    float y[2][4][4] = {};
+    if (tile_live) wino_layer<9>(act, U, CS, RS, wb, lane, y);
+    CW_STAMP(4);
+    __syncthreads();  // B3: act and U free
+    dma_u(upk + CW_U0_FLOATS, 8);
+    CW_STAMP(5);
+
+    wino_groupnorm_lrelu(y, pvalid && tile_live, nw, bias0, gn0w, gn0b, red, lane, wave);
+    if (pvalid) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float *dst = act + (ct * 16 + cbase + r) * CS + ob;
+          dst[0] = y[ct][r][0], dst[1] = y[ct][r][1], dst[RS] = y[ct][r][2], dst[RS + 1] = y[ct][r][3];
+        }
+    }
+    dma_landed();
+    __syncthreads();  // B6
+    CW_STAMP(6);
+
+    if (tile_live) wino_layer<8>(act, U, CS, RS, wb, lane, y);
+    CW_STAMP(7);
+    __syncthreads();  // B7
+    dma_u(upk + CW_U0_FLOATS + CW_U1_FLOATS, 8);
+    CW_STAMP(8);
+
+    wino_groupnorm_lrelu(y, pvalid && tile_live, nw, bias1, gn1w, gn1b, red + CW_RED_FLOATS / 2, lane, wave);
+    if (pvalid) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {   // x2 = x1 + LReLU(GN(conv1(x1)))
+          float *dst = act + (ct * 16 + cbase + r) * CS + ob;
+          dst[0] += y[ct][r][0], dst[1] += y[ct][r][1], dst[RS] += y[ct][r][2], dst[RS + 1] += y[ct][r][3];
+        }
+    }
+    dma_landed();
+    __syncthreads();  // B10
+    CW_STAMP(9);
+
+    if (tile_live) wino_layer<8>(act, U, CS, RS, wb, lane, y);
+    CW_STAMP(10);
+    __syncthreads();  // B11
+    dma_u(upk, 9);    // conv0 of the next step
+    CW_STAMP(11);
+
+    // epilogue: the new features become the next step's gather source; their cost slice is written (coalesced)
+    // at the top of the next step / after the loop
+    if (pvalid) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float b2 = bias2[ct * 16 + cbase + r];
+          float *dst = act + (3 + ct * 16 + cbase + r) * CS + ob;
+          dst[0] = fp[ct][r][0] + (y[ct][r][0] + b2);
+          dst[1] = fp[ct][r][1] + (y[ct][r][1] + b2);
+          dst[RS] = fp[ct][r][2] + (y[ct][r][2] + b2);
+          dst[RS + 1] = fp[ct][r][3] + (y[ct][r][3] + b2);
+        }
+    }
+    CW_STAMP(12);
+    __syncthreads();  // B12
+    CW_STAMP(13);
+  }
+#undef CW_STAMP
+  dma_landed();       // the last step's look-ahead fetch must not outlive the workgroup's LDS
+  write_cost_slice(D - 1);
+}
+
+int chain_wino_launch(const ChainArgs &a, int n_chains, hipStream_t stream) {
+  const size_t lds = chain_wino_lds_bytes(a.rows, a.cols);
+  static LdsOptIn opt;
+  if (int rc = ensure_lds(opt, (const void *)chain_wino_kernel, lds, "mvsn_incremental_cost_volume(winograd)")) return rc;
+  hipLaunchKernelGGL(chain_wino_kernel, dim3(n_chains), dim3(CW_THREADS), lds, stream, a);
+  return check_launch("mvsn_incremental_cost_volume(winograd)");
+}
+
+}  // namespace mvsn

@@ -107,8 +107,11 @@ class EngineOptions:
         # residual_tower_unfused); False keeps one pass per block (tests compare the two).
         self.trim_tower_ends = True
         self.cat_free_heads = True         # refiner heads read [image, features, idepth] in place (no torch.cat)
+        # The fused chain's three 3x3 convolutions: "auto" = Winograd F(2x2,3x3) where the coarse grid has a plan
+        # (16x32 at 512x256 frames), the direct implicit GEMM elsewhere; "direct" / "winograd" force one form.
+        self.chain_form = "auto"
 
-    NAMES = ("fold_residual_blocks", "conv_precision", "winograd", "winograd_with_input_transform",
+    NAMES = ("chain_form", "fold_residual_blocks", "conv_precision", "winograd", "winograd_with_input_transform",
              "winograd_volume", "volume_materialise", "trim_tower_ends", "cat_free_heads")
 
 
@@ -472,13 +475,16 @@ class PlaneSweepEngine:
         cost = torch.empty((N, 32, D, rows, cols), dtype=torch.float32, device=dev)
         mask = torch.empty((N, D, rows, cols), dtype=torch.bool, device=dev)
         fvol = torch.empty_like(cost) if want_features else None
+        form = {"auto": _native.CHAIN_AUTO, "direct": _native.CHAIN_DIRECT, "winograd": _native.CHAIN_WINOGRAD}[self.chain_form]
+        if form == _native.CHAIN_WINOGRAD and self.lib.mvsn_incremental_cost_volume_form(rows, cols) != form:
+            form = _native.CHAIN_DIRECT        # no Winograd plan for this coarse grid
         ws_bytes = self.lib.mvsn_incremental_cost_volume_workspace_bytes(N, rows, cols)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
         P = rows * cols
         self._call("mvsn_incremental_cost_volume", self.lib.mvsn_incremental_cost_volume,
                    _native.ptr(src4), _native.ptr(H4), _native.ptr(Hinc), _native.ptr(plane0), _native.ptr(left_feats),
                    _native.ptr(self.refiner_packed), N, B, D, rows, cols, _native.ptr(cost), _native.ptr(mask),
-                   _native.ptr(fvol), _native.ptr(ws), ws_bytes, _native.stream(),
+                   _native.ptr(fvol), _native.ptr(ws), ws_bytes, form, _native.stream(),
                    flops=N * (D - 1) * 2.0 * 9 * 32 * (35 + 32 + 32) * P,
                    nbytes=N * (4.0 * 67 * P + 128.0 * D * P + D * P))  # Kernel A algorithmic bytes
         return cost, mask, fvol

@@ -51,8 +51,12 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/mvsn_hip.h but not exported"
     assert declared == set(_native.SIGNATURES), (declared ^ set(_native.SIGNATURES))
     typed = _native.load()
-    assert typed.mvsn_abi_version() == 1
-    assert typed.mvsn_feature_refiner_packed_floats() == 9 * 9 * 128 + 2 * 9 * 8 * 128 + 7 * 32
+    assert typed.mvsn_abi_version() == _native.ABI_VERSION == 2
+    assert typed.mvsn_feature_refiner_packed_floats() == (9 * 9 * 128 + 2 * 9 * 8 * 128 + 7 * 32) + 25 * 2048   # direct + Winograd U
+    assert typed.mvsn_incremental_cost_volume_form(16, 32) == _native.CHAIN_WINOGRAD
+    assert typed.mvsn_incremental_cost_volume_form(4, 8) == _native.CHAIN_WINOGRAD
+    assert typed.mvsn_incremental_cost_volume_form(30, 40) == _native.CHAIN_DIRECT      # planes + U exceed 160 KB
+    assert typed.mvsn_incremental_cost_volume_form(5, 6) == _native.CHAIN_DIRECT        # odd rows
 
 
 def test_conv_planning_is_host_side_and_validates():

@@ -512,17 +512,18 @@ def test_flag_branch_elementwise_kernels():
     g = torch.Generator().manual_seed(3)
     x = torch.randn(3, 32, 5, 7, 9, generator=g)
     out = torch.empty(3, 5, 7, 9, device=DEV)
-    _native.check(lib.mvsn_channel_l2_norm(_native.ptr(x.to(DEV)), 3, 32, 5 * 7 * 9, _native.ptr(out), _native.stream()),
-                  "l2")
+    xd = x.to(DEV)
+    _native.check(lib.mvsn_channel_l2_norm(_native.ptr(xd), 3, 32, 5 * 7 * 9, _native.ptr(out), _native.stream()), "l2")
     close(out, torch.norm(x, dim=1), rtol=1e-6, atol=1e-7)
     prior = torch.rand(4, 1, 11, 13, generator=g) * 2
     delta = torch.randn(4, 1, 11, 13, generator=g) * 40
     fx = torch.tensor([410.0, 25.6, 51.2, 102.4])
     o1, o2 = torch.empty(4, 1, 11, 13, device=DEV), torch.empty(4, 1, 11, 13, device=DEV)
-    _native.check(lib.mvsn_idepth_scale(_native.ptr(prior.to(DEV)), _native.ptr(fx.to(DEV)), 4, 143, _native.ptr(o1),
-                                        _native.stream()), "scale")
-    _native.check(lib.mvsn_refiner_epilogue(_native.ptr(prior.to(DEV)), _native.ptr(fx.to(DEV)),
-                                            _native.ptr(delta.to(DEV)), 4, 143, _native.ptr(o2), _native.stream()), "epi")
+    pd, fd, dd = prior.to(DEV), fx.to(DEV), delta.to(DEV)      # kept alive across the raw-pointer calls
+    _native.check(lib.mvsn_idepth_scale(_native.ptr(pd), _native.ptr(fd), 4, 143, _native.ptr(o1), _native.stream()),
+                  "scale")
+    _native.check(lib.mvsn_refiner_epilogue(_native.ptr(pd), _native.ptr(fd), _native.ptr(dd), 4, 143, _native.ptr(o2),
+                                            _native.stream()), "epi")
     sc = fx.view(-1, 1, 1, 1)
     assert torch.equal(o1.cpu(), prior * sc)
     assert torch.equal(o2.cpu(), torch.relu(prior * sc + delta) / sc)
@@ -591,11 +592,25 @@ def test_upsamplers_golden_units():
                                                    (80, 96, 8, 2, 2, "gta_sfm_150epochs"),
                                                    (480, 640, 12, 1, 1, "demon_45epochs"),
                                                    (512, 1024, 6, 1, 1, "gta_sfm_150epochs")])
-def test_incremental_chain_vs_oracle(rows, cols, D, S, B, wname):
+@pytest.mark.parametrize("form", ["direct", "winograd"])
+def test_incremental_chain_vs_oracle(rows, cols, D, S, B, wname, form):
     """The fused chain (features, cost, mask) against the oracle's step-by-step recurrence, fed
-    with the SAME plane-0 features and homographies so only the chain itself is compared."""
+    with the SAME plane-0 features and homographies so only the chain itself is compared.  Both forms of the
+    three 3x3 convolutions: direct implicit GEMM (any grid) and Winograd F(2x2,3x3) (where the grid has a plan)."""
     w = load_weights(wname)
-    eng = net_for(wname).engine()
+    net = net_for(wname)
+    eng = net.engine()
+    r4, c4 = (rows + 15) // 16, (cols + 15) // 16
+    if form == "winograd" and eng.lib.mvsn_incremental_cost_volume_form(r4, c4) != _native.CHAIN_WINOGRAD:
+        pytest.skip(f"no Winograd plan for a {r4}x{c4} coarse grid")
+    net.options.chain_form = form
+    try:
+        _chain_vs_oracle(w, eng, rows, cols, D, S, B, form)
+    finally:
+        net.options.chain_form = "auto"
+
+
+def _chain_vs_oracle(w, eng, rows, cols, D, S, B, form):
     batch = synthetic.make_batch(rows, cols, S, batch=B, seed=11, pose_jitter=0.2)
     inp = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
     r4, c4 = inp["left_image_pyr"][4].shape[-2:]
@@ -623,6 +638,7 @@ def test_incremental_chain_vs_oracle(rows, cols, D, S, B, wname):
         assert int((mask.cpu() != mask_ref).sum()) == 0
         for name, a, b in (("features", fvol, fvol_ref), ("cost", cost, cost_ref)):
             mean_rel, max_rel = rel_err(a.cpu(), b)
+            print(f"chain[{form}] {r4}x{c4} D={D} source {s} {name}: mean-rel {mean_rel:.3e} max-rel {max_rel:.3e}")
             assert mean_rel < 1e-4 and max_rel < 2e-3, (name, s, mean_rel, max_rel)
 
 
