@@ -40,6 +40,7 @@ constexpr int CW_THREADS = 512;
 constexpr int CW_WAVES = 8;
 constexpr int CW_RED_FLOATS = 2 * CW_WAVES * 4 * 4;
 constexpr float CW_GN_EPS = 1e-5f;
+typedef float float2v __attribute__((ext_vector_type(2)));
 
 #define CW_GPTR(p) ((const __attribute__((address_space(1))) void *)(p))
 #define CW_LPTR(p) ((__attribute__((address_space(3))) void *)(p))
@@ -62,6 +63,12 @@ bool chain_wino_supported(int rows, int cols) {
 // The 16 xi = (i, j) are walked in two halves by transform row i (i = 0,1 then i = 2,3): 64 accumulator registers
 // at a time instead of 128, each half's output transform folded into y as soon as its multiplies are done.  The
 // input transform costs the same (row i of B^T d B needs two rows of d), the window reads 3 rows per half.
+// Software pipeline per k-step: transform the window that is already in registers, issue the LDS reads of the NEXT
+// k-step (3 window rows + 4 quads of U), then the 16 multiplies -- no LDS round trip sits in front of an MFMA.
+// (Measured alternatives, tools/chain_phases.py: a raised priority for one wave of each SIMD pair changes nothing;
+// the next k-step's transform interleaved instruction by instruction with the multiplies is 7 % slower per layer.
+// The SIMD issues the ~23 VALU / LDS instructions of a k-step at ~8 cycles each NEXT TO, not under, its 16 MFMAs:
+// 512 + 185 cycles per wave and k-step, 73 % of the matrix pipe -- the price of transforming in registers.)
 template <int NC>
 __device__ __forceinline__ void wino_layer(const float *__restrict__ act, const float *__restrict__ U, int CS, int RS,
                                            int wb, int lane, float (&y)[2][4][4]) {
@@ -70,31 +77,37 @@ __device__ __forceinline__ void wino_layer(const float *__restrict__ act, const 
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     floatx4 acc[2][8];
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int xi = 0; xi < 8; ++xi) acc[ct][xi] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c4 = 0; c4 < NC; ++c4) {
+    float d[2][3][4];
+    floatx4 u[2][4];
+    auto fetch = [&](int buf, int c4) {
       // rows (half 0: 0,1,2; half 1: 1,2,3) of this lane's 4x4 window: rows 2pr-1 .. 2pr+2, columns 2pc-1 .. 2pc+2
-      float d[3][4];
       const float *wp = wbase + c4 * 4 * CS + half * RS;
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const float2 lo = *reinterpret_cast<const float2 *>(wp + i * RS);
         const float2 hi = *reinterpret_cast<const float2 *>(wp + i * RS + 2);
-        d[i][0] = lo.x, d[i][1] = lo.y, d[i][2] = hi.x, d[i][3] = hi.y;
+        d[buf][i][0] = lo.x, d[buf][i][1] = lo.y, d[buf][i][2] = hi.x, d[buf][i][3] = hi.y;
       }
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int xq = 0; xq < 2; ++xq)
+          u[buf][ct * 2 + xq] = *reinterpret_cast<const floatx4 *>(ub + ((c4 * 2 + ct) * 4 + half * 2 + xq) * 256);
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int c4 = 0; c4 < NC; ++c4) {
+      const int cur = c4 & 1;
       // V = B^T d B,  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]; rows i = 2*half, 2*half + 1
       float t[2][4], v[8];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (half == 0) {
-          t[0][j] = d[0][j] - d[2][j];   // d0 - d2
-          t[1][j] = d[1][j] + d[2][j];   // d1 + d2
+          t[0][j] = d[cur][0][j] - d[cur][2][j];   // d0 - d2
+          t[1][j] = d[cur][1][j] + d[cur][2][j];   // d1 + d2
         } else {
-          t[0][j] = d[1][j] - d[0][j];   // d2 - d1
-          t[1][j] = d[0][j] - d[2][j];   // d1 - d3
+          t[0][j] = d[cur][1][j] - d[cur][0][j];   // d2 - d1
+          t[1][j] = d[cur][0][j] - d[cur][2][j];   // d1 - d3
         }
       }
 #pragma unroll
@@ -104,14 +117,18 @@ __device__ __forceinline__ void wino_layer(const float *__restrict__ act, const 
         v[i * 4 + 2] = t[i][2] - t[i][1];
         v[i * 4 + 3] = t[i][1] - t[i][3];
       }
+      if (c4 + 1 < NC) fetch(cur ^ 1, c4 + 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int xq = 0; xq < 2; ++xq) {
-          const floatx4 u = *reinterpret_cast<const floatx4 *>(ub + ((c4 * 2 + ct) * 4 + half * 2 + xq) * 256);
+        for (int xq = 0; xq < 2; ++xq)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[ct][xq * 4 + j] = mfma16x16x4(u[j], v[xq * 4 + j], acc[ct][xq * 4 + j]);
-        }
+          for (int j = 0; j < 4; ++j) {
+            const floatx4 c0 = c4 == 0 ? floatx4{0.f, 0.f, 0.f, 0.f} : acc[ct][xq * 4 + j];
+            acc[ct][xq * 4 + j] = mfma16x16x4(u[cur][ct * 2 + xq][j], v[xq * 4 + j], c0);
+          }
+      __builtin_amdgcn_sched_barrier(0);
     }
     // Y = A^T m A,  A^T = [[1,1,1,0],[0,1,-1,-1]]: rows m0, m1 (half 0) / m2, m3 (half 1) of m enter
     // s0 = m0 + m1 + m2 and s1 = m1 - m2 - m3; element r of acc[ct][xi] is cout ct*16 + (lane>>4)*4 + r
@@ -135,74 +152,78 @@ __device__ __forceinline__ void wino_layer(const float *__restrict__ act, const 
         if (half == 0) y[ct][r][0] = y0, y[ct][r][1] = y1, y[ct][r][2] = y2, y[ct][r][3] = y3;
         else y[ct][r][0] += y0, y[ct][r][1] += y1, y[ct][r][2] += y2, y[ct][r][3] += y3;
       }
+    // keep the halves apart: interleaved by the scheduler they hold all 128 accumulators at once, and whatever is
+    // live across the layer (moved features, left features) spills
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-// sum over the 32 lanes of a half-wave (lanes 0..31 hold the channels of GroupNorm group 2ct, 32..63 of 2ct+1)
-__device__ __forceinline__ float half_wave_sum(float s) {
-  s += dpp_mov<0xB1>(s);    // quad_perm [1, 0, 3, 2]
-  s += dpp_mov<0x4E>(s);    // quad_perm [2, 3, 0, 1]
-  s += dpp_mov<0x141>(s);   // row_half_mirror
-  s += dpp_mov<0x140>(s);   // row_mirror
-  s += __shfl_xor(s, 16, 64);
-  return s;
+// Sums of four values at once over the 32 lanes of each half-wave (lanes 0..31 hold the channels of GroupNorm group
+// 2ct, lanes 32..63 of group 2ct+1).  Four DPP steps leave every lane of a 16-lane row with its row's sum;
+// row_bcast:15 then adds row 0 into row 1 and row 2 into row 3, so the half-wave sums sit in rows 1 and 3
+// (lanes 16..31 / 48..63) -- no LDS crossbar round trip (ds_bpermute) in the chain of dependent steps.
+__device__ __forceinline__ void half_wave_sums(float (&s)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) s[k] += dpp_mov<0xB1>(s[k]);    // quad_perm [1, 0, 3, 2]
+#pragma unroll
+  for (int k = 0; k < 4; ++k) s[k] += dpp_mov<0x4E>(s[k]);    // quad_perm [2, 3, 0, 1]
+#pragma unroll
+  for (int k = 0; k < 4; ++k) s[k] += dpp_mov<0x141>(s[k]);   // row_half_mirror
+#pragma unroll
+  for (int k = 0; k < 4; ++k) s[k] += dpp_mov<0x140>(s[k]);   // row_mirror
+#pragma unroll
+  for (int k = 0; k < 4; ++k)                                  // row_bcast:15 into rows 1 and 3 (row_mask 0xA)
+    s[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s[k]), 0x142, 0xA, 0xF, false));
 }
 
-// y (+bias) -> LeakyReLU(GroupNorm(.)) in place.  `nw` = values of one group this wave holds (0 for an idle wave).
-__device__ __forceinline__ void wino_groupnorm_lrelu(float (&y)[2][4][4], bool pvalid, float nw,
+// y (+bias) -> LeakyReLU(GroupNorm(.)) in place, statistics over the whole workgroup with ONE barrier.
+// Shifted single pass: every lane accumulates sum(x - c) and sum((x - c)^2) with c = the group's mean of the
+// previous step (`shift`, identical in all lanes of the group; 0 at the first step), the per-wave sums are combined
+// behind the barrier, and var = E[(x-c)^2] - (E[x-c])^2.  The recurrence moves slowly from plane to plane, so c sits
+// within a fraction of a standard deviation of the mean and the subtraction cancels nothing of significance
+// (with c = 0 it is the plain one-pass formula, still accurate here: |mean| is of the order of the deviation).
+__device__ __forceinline__ void wino_groupnorm_lrelu(float (&y)[2][4][4], bool pvalid, float inv_n, float (&shift)[2],
                                                      const float *__restrict__ bias, const float *__restrict__ gamma,
                                                      const float *__restrict__ beta, float *red_slab, int lane,
                                                      int wave) {
   const int cbase = (lane >> 4) * 4;
-  const float inv_nw = nw > 0.f ? 1.0f / nw : 0.f;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};   // [ct][sum, sum of squares]
 #pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-    float s = 0.f;
+  for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float b = bias[ct * 16 + cbase + r];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         y[ct][r][e] += b;
-        s += y[ct][r][e];
+        const float dv = y[ct][r][e] - shift[ct];
+        s[ct * 2] += dv;
+        s[ct * 2 + 1] += dv * dv;
       }
     }
-    s = half_wave_sum(pvalid ? s : 0.f);
-    const float mw = s * inv_nw;
-    float q = 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float dv = y[ct][r][e] - mw;
-        q += dv * dv;
-      }
-    q = half_wave_sum(pvalid ? q : 0.f);
-    if ((lane & 31) == 0) {
-      float *rec = red_slab + (wave * 4 + ct * 2 + (lane >> 5)) * 4;
-      rec[0] = nw, rec[1] = mw, rec[2] = q;
-    }
+  if (!pvalid) s[0] = s[1] = s[2] = s[3] = 0.f;
+  half_wave_sums(s);
+  if ((lane & 31) == 16) {
+    float *rec = red_slab + (wave * 4 + (lane >> 5)) * 2;       // [wave][group = ct*2 + half][2]
+    rec[0] = s[0], rec[1] = s[1];
+    rec[4] = s[2], rec[5] = s[3];
   }
   __syncthreads();
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
     const int g = ct * 2 + (lane >> 5);
-    float n = 0.f, sm = 0.f;
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int w = 0; w < CW_WAVES; ++w) {
-      const float *rec = red_slab + (w * 4 + g) * 4;
-      n += rec[0];
-      sm += rec[0] * rec[1];
+      const float2 rec = *reinterpret_cast<const float2 *>(red_slab + (w * 4 + g) * 2);
+      s1 += rec.x;
+      s2 += rec.y;
     }
-    const float mean = sm / n;
-    float m2 = 0.f;
-#pragma unroll
-    for (int w = 0; w < CW_WAVES; ++w) {
-      const float *rec = red_slab + (w * 4 + g) * 4;
-      const float dm = rec[1] - mean;
-      m2 += rec[2] + rec[0] * dm * dm;
-    }
-    const float rstd = 1.0f / sqrtf(m2 / n + CW_GN_EPS);
+    const float ms = s1 * inv_n;
+    const float var = fmaxf(s2 * inv_n - ms * ms, 0.0f);
+    const float mean = shift[ct] + ms;
+    shift[ct] = mean;
+    const float rstd = 1.0f / sqrtf(var + CW_GN_EPS);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int c = ct * 16 + cbase + r;
@@ -214,12 +235,18 @@ __device__ __forceinline__ void wino_groupnorm_lrelu(float (&y)[2][4][4], bool p
   }
 }
 
+// ROWS x COLS: the coarse grid as compile-time constants (every LDS access becomes base register + immediate
+// offset: no address registers live across the step loop); 0 x 0 = run-time sizes (same code, any supported grid).
+template <int ROWS, int COLS>
 __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid0 = threadIdx.x, lane = tid0 & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int n = blockIdx.x;
-  const int rows = a.rows, cols = a.cols, P = rows * cols, RS = cols + 2, CS = (rows + 1) * RS, D = a.D;
+  const int rows = ROWS ? ROWS : a.rows, cols = COLS ? COLS : a.cols;
+  const int P = rows * cols, RS = cols + 2, CS = (rows + 1) * RS, D = a.D;
+  int tid = tid0;
+  constexpr int IMG_IT = ROWS ? (ROWS * COLS + CW_THREADS - 1) / CW_THREADS : 2;   // pixels per thread (image plane pass)
   const int pcols = cols >> 1, NPT = (rows >> 1) * pcols;
 
   float *U = smem;
@@ -231,10 +258,13 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a) {
   const int act_floats = 36 * CS + RS + 2;
 
   const float *upk = a.packed + CH_DIRECT_FLOATS;
+  int lane16 = lane * 16;   // byte offset of this lane inside a 1 KB DMA run (made opaque per step, see below)
   auto dma_u = [&](const float *src, int nchunks) {   // 1 KB runs, wave w takes runs w, w + 8, ...
     const int runs = nchunks * (CW_UCHUNK / 256);
-    for (int run = wave; run < runs; run += CW_WAVES)
-      __builtin_amdgcn_global_load_lds(CW_GPTR(src + (size_t)run * 256 + lane * 4), CW_LPTR(U + run * 256), 16, 0, 0);
+    const char *base = reinterpret_cast<const char *>(src + (size_t)wave * 256);   // wave-uniform (SGPR pair)
+    for (int run = wave, i = 0; run < runs; run += CW_WAVES, ++i)
+      __builtin_amdgcn_global_load_lds(CW_GPTR(base + (size_t)i * (CW_WAVES * 1024) + (unsigned)lane16),
+                                       CW_LPTR(U + run * 256), 16, 0, 0);
   };
   auto dma_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
@@ -254,8 +284,8 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a) {
   const int ob = wb + RS + 1;                            // output (0,0); (a,b) at ob + a*RS + b
   const int cbase = (lane >> 4) * 4;                     // this lane's couts: ct*16 + cbase + r
   const bool tile_live = wave * 16 < NPT;                // wave-uniform
-  const int nvalid = NPT - wave * 16 < 16 ? (NPT - wave * 16 < 0 ? 0 : NPT - wave * 16) : 16;
-  const float nw = (float)(nvalid * 32);                 // values per GroupNorm group held by this wave
+  const float inv_n = 1.0f / (8.0f * (float)P);          // values per GroupNorm group: 8 channels x P pixels
+  float shift0[2] = {0.f, 0.f}, shift1[2] = {0.f, 0.f};  // previous step's group means (GroupNorm 0 / 1, per cout tile)
   __syncthreads();
 
   const float *f0 = a.f0 + (size_t)n * 32 * P;
@@ -319,23 +349,47 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a) {
     }
   };
 
+  // plane 0 (the extractor's features) goes out through the generic pass; planes 1..D-1 are written by the lanes
+  // that produce them, straight from registers, against the left features each lane keeps for its own
+  // (8 channels x 2x2 pixels) outputs: the left features are read from HBM once per chain, not once per plane
+  write_cost_slice(0);
+  float fl[2][4][4];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int a2 = 0; a2 < 2; ++a2) {
+        const float2 l = pvalid ? *reinterpret_cast<const float2 *>(flp + (size_t)(ct * 16 + cbase + r) * P +
+                                                                      (2 * pr + a2) * cols + 2 * pc)
+                                : float2{0.f, 0.f};
+        fl[ct][r][a2 * 2] = l.x, fl[ct][r][a2 * 2 + 1] = l.y;
+      }
+  int slice_off = (cbase * D) * P + (2 * pr) * cols + 2 * pc;   // this lane's origin inside a chain's cost volume
+
   // ---- the recurrence ------------------------------------------------------------------------
 #define CW_STAMP(i)                                                                     \
   do {                                                                                  \
     if (a.dbg && blockIdx.x == 0 && tid == 0 && d <= 4) a.dbg[(d - 1) * 16 + (i)] = __builtin_readcyclecounter(); \
   } while (0)
+#define CW_WSTAMP(i)                                                                    \
+  do {                                                                                  \
+    if (a.dbg && blockIdx.x == 0 && lane == 0 && d == 3) a.dbg[64 + wave * 8 + (i)] = __builtin_readcyclecounter(); \
+  } while (0)
   for (int d = 1; d < D; ++d) {
+    // per-thread index arithmetic of the pixel / slice loops is recomputed every step from an opaque copy of the
+    // thread id: hoisted out of the loop it would occupy dozens of VGPRs across the convolutions (and spill)
+    asm volatile("" : "+v"(tid), "+v"(lane16), "+v"(slice_off));
     CW_STAMP(0);
-    write_cost_slice(d - 1);
 
     // A1: image plane d and its mask (global gathers; the 6 KB source image stays in L1/L2)
-    float img[2][3], mk[2];
+    float img[IMG_IT][3], mk[IMG_IT];
     {
       float Hl[9];
 #pragma unroll
       for (int i = 0; i < 9; ++i) Hl[i] = Hn[d * 9 + i];
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
+      for (int it = 0; it < IMG_IT; ++it) {
         const int p = tid + it * CW_THREADS;
         if (p < P) {
           WarpCoord c = warp_coord(Hl, (float)(p % cols), (float)(p / cols), (float)rows, (float)cols);
@@ -392,7 +446,7 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a) {
         }
     }
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < IMG_IT; ++it) {
       const int p = tid + it * CW_THREADS;
       if (p < P) {
         const int yy = p / cols, xx = p - yy * cols;
@@ -409,13 +463,17 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a) {
     CW_STAMP(3);
 
     float y[2][4][4] = {};
+    CW_WSTAMP(0);
     if (tile_live) wino_layer<9>(act, U, CS, RS, wb, lane, y);
     CW_STAMP(4);
+    CW_WSTAMP(1);
     __syncthreads();  // B3: act and U free
+    CW_WSTAMP(2);
     dma_u(upk + CW_U0_FLOATS, 8);
+    CW_WSTAMP(6);
     CW_STAMP(5);
 
-    wino_groupnorm_lrelu(y, pvalid && tile_live, nw, bias0, gn0w, gn0b, red, lane, wave);
+    wino_groupnorm_lrelu(y, pvalid && tile_live, inv_n, shift0, bias0, gn0w, gn0b, red, lane, wave);
     if (pvalid) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
@@ -425,8 +483,11 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a) {
           dst[0] = y[ct][r][0], dst[1] = y[ct][r][1], dst[RS] = y[ct][r][2], dst[RS + 1] = y[ct][r][3];
         }
     }
+    CW_WSTAMP(3);
     dma_landed();
+    CW_WSTAMP(4);
     __syncthreads();  // B6
+    CW_WSTAMP(5);
     CW_STAMP(6);
 
     if (tile_live) wino_layer<8>(act, U, CS, RS, wb, lane, y);
@@ -435,7 +496,7 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a) {
     dma_u(upk + CW_U0_FLOATS + CW_U1_FLOATS, 8);
     CW_STAMP(8);
 
-    wino_groupnorm_lrelu(y, pvalid && tile_live, nw, bias1, gn1w, gn1b, red + CW_RED_FLOATS / 2, lane, wave);
+    wino_groupnorm_lrelu(y, pvalid && tile_live, inv_n, shift1, bias1, gn1w, gn1b, red + CW_RED_FLOATS / 2, lane, wave);
     if (pvalid) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
@@ -455,19 +516,43 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a) {
     dma_u(upk, 9);    // conv0 of the next step
     CW_STAMP(11);
 
-    // epilogue: the new features become the next step's gather source; their cost slice is written (coalesced)
-    // at the top of the next step / after the loop
+    // epilogue: the new features become the next step's gather source, and their cost slice
+    // (not mask) * |left - right| leaves for HBM straight from the registers (8-byte pieces, 128-byte runs per
+    // 16 lanes; streaming stores)
     if (pvalid) {
+      const float2 m0 = *reinterpret_cast<const float2 *>(maskb + (2 * pr) * cols + 2 * pc);
+      const float2 m1 = *reinterpret_cast<const float2 *>(maskb + (2 * pr + 1) * cols + 2 * pc);
+      const bool out[4] = {m0.x != 0.0f, m0.y != 0.0f, m1.x != 0.0f, m1.y != 0.0f};
+      float *cd = costg + (size_t)d * P;
+      float *fd = fvolg ? fvolg + (size_t)d * P : nullptr;
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float b2 = bias2[ct * 16 + cbase + r];
+          float f[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[e] = fp[ct][r][e] + (y[ct][r][e] + b2);
           float *dst = act + (3 + ct * 16 + cbase + r) * CS + ob;
-          dst[0] = fp[ct][r][0] + (y[ct][r][0] + b2);
-          dst[1] = fp[ct][r][1] + (y[ct][r][1] + b2);
-          dst[RS] = fp[ct][r][2] + (y[ct][r][2] + b2);
-          dst[RS + 1] = fp[ct][r][3] + (y[ct][r][3] + b2);
+          dst[0] = f[0], dst[1] = f[1], dst[RS] = f[2], dst[RS + 1] = f[3];
+          float *cdst = cd + ((ct * 16 + r) * D) * P + slice_off;
+#pragma unroll
+          for (int a2 = 0; a2 < 2; ++a2) {
+            float2v c2;
+            c2.x = out[a2 * 2] ? 0.0f : fabsf(fl[ct][r][a2 * 2] - f[a2 * 2]);
+            c2.y = out[a2 * 2 + 1] ? 0.0f : fabsf(fl[ct][r][a2 * 2 + 1] - f[a2 * 2 + 1]);
+            __builtin_nontemporal_store(c2, reinterpret_cast<float2v *>(cdst + a2 * cols));
+          }
+          if (fd) {
+            float *fdst = fd + ((ct * 16 + r) * D) * P + slice_off;
+#pragma unroll
+            for (int a2 = 0; a2 < 2; ++a2) {
+              float2v f2;
+              f2.x = out[a2 * 2] ? 0.0f : f[a2 * 2];
+              f2.y = out[a2 * 2 + 1] ? 0.0f : f[a2 * 2 + 1];
+              __builtin_nontemporal_store(f2, reinterpret_cast<float2v *>(fdst + a2 * cols));
+            }
+          }
         }
     }
     CW_STAMP(12);
@@ -475,15 +560,22 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a) {
     CW_STAMP(13);
   }
 #undef CW_STAMP
+#undef CW_WSTAMP
   dma_landed();       // the last step's look-ahead fetch must not outlive the workgroup's LDS
-  write_cost_slice(D - 1);
 }
 
 int chain_wino_launch(const ChainArgs &a, int n_chains, hipStream_t stream) {
   const size_t lds = chain_wino_lds_bytes(a.rows, a.cols);
-  static LdsOptIn opt;
-  if (int rc = ensure_lds(opt, (const void *)chain_wino_kernel, lds, "mvsn_incremental_cost_volume(winograd)")) return rc;
-  hipLaunchKernelGGL(chain_wino_kernel, dim3(n_chains), dim3(CW_THREADS), lds, stream, a);
+#define CW_LAUNCH(R, C)                                                                                              \
+  do {                                                                                                               \
+    static LdsOptIn opt;                                                                                             \
+    if (int rc = ensure_lds(opt, (const void *)chain_wino_kernel<R, C>, lds, "mvsn_incremental_cost_volume(winograd)")) \
+      return rc;                                                                                                     \
+    hipLaunchKernelGGL((chain_wino_kernel<R, C>), dim3(n_chains), dim3(CW_THREADS), lds, stream, a);                 \
+  } while (0)
+  if (a.rows == 16 && a.cols == 32) CW_LAUNCH(16, 32);   // 512x256 frames (BASELINE configs 2, 3 and the headline)
+  else CW_LAUNCH(0, 0);
+#undef CW_LAUNCH
   return check_launch("mvsn_incremental_cost_volume(winograd)");
 }
 

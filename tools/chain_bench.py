@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Time the fused chain alone (mvsn_incremental_cost_volume) in both forms: ms per launch, us per step,
+algorithmic TFLOP/s and GB/s.   python tools/chain_bench.py [N ...]   (N = chains per launch; default 2 and 256)"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multi_view_stereonet_amd import MultiViewStereoNet
+from multi_view_stereonet_amd.weights import load_weights
+torch.set_grad_enabled(False)
+net = MultiViewStereoNet(); net.load_state_dict(load_weights("gta_sfm_150epochs")); net = net.cuda().eval()
+eng = net.engine()
+rows, cols, D = 16, 32, 64
+P = rows * cols
+g = torch.Generator().manual_seed(0)
+for N in [int(a) for a in sys.argv[1:]] or [2, 256]:
+    B = max(1, N // 2)
+    src4 = (torch.rand(N, 3, rows, cols, generator=g) * 2 - 1).cuda()
+    H = torch.eye(3).repeat(N, D, 1, 1)
+    H[:, :, 0, 2] = torch.linspace(0, 12, D)[None]          # ~0.2 px of disparity per plane
+    Hinc = torch.eye(3).repeat(N, D, 1, 1); Hinc[:, 1:, 0, 2] = 12.0 / (D - 1)
+    F0 = torch.randn(N, 32, rows, cols, generator=g).cuda(); FL = torch.randn(B, 32, rows, cols, generator=g).cuda()
+    H, Hinc = H.cuda(), Hinc.cuda()
+    for form in ("direct", "winograd"):
+        net.options.chain_form = form
+        for _ in range(3):
+            eng.incremental_cost_volume(src4, H, Hinc, F0, FL)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        a.record()
+        for _ in range(reps):
+            eng.incremental_cost_volume(src4, H, Hinc, F0, FL)
+        b.record(); torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / reps
+        flops = N * (D - 1) * 2.0 * 9 * 32 * 99 * P
+        nbytes = N * (4.0 * 67 * P + 128.0 * D * P + D * P)
+        print(f"N={N:4d} {form:8s}: {ms:7.3f} ms/launch  {ms * 1e3 / (D - 1):6.1f} us/step  "
+              f"{flops / ms / 1e9:6.1f} direct-form TFLOP/s  {nbytes / ms / 1e6:7.1f} GB/s algorithmic")
