@@ -42,6 +42,10 @@ constexpr int CW_RED_FLOATS = 2 * CW_WAVES * 4 * 4;
 constexpr float CW_GN_EPS = 1e-5f;
 typedef float float2v __attribute__((ext_vector_type(2)));
 
+// Workgroup barrier that publishes LDS writes but leaves global loads / stores in flight (__syncthreads() also waits
+// for vmcnt(0): the cost-slice stores and the left-feature loads would be drained at every barrier of the step).
+__device__ __forceinline__ void cw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 #define CW_GPTR(p) ((const __attribute__((address_space(1))) void *)(p))
 #define CW_LPTR(p) ((__attribute__((address_space(3))) void *)(p))
 
@@ -208,7 +212,7 @@ __device__ __forceinline__ void wino_groupnorm_lrelu(float (&y)[2][4][4], bool p
     rec[0] = s[0], rec[1] = s[1];
     rec[4] = s[2], rec[5] = s[3];
   }
-  __syncthreads();
+  cw_barrier();
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
     const int g = ct * 2 + (lane >> 5);
@@ -350,21 +354,11 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a) {
   };
 
   // plane 0 (the extractor's features) goes out through the generic pass; planes 1..D-1 are written by the lanes
-  // that produce them, straight from registers, against the left features each lane keeps for its own
-  // (8 channels x 2x2 pixels) outputs: the left features are read from HBM once per chain, not once per plane
+  // that produce them, straight from registers: each lane fetches the left features of its own (8 channels x 2x2
+  // pixels) outputs as 8-byte pieces (L2 hits: 64 KB per reference image, shared by its S chains; the cost stores
+  // are streaming and do not evict them) ahead of the barrier that ends the last layer
   write_cost_slice(0);
-  float fl[2][4][4];
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int a2 = 0; a2 < 2; ++a2) {
-        const float2 l = pvalid ? *reinterpret_cast<const float2 *>(flp + (size_t)(ct * 16 + cbase + r) * P +
-                                                                      (2 * pr + a2) * cols + 2 * pc)
-                                : float2{0.f, 0.f};
-        fl[ct][r][a2 * 2] = l.x, fl[ct][r][a2 * 2 + 1] = l.y;
-      }
+  const float *fl_lane = flp + (size_t)cbase * P + (2 * pr) * cols + 2 * pc;
   int slice_off = (cbase * D) * P + (2 * pr) * cols + 2 * pc;   // this lane's origin inside a chain's cost volume
 
   // ---- the recurrence ------------------------------------------------------------------------
@@ -432,7 +426,7 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a) {
       }
     }
     CW_STAMP(1);
-    __syncthreads();  // B1: every gather of plane d-1 is done
+    cw_barrier();  // B1: every gather of plane d-1 is done
     CW_STAMP(2);
 
     // A3: lay out the refiner input [image(3) | moved features(32)]
@@ -459,7 +453,7 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a) {
       }
     }
     dma_landed();     // conv0's U (issued behind the previous step's conv2, or in the set-up)
-    __syncthreads();  // B2
+    cw_barrier();  // B2
     CW_STAMP(3);
 
     float y[2][4][4] = {};
@@ -467,7 +461,7 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a) {
     if (tile_live) wino_layer<9>(act, U, CS, RS, wb, lane, y);
     CW_STAMP(4);
     CW_WSTAMP(1);
-    __syncthreads();  // B3: act and U free
+    cw_barrier();  // B3: act and U free
     CW_WSTAMP(2);
     dma_u(upk + CW_U0_FLOATS, 8);
     CW_WSTAMP(6);
@@ -486,13 +480,13 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a) {
     CW_WSTAMP(3);
     dma_landed();
     CW_WSTAMP(4);
-    __syncthreads();  // B6
+    cw_barrier();  // B6
     CW_WSTAMP(5);
     CW_STAMP(6);
 
     if (tile_live) wino_layer<8>(act, U, CS, RS, wb, lane, y);
     CW_STAMP(7);
-    __syncthreads();  // B7
+    cw_barrier();  // B7
     dma_u(upk + CW_U0_FLOATS + CW_U1_FLOATS, 8);
     CW_STAMP(8);
 
@@ -507,12 +501,21 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a) {
         }
     }
     dma_landed();
-    __syncthreads();  // B10
+    cw_barrier();  // B10
     CW_STAMP(9);
 
     if (tile_live) wino_layer<8>(act, U, CS, RS, wb, lane, y);
+    float2 fl[2][4][2];   // left features of this lane's outputs, in flight across the barrier
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2)
+          fl[ct][r][a2] = pvalid ? *reinterpret_cast<const float2 *>(fl_lane + (size_t)(ct * 16 + r) * P + a2 * cols)
+                                 : float2{0.f, 0.f};
     CW_STAMP(10);
-    __syncthreads();  // B11
+    cw_barrier();  // B11
     dma_u(upk, 9);    // conv0 of the next step
     CW_STAMP(11);
 
@@ -539,8 +542,8 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a) {
 #pragma unroll
           for (int a2 = 0; a2 < 2; ++a2) {
             float2v c2;
-            c2.x = out[a2 * 2] ? 0.0f : fabsf(fl[ct][r][a2 * 2] - f[a2 * 2]);
-            c2.y = out[a2 * 2 + 1] ? 0.0f : fabsf(fl[ct][r][a2 * 2 + 1] - f[a2 * 2 + 1]);
+            c2.x = out[a2 * 2] ? 0.0f : fabsf(fl[ct][r][a2].x - f[a2 * 2]);
+            c2.y = out[a2 * 2 + 1] ? 0.0f : fabsf(fl[ct][r][a2].y - f[a2 * 2 + 1]);
             __builtin_nontemporal_store(c2, reinterpret_cast<float2v *>(cdst + a2 * cols));
           }
           if (fd) {
@@ -556,7 +559,7 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a) {
         }
     }
     CW_STAMP(12);
-    __syncthreads();  // B12
+    cw_barrier();  // B12
     CW_STAMP(13);
   }
 #undef CW_STAMP
