@@ -262,6 +262,34 @@ int mvsn_fuse_sources(const float *raw, const float *refined, const float *basel
                       int n_sources, int batch, int num_idepth_samples, int pixels, int refined_aliases_raw,
                       float *raw_out, float *refined_out, uint8_t *mask_out, mvsn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Two-view consistency (the bidirectional path, multi_view_stereonet_utils.py:503-539 with
+ * estimate_right_idepthmap, and what its outputs feed in multi_view_stereonet/losses.py).
+ *
+ * mvsn_idepth_reproject: every pixel (x, y, idepth) of THIS view is lifted to 3-D, moved into the OTHER view and
+ * projected: its idepth there, its normalised pixel coordinate there, whether that leaves the image
+ * (IDepthmapProjector.forward, stereo/image_predictor.py:538-576), and the other view's idepth map (and optionally a
+ * mask, as float, > 0) sampled at that coordinate (grid_sample bilinear / border / align_corners=False,
+ * losses.py:59-61, :129-135).  absdiff_partials (optional, batch * mvsn_idepth_reproject_blocks(pixels) floats)
+ * receives per-workgroup sums of |sampled - reprojected| for mvsn_occlusion_mask.
+ *   K (B,4,4) of this pyramid level   T_other_in_this (B,4,4)   idepth, other_idepth (B,rows,cols)
+ *   other_mask (B,rows,cols) u8 or NULL
+ *   -> idepth_in_other, other_sampled (B,rows,cols)  other_mask_sampled u8 or NULL  invalid u8  uv (B,rows,cols,2) or NULL
+ * mvsn_occlusion_mask: get_occlusion_mask (losses.py:42-82): (sampled - reprojected) > mean|sampled - reprojected|
+ * of the image, or invalid.
+ * mvsn_masked_l1: loss (+)= mean |a - b| over the elements with neither skip flag set (the two l1_loss terms of
+ * left_right_idepthmap_consistency_losses, losses.py:137-157); NaN when nothing is selected, as the reference.
+ * ------------------------------------------------------------------------------------------- */
+int mvsn_idepth_reproject_blocks(int pixels);
+int mvsn_idepth_reproject(const float *K, const float *T_other_in_this, const float *idepth, const float *other_idepth,
+                          const uint8_t *other_mask, int batch, int rows, int cols, float *idepth_in_other,
+                          float *other_sampled, uint8_t *other_mask_sampled, uint8_t *invalid, float *uv,
+                          float *absdiff_partials, mvsn_stream_t stream);
+int mvsn_occlusion_mask(const float *idepth_in_other, const float *other_sampled, const uint8_t *invalid,
+                        const float *absdiff_partials, int batch, int pixels, uint8_t *mask, mvsn_stream_t stream);
+int mvsn_masked_l1(const float *a, const float *b, const uint8_t *skip_a, const uint8_t *skip_b, long n, int accumulate,
+                   float *loss, mvsn_stream_t stream);
+
 /* Device self-test of the MFMA fragment mapping the conv kernels rely on (A = 16x4, B = 4x16
  * fp32, asymmetric operands); returns 0 when the on-device result matches the scalar product. */
 int mvsn_selftest_mfma(mvsn_stream_t stream);

@@ -58,6 +58,10 @@ SIGNATURES = {
     "mvsn_upsample_mask": (c_int, [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
     "mvsn_area_downsample": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p, c_void_p]),
     "mvsn_fuse_sources": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p] * 3 + [c_void_p]),
+    "mvsn_idepth_reproject_blocks": (c_int, [c_int]),
+    "mvsn_idepth_reproject": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p] * 6 + [c_void_p]),
+    "mvsn_occlusion_mask": (c_int, [c_void_p] * 4 + [c_int] * 2 + [c_void_p, c_void_p]),
+    "mvsn_masked_l1": (c_int, [c_void_p] * 4 + [c_long, c_int, c_void_p, c_void_p]),
     "mvsn_selftest_mfma": (c_int, [c_void_p]),
 }
 

@@ -13,8 +13,9 @@ three transforms the evaluation path uses are written directly on PIL / torch:
                                            the -0.5 px principal-point fix :400-411, depth/<id>.npy)
 * ``DeMoNDataset``                      <- datasets/demon_dataset.py:18-161 (cam.txt, poses.txt, neighbour choice)
 
-No reference run pins these (its readers import torchvision and pyquaternion, both absent): they are
-covered by known-answer tests on synthetic files (tests/test_datasets_cpu.py).
+Pinned to the reference's own readers: tests/golden/make_dataset_golden.py runs them (with stand-ins for the
+torchvision entry points they call) over miniature trees and records every sample; tests/test_datasets_cpu.py replays
+the same files through this module (g10_datasets.npz), next to known-answer tests on synthetic files.
 """
 import glob
 import os
@@ -140,7 +141,10 @@ class MultiViewStereoDataset(tud.Dataset):
             if not os.path.exists(f):
                 raise AssertionError(f"missing image {f}")
         K, T_right_in_left = self.get_calibration(idx)
-        sample = {"left_filename": left_filename, "right_filename": right_filenames,
+        # "right_filename" is the LAST source image's path, not the list: the reference builds the dict from its
+        # loop variable (datasets/multi_view_stereo_dataset.py:303-311) and its callers hash that one string
+        # (multi_view_stereonet_utils.py:302-304)
+        sample = {"left_filename": left_filename, "right_filename": right_filenames[-1],
                   "left_image": Image.open(left_filename), "right_image": [Image.open(f) for f in right_filenames],
                   "K": K, "T_right_in_left": T_right_in_left}
         if self.load_groundtruth_depthmaps:
@@ -233,7 +237,9 @@ class DeMoNDataset(tud.Dataset):
             images = sorted(glob.glob(os.path.join(scene, "*.jpg")))
             if len(images) < num_right + 1:
                 continue
-            bottom = np.array([[0, 0, 0, 1]], dtype=np.float32)
+            # float32 rows under an integer bottom row promote to float64: the reference composes the relative poses
+            # in double and rounds once at the end (datasets/demon_dataset.py:96, :114-116)
+            bottom = np.array([[0, 0, 0, 1]])
             world_in = [np.concatenate((p.reshape(3, 4), bottom), 0) for p in inv_poses]
             for li, left_filename in enumerate(images):
                 shifts = self.neighbour_indices(li, len(images), num_right)

@@ -346,3 +346,64 @@ def forward(w: Weights, left_image_pyr: List[torch.Tensor], K_pyr: List[torch.Te
     if capture is not None:
         capture["left_features"] = left_feats
     return {"left_idepthmap_pyr": idepth, "left_idepthmap_raw_pyr": prior, "left_idepthmap_mask_pyr": masks}
+
+
+# ---------------------------------------------------------------------------------------------------
+# Two-view consistency ops: multi_view_stereonet/losses.py:42-160 over
+# stereo/image_predictor.py:36-118 (DepthmapToPointCloud, PointCloudToPixel) and :525-576 (IDepthmapProjector)
+# ---------------------------------------------------------------------------------------------------
+def idepthmap_projector(K: torch.Tensor, T_right_in_left: torch.Tensor, left_idepthmap: torch.Tensor):
+    """image_predictor.py:538-576: every left pixel (x, y, idepth) -> its normalised pixel coordinate in the right
+    image (B,rows,cols,2), its idepth in the right frame (B,1,rows,cols) and the out-of-image mask (B,1,rows,cols)."""
+    B, _, rows, cols = left_idepthmap.shape
+    Kinv = torch.inverse(K)
+    T_left_in_right = torch.inverse(T_right_in_left)
+    depth = 1.0 / (left_idepthmap + 1e-6)                                       # :557
+    ys, xs = torch.meshgrid(torch.arange(rows), torch.arange(cols), indexing="ij")
+    pix = torch.stack([xs.reshape(-1).float(), ys.reshape(-1).float(), torch.ones(rows * cols)], 0)
+    pts = depth.reshape(B, 1, -1) * torch.matmul(Kinv[:, :3, :3], pix.unsqueeze(0).expand(B, -1, -1))   # :69-70
+    pts = torch.cat([pts, torch.ones(B, 1, rows * cols)], 1)
+    right_pts = torch.matmul(T_left_in_right[:, :3, :], pts)                    # :563
+    right_idepths = (1.0 / (right_pts[:, 2, :] + 1e-6)).view(left_idepthmap.shape)
+    cam = torch.matmul(torch.matmul(K, T_left_in_right)[:, :3, :], pts)         # :104-105
+    uv = cam[:, :2, :] / (cam[:, 2, :].unsqueeze(1) + 1e-7)
+    uv = uv.view(B, 2, rows, cols).permute(0, 2, 3, 1).clone()
+    uv += 0.5
+    uv *= 2.0
+    uv[..., 0] /= cols
+    uv[..., 1] /= rows
+    uv -= 1.0
+    mask = ((uv[..., 0].abs() > 1.0) | (uv[..., 1].abs() > 1.0)).unsqueeze(1)
+    return uv, right_idepths, mask
+
+
+def _sample(image: torch.Tensor, uv: torch.Tensor) -> torch.Tensor:
+    return F.grid_sample(image, uv, mode="bilinear", padding_mode="border", align_corners=False)
+
+
+def get_occlusion_mask(K, T_right_in_left, left_idepthmap, right_idepthmap) -> torch.Tensor:
+    """losses.py:42-82: 1 where a left pixel is occluded in the right view (reprojected idepth farther than the right
+    map's by more than the image's mean absolute difference) or leaves the right image."""
+    B = left_idepthmap.shape[0]
+    uv, id_prime, invalid = idepthmap_projector(K, T_right_in_left, left_idepthmap)
+    id_diff = _sample(right_idepthmap, uv) - id_prime
+    thr = id_diff.view(B, -1).abs().mean(dim=1).view(B, 1, 1, 1)
+    return (id_diff > thr) | invalid
+
+
+def left_right_consistency_loss(T_right_in_left, T_left_in_right, K_pyr, left_idepthmap_pyr, left_occlusion_mask_pyr,
+                                right_idepthmap_pyr, right_occlusion_mask_pyr) -> torch.Tensor:
+    """losses.py:112-160: per level, L1 between the reprojected idepths of one view and the other view's map sampled
+    at the reprojected pixels, over pixels unoccluded in both; both directions, summed over levels."""
+    loss = torch.zeros(())
+    for lvl in range(len(left_idepthmap_pyr)):
+        if left_idepthmap_pyr[lvl] is None:
+            continue
+        for T, a, a_occ, b, b_occ in ((T_right_in_left, left_idepthmap_pyr[lvl], left_occlusion_mask_pyr[lvl],
+                                       right_idepthmap_pyr[lvl], right_occlusion_mask_pyr[lvl]),
+                                      (T_left_in_right, right_idepthmap_pyr[lvl], right_occlusion_mask_pyr[lvl],
+                                       left_idepthmap_pyr[lvl], left_occlusion_mask_pyr[lvl])):
+            uv, projected, _ = idepthmap_projector(K_pyr[lvl], T, a)
+            keep = ~a_occ & ~(_sample(b_occ.float(), uv) > 0)
+            loss = loss + F.l1_loss(projected[keep], _sample(b, uv)[keep])
+    return loss

@@ -20,6 +20,7 @@ Fixtures:
   g6_flags_128x64.npz           do_cost_volume_filter=False / refiners off variants
   g7_depth_metrics.npz          test.py's depth metrics on a synthetic truth/estimate pair
   g8_two_view_128x64_d12.npz    2-view twins (unpack_batch / forward) with the right-view estimate
+  g9_two_view_consistency.npz   occlusion masks + left/right consistency loss of the reference's losses.py, 5 levels
   gc2_gta_512x256_d64_s1.npz    BASELINE config 2 (one source view): outputs only
   gc3_gta_512x256_d64_s5.npz    BASELINE config 3 (five source views): outputs only
   gc5_gta_1024x512_d128_s4.npz  BASELINE config 5 geometry (fp32 reference): idepth_0 (fp32), idepth_4, mask_4
@@ -332,6 +333,49 @@ def two_view_pins(name):
     print(name, "ok")
 
 
+def consistency_pins(name):
+    """Occlusion masks and the left/right consistency loss (section 8f rank 4): the reference's own losses.py
+    (:42-82, :112-160) over its IDepthmapProjector, every pyramid level.  The idepth maps are seeded smooth maps in a
+    geometrically sensible range (0.02 .. 0.1 at unit baseline: the network's estimates on white-noise frames project
+    out of the other image everywhere and pin nothing); poses / intrinsics are the two-view batch of g8."""
+    import copy
+    from multi_view_stereonet import losses as ref_losses
+    mv = synthetic.make_batch(64, 128, 1, batch=2, seed=13, pose_jitter=0.2)
+    batch = {"left_image": mv["left_image"], "right_image": mv["right_image"][0], "K": mv["K"],
+             "T_right_in_left": mv["T_right_in_left"][0], "left_filename": ["l"] * 2, "right_filename": ["r"] * 2}
+    inputs = ref_snu.unpack_batch(copy.deepcopy(batch), torch.device("cpu"), 5)
+    gen = torch.Generator().manual_seed(99)
+    d = {"T_right_in_left": npy(inputs["T_right_in_left"]), "T_left_in_right": npy(inputs["T_left_in_right"])}
+    Ls, Rs, left_occ, right_occ = [], [], [], []
+    for lvl in range(5):
+        rows, cols = inputs["left_image_pyr"][lvl].shape[-2:]
+        L = 0.06 + 0.04 * synthetic._smooth_image(gen, 2, rows, cols)[:, :1]
+        R = 0.06 + 0.04 * synthetic._smooth_image(gen, 2, rows, cols)[:, :1]
+        R[:, :, : rows // 3] += 0.05                      # a nearer band: real occlusions
+        dummy = torch.zeros(2, 1, rows, cols, dtype=torch.bool)
+        lo = ref_losses.get_occlusion_mask(inputs["K_pyr"][lvl], inputs["T_right_in_left"], L, dummy, R, dummy)
+        ro = ref_losses.get_occlusion_mask(inputs["K_pyr"][lvl], inputs["T_left_in_right"], R, dummy, L, dummy)
+        Ls.append(L), Rs.append(R), left_occ.append(lo), right_occ.append(ro)
+        d[f"K_{lvl}"] = npy(inputs["K_pyr"][lvl])
+        d[f"left_idepth_{lvl}"], d[f"right_idepth_{lvl}"] = npy(L), npy(R)
+        d[f"left_occlusion_{lvl}"], d[f"right_occlusion_{lvl}"] = npy(lo), npy(ro)
+        if lvl in (2, 4):
+            uv, idp, inv = ref_ip.IDepthmapProjector()(inputs["K_pyr"][lvl], inputs["T_right_in_left"], L)
+            d[f"proj_uv_{lvl}"], d[f"proj_idepth_{lvl}"], d[f"proj_invalid_{lvl}"] = npy(uv), npy(idp), npy(inv)
+    loss = ref_losses.left_right_idepthmap_consistency_losses(
+        inputs["T_right_in_left"], inputs["T_left_in_right"], inputs["K_pyr"], Ls, left_occ, Rs, right_occ)
+    d["left_right_loss"] = np.float64(loss.item())
+    per_level = []
+    for lvl in range(5):
+        pick = lambda pyr: [t if i == lvl else None for i, t in enumerate(pyr)]   # noqa: E731
+        per_level.append(ref_losses.left_right_idepthmap_consistency_losses(
+            inputs["T_right_in_left"], inputs["T_left_in_right"], inputs["K_pyr"], pick(Ls), left_occ, pick(Rs),
+            right_occ).item())
+    d["left_right_loss_per_level"] = np.array(per_level, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, name), **d)
+    print(name, "ok", "loss", d["left_right_loss"], [(int(m.sum()), m.numel()) for m in left_occ])
+
+
 def main():
     torch.set_num_threads(8)
     G = "gta_sfm_150epochs"
@@ -350,6 +394,7 @@ def main():
         ("gc2_gta_512x256_d64_s1.npz", lambda n: outputs_only(n, G, 256, 512, 64, 1, seed=21, slim=True)),
         ("gc3_gta_512x256_d64_s5.npz", lambda n: outputs_only(n, G, 256, 512, 64, 5, seed=23, slim=True)),
         ("gc5_gta_1024x512_d128_s4.npz", lambda n: outputs_only(n, G, 512, 1024, 128, 4, seed=25, slim=True)),
+        ("g9_two_view_consistency.npz", lambda n: consistency_pins(n)),
     ]
     want = sys.argv[1:]
     for name, job in jobs:

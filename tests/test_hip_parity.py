@@ -910,6 +910,66 @@ def test_two_view_bidirectional_golden():
         assert mean_rel < 2e-4 and max_rel < 2e-3, (key, lvl, mean_rel, max_rel)
 
 
+def test_torchscript_archive_matches_eager(tmp_path):
+    """The literal test.py flow (test.py:308-314, multi_view_stereonet_utils.py:647-654): torch.jit.load of a
+    stereo_network.pt, .to(device), .eval(), seven positional arguments -- same tensors as the eager module."""
+    from multi_view_stereonet_amd import torchscript as ts
+    sd = load_weights("gta_sfm_150epochs")
+    ts.export_archive(sd, str(tmp_path / "stereo_network.pt"))
+    stereo_network = torch.jit.load(str(tmp_path / "stereo_network.pt"))
+    stereo_network = stereo_network.to(torch.device(DEV))
+    stereo_network.eval()
+    fix = load_golden("g1_gta_128x64_d16_s1.npz")
+    batch, D = batch_from_meta(fix["meta"])
+    inputs = snu.multi_view_unpack_batch(batch, torch.device(DEV), stereo_network.num_levels)
+    params = {"num_idepth_samples": D, "cost_volume_filter": True, "refiners": [True] * 5}
+    out = snu.multi_view_forward(stereo_network, inputs, params)
+    eager = snu.multi_view_forward(net_for("gta_sfm_150epochs"), inputs, params)
+    for key in ("left_idepthmap_pyr", "left_idepthmap_raw_pyr", "left_idepthmap_mask_pyr"):
+        for a, b in zip(out[key], eager[key]):
+            assert a.dtype == b.dtype and torch.equal(a, b)
+    mean_rel, max_rel = rel_err(out["left_idepthmap_pyr"][0].cpu(), fix["idepth_0"])
+    assert mean_rel < 2e-4 and max_rel < 2e-3
+    # a second call reuses the cached engine (same parameter storage), a flag variant goes through the same operator
+    again = snu.multi_view_forward(stereo_network, inputs, dict(params, refiners=[False, True, True, True, True]))
+    assert torch.equal(again["left_idepthmap_pyr"][1], out["left_idepthmap_pyr"][1])
+
+
+def test_two_view_consistency_ops_golden():
+    """SURVEY 8f rank 4, loss side: get_occlusion_mask and left_right_idepthmap_consistency_losses
+    (multi_view_stereonet/losses.py:42-160) on the HIP path against the reference's own outputs (g9)."""
+    from test_oracle_golden import _consistency_inputs
+    from multi_view_stereonet_amd import losses
+    fix = load_golden("g9_two_view_consistency.npz")
+    T, Ti, Ks, L, R = _consistency_inputs(fix, DEV)
+    lo, ro = [], []
+    for lvl in range(5):
+        lo.append(losses.get_occlusion_mask(Ks[lvl], T, L[lvl], None, R[lvl], None))
+        ro.append(losses.get_occlusion_mask(Ks[lvl], Ti, R[lvl], None, L[lvl], None))
+        bad = int((lo[-1].cpu() != t(fix[f"left_occlusion_{lvl}"])).sum()) + \
+            int((ro[-1].cpu() != t(fix[f"right_occlusion_{lvl}"])).sum())
+        print(f"level {lvl}: occlusion-mask mismatches {bad} of {2 * lo[-1].numel()}")
+        assert lo[-1].dtype == torch.bool and bad <= max(2, lo[-1].numel() // 2000)   # pixels on the threshold
+    for lvl in (2, 4):
+        uv, idp, inv = losses.idepthmap_projector(Ks[lvl], T, L[lvl])
+        close(uv, fix[f"proj_uv_{lvl}"], rtol=1e-5, atol=2e-6)
+        close(idp, fix[f"proj_idepth_{lvl}"], rtol=1e-5, atol=1e-7)
+        assert int((inv.cpu() != t(fix[f"proj_invalid_{lvl}"])).sum()) <= 1
+    # the loss with the REFERENCE's masks (isolates the loss kernels), then end to end with the HIP masks
+    ref_lo = [t(fix[f"left_occlusion_{lvl}"]).to(DEV) for lvl in range(5)]
+    ref_ro = [t(fix[f"right_occlusion_{lvl}"]).to(DEV) for lvl in range(5)]
+    loss = losses.left_right_idepthmap_consistency_losses(T, Ti, Ks, L, ref_lo, R, ref_ro)
+    assert abs(float(loss) - float(fix["left_right_loss"])) < 2e-6 * 10
+    for lvl in range(5):
+        pick = lambda pyr: [x if i == lvl else None for i, x in enumerate(pyr)]   # noqa: E731
+        one = losses.left_right_idepthmap_consistency_losses(T, Ti, Ks, pick(L), ref_lo, pick(R), ref_ro)
+        assert abs(float(one) - float(fix["left_right_loss_per_level"][lvl])) < 1e-6
+    loss2 = losses.left_right_idepthmap_consistency_losses(T, Ti, Ks, L, lo, R, ro)
+    assert abs(float(loss2) - float(fix["left_right_loss"])) < 1e-3 * float(fix["left_right_loss"])
+    with pytest.raises(RuntimeError):
+        losses.get_occlusion_mask(Ks[0].cpu(), T.cpu(), L[0].cpu(), None, R[0].cpu(), None)     # no CPU path
+
+
 def test_graph_replay_matches_eager():
     """hipGraph capture of the whole forward: replay on new inputs equals the eager launch sequence."""
     from multi_view_stereonet_amd.graphed import GraphedForward

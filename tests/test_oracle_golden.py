@@ -204,3 +204,29 @@ def test_two_view_twins_against_reference():
         mean_rel, max_rel = rel_err(out[f"{key}_idepthmap_pyr"][lvl], fix[f"{key}_idepth_{lvl}"])
         assert mean_rel < 1e-4 and max_rel < 1e-3, (key, lvl, mean_rel, max_rel)
     assert "right_idepthmap_pyr" not in snu.forward(net, inputs, {"num_idepth_samples": 12})
+
+
+def _consistency_inputs(fix, device="cpu"):
+    T, Ti = t(fix["T_right_in_left"]).to(device), t(fix["T_left_in_right"]).to(device)
+    Ks = [t(fix[f"K_{lvl}"]).to(device) for lvl in range(5)]
+    L = [t(fix[f"left_idepth_{lvl}"]).to(device) for lvl in range(5)]
+    R = [t(fix[f"right_idepth_{lvl}"]).to(device) for lvl in range(5)]
+    return T, Ti, Ks, L, R
+
+
+def test_two_view_consistency_ops_against_reference():
+    """Occlusion masks and the left/right consistency loss (losses.py:42-160) on the reference's own outputs."""
+    fix = load_golden("g9_two_view_consistency.npz")
+    T, Ti, Ks, L, R = _consistency_inputs(fix)
+    lo, ro = [], []
+    for lvl in range(5):
+        lo.append(oracle.get_occlusion_mask(Ks[lvl], T, L[lvl], R[lvl]))
+        ro.append(oracle.get_occlusion_mask(Ks[lvl], Ti, R[lvl], L[lvl]))
+        assert torch.equal(lo[-1], t(fix[f"left_occlusion_{lvl}"])) and torch.equal(ro[-1], t(fix[f"right_occlusion_{lvl}"]))
+        assert 0 < int(lo[-1].sum()) < lo[-1].numel()
+    for lvl in (2, 4):
+        uv, idp, inv = oracle.idepthmap_projector(Ks[lvl], T, L[lvl])
+        assert torch.allclose(uv, t(fix[f"proj_uv_{lvl}"]), atol=1e-6) and torch.equal(inv, t(fix[f"proj_invalid_{lvl}"]))
+        assert torch.allclose(idp, t(fix[f"proj_idepth_{lvl}"]), rtol=1e-6)
+    loss = oracle.left_right_consistency_loss(T, Ti, Ks, L, lo, R, ro)
+    assert abs(float(loss) - float(fix["left_right_loss"])) < 1e-7
