@@ -176,6 +176,28 @@ def forward(stereo_network, inputs: Dict[str, object], params: Dict[str, object]
     return outputs
 
 
+def occlusion_masks(inputs: Dict[str, object], outputs: Dict[str, object]) -> Dict[str, list]:
+    """The occlusion-mask pyramids the reference derives from a bidirectional estimate
+    (multi_view_stereonet_utils.py:711-730): per level, where a left pixel is hidden in the right view and vice
+    versa.  `outputs` must come from forward(..., estimate_right_idepthmap=True).  Levels without an estimate stay
+    None.  Both pyramids feed losses.left_right_idepthmap_consistency_losses (:749-753)."""
+    from . import losses
+    n = len(outputs["left_idepthmap_pyr"])
+    left_occ, right_occ = [None] * n, [None] * n
+    for lvl in range(n):
+        if outputs["left_idepthmap_pyr"][lvl] is None:
+            continue
+        left_occ[lvl] = losses.get_occlusion_mask(
+            inputs["K_pyr"][lvl], inputs["T_right_in_left"], outputs["left_idepthmap_pyr"][lvl],
+            outputs["left_idepthmap_mask_pyr"][lvl], outputs["right_idepthmap_pyr"][lvl],
+            outputs["right_idepthmap_mask_pyr"][lvl])
+        right_occ[lvl] = losses.get_occlusion_mask(
+            inputs["K_pyr"][lvl], inputs["T_left_in_right"], outputs["right_idepthmap_pyr"][lvl],
+            outputs["right_idepthmap_mask_pyr"][lvl], outputs["left_idepthmap_pyr"][lvl],
+            outputs["left_idepthmap_mask_pyr"][lvl])
+    return {"left_occlusion_mask_pyr": left_occ, "right_occlusion_mask_pyr": right_occ}
+
+
 def _tick(device_is_gpu: bool):
     if device_is_gpu:
         torch.cuda.synchronize()

@@ -908,6 +908,18 @@ def test_two_view_bidirectional_golden():
     for key, lvl in (("left", 0), ("right", 0), ("left", 4), ("right", 4)):
         mean_rel, max_rel = rel_err(out[f"{key}_idepthmap_pyr"][lvl].cpu(), fix[f"{key}_idepth_{lvl}"])
         assert mean_rel < 2e-4 and max_rel < 2e-3, (key, lvl, mean_rel, max_rel)
+    # the occlusion pyramids and the consistency loss the reference derives from such a pair (:711-753), HIP vs oracle
+    from multi_view_stereonet_amd import losses
+    occ = snu.occlusion_masks(inputs, out)
+    cpu = lambda x: x.cpu()   # noqa: E731
+    for lvl in range(5):
+        ref = oracle.get_occlusion_mask(cpu(inputs["K_pyr"][lvl]), cpu(inputs["T_right_in_left"]),
+                                        cpu(out["left_idepthmap_pyr"][lvl]), cpu(out["right_idepthmap_pyr"][lvl]))
+        assert int((occ["left_occlusion_mask_pyr"][lvl].cpu() != ref).sum()) <= max(2, ref.numel() // 2000)
+    loss = losses.left_right_idepthmap_consistency_losses(
+        inputs["T_right_in_left"], inputs["T_left_in_right"], inputs["K_pyr"], out["left_idepthmap_pyr"],
+        occ["left_occlusion_mask_pyr"], out["right_idepthmap_pyr"], occ["right_occlusion_mask_pyr"])
+    assert loss.is_cuda and loss.dim() == 0    # (NaN when every pixel is occluded, as in the reference)
 
 
 def test_torchscript_archive_matches_eager(tmp_path):
