@@ -69,10 +69,16 @@ bool chain_wino_supported(int rows, int cols) {
 // input transform costs the same (row i of B^T d B needs two rows of d), the window reads 3 rows per half.
 // Software pipeline per k-step: transform the window that is already in registers, issue the LDS reads of the NEXT
 // k-step (3 window rows + 4 quads of U), then the 16 multiplies -- no LDS round trip sits in front of an MFMA.
-// (Measured alternatives, tools/chain_phases.py: a raised priority for one wave of each SIMD pair changes nothing;
-// the next k-step's transform interleaved instruction by instruction with the multiplies is 7 % slower per layer.
-// The SIMD issues the ~23 VALU / LDS instructions of a k-step at ~8 cycles each NEXT TO, not under, its 16 MFMAs:
-// 512 + 185 cycles per wave and k-step, 73 % of the matrix pipe -- the price of transforming in registers.)
+// Measured (tools/chain_phases.py, s_memtime stamps per wave), 9 k-steps x 2 halves of the first layer:
+//   * one wave per SIMD alone: 730 cycles per k-step = 16 MFMAs x 32 + 23 VALU / LDS instructions x ~9.5;
+//   * two waves per SIMD (this kernel): 1405 per pair of k-steps -- the two waves leave their barrier together, run
+//     their transform sections together and then alternate on the matrix pipe, so the sections ADD instead of
+//     hiding under each other (73 % of the pipe); a raised priority for one wave of each pair starves the other
+//     instead (same total);
+//   * the next k-step's transform interleaved instruction by instruction with the multiplies (sched_group_barrier,
+//     MFMA / VALU alternating): 834 cycles per k-step for a wave alone, 7 % slower for the pair -- a VALU
+//     instruction between two fp32 MFMAs costs more than its slot.
+// The in-register transform costs one VALU per MFMA at 32 output channels; that ratio, not the schedule, is the limit.
 template <int NC>
 __device__ __forceinline__ void wino_layer(const float *__restrict__ act, const float *__restrict__ U, int CS, int RS,
                                            int wb, int lane, float (&y)[2][4][4]) {
