@@ -216,6 +216,9 @@ def main():
                     help="arithmetic of the 32->32 3x3 layers: exact fp32 MFMA, or the 3 x bf16 split tier")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tiers", action="store_true", help="skip the bf16x3 / bf16 tier legs and the batch-latency leg")
+    ap.add_argument("--sustain", type=float, default=0.0, metavar="SECONDS",
+                    help="after the timed region: keep stepping for this long and report the rate per 2-second window "
+                         "(clock settling under sustained MFMA load); writes nothing, adds a 'sustained' key")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU ranks over gloo with a stand-in step: checks the launch/timing/gather plumbing only")
     args = ap.parse_args()
@@ -293,7 +296,7 @@ def main():
             tfl = direct_tfl * (4.0 / 9.0 if wino else 1.0)
             traffic = None
             try:   # HBM bytes per launch from the committed PMC passes (profiles/), scaled to this batch
-                with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
                     t = json.load(f).get(name)
                 if t:
                     traffic = (t["fetch_bytes_per_chain"] + t["write_bytes_per_chain"]) * B * S
@@ -310,15 +313,51 @@ def main():
             ch = agg.get("mvsn_incremental_cost_volume")
             if ch:
                 sec = ch["ms"] * 1e-3
+                r4, c4 = (ROWS + 15) // 16, (COLS + 15) // 16
+                wino_chain = net.engine().lib.mvsn_incremental_cost_volume_form(r4, c4) == 2 and \
+                    net.options.chain_form != "direct"
+                direct_tfl = ch["flops"] / sec / 1e12
+                exec_tfl = direct_tfl * (4.0 / 9.0 if wino_chain else 1.0)
                 line["chain_kernel"] = {"kernel": "mvsn_incremental_cost_volume (warp + refine + cost volume, fused)",
+                                        "form": "Winograd F(2x2,3x3) for the three 3x3 convolutions of a step: 16 "
+                                                "multiplies per 2x2 outputs instead of 36" if wino_chain else "direct",
                                         "avg_launch_ms": ch["ms"] / ch["launches"],
                                         "algorithmic_GBps": ch["bytes"] / sec / 1e9,
                                         "frac_of_hbm_peak": ch["bytes"] / sec / 1e9 / PEAK_HBM_GBS,
-                                        "algorithmic_TFLOPs": ch["flops"] / sec / 1e12,
-                                        "frac_of_fp32_mfma_peak": ch["flops"] / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                        "direct_form_TFLOPs": direct_tfl,
+                                        "direct_form_frac_of_fp32_mfma_peak": direct_tfl / PEAK_FP32_MFMA_TFLOPS,
+                                        "executed_TFLOPs": exec_tfl,
+                                        "executed_frac_of_fp32_mfma_peak": exec_tfl / PEAK_FP32_MFMA_TFLOPS,
                                         "share_of_step": ch["ms"] / total_ms}
+                try:
+                    with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+                        t = json.load(f).get("mvsn_incremental_cost_volume")
+                    if t:
+                        line["chain_kernel"]["hbm_traffic_bytes_per_chain"] = {
+                            "fetched": t["fetch_bytes_per_chain"], "written": t["write_bytes_per_chain"],
+                            "algorithmic": t["algorithmic_bytes_per_chain"],
+                            "ratio": (t["fetch_bytes_per_chain"] + t["write_bytes_per_chain"]) /
+                            t["algorithmic_bytes_per_chain"]}
+                except OSError:
+                    pass
             line["kernel_ms_per_step"] = {k: round(v["ms"], 3) for k, v in
                                           sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]}
+            if args.sustain > 0:
+                windows, t_end = [], time.perf_counter() + args.sustain
+                while time.perf_counter() < t_end:
+                    n_steps, t1 = 0, time.perf_counter()
+                    while time.perf_counter() - t1 < 2.0:
+                        run_forward(net, inp)
+                        n_steps += 1
+                        if n_steps % 8 == 0:
+                            torch.cuda.synchronize()
+                    torch.cuda.synchronize()
+                    windows.append(B * n_steps / (time.perf_counter() - t1))
+                line["sustained"] = {"seconds": args.sustain, "window_s": 2.0,
+                                     "depthmaps_per_s_per_window": [round(w, 1) for w in windows],
+                                     "first": round(windows[0], 1), "last": round(windows[-1], 1),
+                                     "min": round(min(windows), 1), "droop_last_vs_first": 1.0 - windows[-1] / windows[0],
+                                     "timed_region_value": line["value"]}
             if not args.no_tiers:
                 line["batch_latency"] = batch_latency(net)
             if args.precision == "fp32" and not args.no_tiers:

@@ -4,12 +4,12 @@
 set -u
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-TAG=${TAG:-r01}
+TAG=${TAG:-r02}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-BENCH="python bench.py --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline"
+BENCH="python bench.py --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline --no-tiers"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- $BENCH > $OUT/bench_under_trace.json 2> $OUT/trace.log
-PMC="python bench.py --steps 1 --warmup 1 --no-cpu-baseline"
+PMC="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-tiers"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -o pmc_fetch -- $PMC > /dev/null 2> $OUT/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT -o pmc_write -- $PMC > /dev/null 2> $OUT/pmc_write.log
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT -o pmc_sq -- $PMC > /dev/null 2> $OUT/pmc_sq.log
