@@ -203,6 +203,12 @@ int mvsn_groupnorm_lrelu_add2(const float *x, const float *stats, const float *g
 int mvsn_conv_to1_supported(int rows, int cols);
 int mvsn_conv_to1(const float *in, const float *weight, const float *bias, const float *prior, const float *fx,
                   int n, int depth, int rows, int cols, int kd, float *out, mvsn_stream_t stream);
+/* The 3-D layer on a RAW convolution output: LeakyReLU(GroupNorm(in_raw)) (CostVolumeFilter's bn3 + relu,
+ * multi_view_stereonet.py:349-350) is applied while the planes are loaded, so the regulariser's last normalise /
+ * activate pass never goes through HBM.   in_raw (N,32,D,H,W)  in_stats (N,4,2)  in_gamma, in_beta (32)  out (N,D,H,W) */
+int mvsn_conv_to1_volume_norm(const float *in_raw, const float *in_stats, const float *in_gamma, const float *in_beta,
+                              const float *weight, const float *bias, int n, int depth, int rows, int cols, float *out,
+                              mvsn_stream_t stream);
 /* The same 2-D layer with the tower's LAST residual block folded into its load: the input
  * in_residual + LeakyReLU(GroupNorm(in_raw)) (SimpleBasicBlock, multi_view_stereonet.py:21-38) is formed in
  * registers from the raw output of the block's convolution and the block's input, never written.

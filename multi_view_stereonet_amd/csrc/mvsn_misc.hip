@@ -341,8 +341,14 @@ constexpr int T3_SLOTS = T3_HY * T3_XS;               // 720
 constexpr int T3_GROUPS = (T3_SLOTS + 63) / 64;       // 12 groups of 64 slots, 3 per wave
 constexpr int T3_LDS_FLOATS = 27 * T3_SLOTS;          // 77,760 bytes: two workgroups per CU
 
+// XF: the input is a raw convolution output whose LeakyReLU(GroupNorm(.)) is applied on load (two VALU per
+// element behind an HBM-bound stream) -- the regulariser's last normalise/activate pass never touches HBM.
+template <bool XF>
 __global__ __launch_bounds__(256, 2) void conv_to1_3d_mfma_kernel(const float *__restrict__ in, const float *__restrict__ w,
-                                                                  const float *__restrict__ bias, int D, int H, int W,
+                                                                  const float *__restrict__ bias,
+                                                                  const float *__restrict__ in_stats,
+                                                                  const float *__restrict__ in_gamma,
+                                                                  const float *__restrict__ in_beta, int D, int H, int W,
                                                                   int ntx, int zslab, float *__restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float P[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -364,6 +370,17 @@ __global__ __launch_bounds__(256, 2) void conv_to1_3d_mfma_kernel(const float *_
       const int tap = t * 16 + (lane & 15), c = ks * 4 + (lane >> 4);
       a[t][ks] = tap < 27 ? w[c * 27 + tap] : 0.0f;
     }
+
+  float xsc[8], xsh[8];   // XF: per k-step scale / shift of this lane's channel 4 ks + (lane>>4) (group ks >> 1)
+  if constexpr (XF) {
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int c = ks * 4 + (lane >> 4);
+      const float mean = in_stats[((size_t)n * 4 + (ks >> 1)) * 2], rstd = in_stats[((size_t)n * 4 + (ks >> 1)) * 2 + 1];
+      xsc[ks] = rstd * in_gamma[c];
+      xsh[ks] = in_beta[c] - mean * xsc[ks];
+    }
+  }
 
   // this lane's slots: group g = wave + 4 u, slots 64 g + 4 (lane&15) .. + 3
   constexpr int GPW = T3_GROUPS / 4;   // 3
@@ -391,8 +408,15 @@ __global__ __launch_bounds__(256, 2) void conv_to1_3d_mfma_kernel(const float *_
       auto load_group = [&](int u, floatx4 (&dst)[8]) {
         const float *src = inn + (size_t)z * plane + (goff[u] >= 0 ? goff[u] : 0);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
+        for (int ks = 0; ks < 8; ++ks) {
           dst[ks] = goff[u] >= 0 ? *reinterpret_cast<const floatx4 *>(src + (size_t)ks * 4 * chan) : floatx4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (XF) {   // padding stays zero: it pads the ACTIVATED tensor
+            if (goff[u] >= 0) {
+#pragma unroll
+              for (int p = 0; p < 4; ++p) dst[ks][p] = lrelu02(dst[ks][p] * xsc[ks] + xsh[ks]);
+            }
+          }
+        }
       };
       load_group(0, bfr[0]);
 #pragma unroll
@@ -559,6 +583,33 @@ __global__ __launch_bounds__(256) void conv_to1_2d_mfma_kernel(const float *__re
 
 }  // namespace mvsn
 
+static int conv_to1_volume(const float *in, const float *weight, const float *bias, const float *in_stats,
+                           const float *in_gamma, const float *in_beta, int n, int depth, int rows, int cols,
+                           float *out, mvsn_stream_t stream) {
+  using namespace mvsn;
+  // tap GEMM on the matrix cores; slabs of planes so that even one chain fills the chip
+  const int nty = (rows + T3_TY - 1) / T3_TY, ntx = (cols + T3_TX - 1) / T3_TX;
+  int nslab = 1;
+  while (nslab < 8 && (long)n * nty * ntx * nslab < 1024 && depth / (nslab * 2) >= 8) nslab *= 2;
+  const int zslab = (depth + nslab - 1) / nslab;
+  const int nz = (depth + zslab - 1) / zslab;
+  MVSN_REQUIRE(n <= 65535 && nz <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_to1: grid");
+  const size_t lds = (size_t)T3_LDS_FLOATS * sizeof(float);
+  if (in_stats) {
+    static LdsOptIn opt;
+    if (int rc = ensure_lds(opt, (const void *)conv_to1_3d_mfma_kernel<true>, lds, "mvsn_conv_to1")) return rc;
+    hipLaunchKernelGGL(conv_to1_3d_mfma_kernel<true>, dim3(nty * ntx, nz, n), dim3(256), lds, (hipStream_t)stream, in,
+                       weight, bias, in_stats, in_gamma, in_beta, depth, rows, cols, ntx, zslab, out);
+  } else {
+    static LdsOptIn opt;
+    if (int rc = ensure_lds(opt, (const void *)conv_to1_3d_mfma_kernel<false>, lds, "mvsn_conv_to1")) return rc;
+    hipLaunchKernelGGL(conv_to1_3d_mfma_kernel<false>, dim3(nty * ntx, nz, n), dim3(256), lds, (hipStream_t)stream, in,
+                       weight, bias, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, depth,
+                       rows, cols, ntx, zslab, out);
+  }
+  return mvsn::check_launch("mvsn_conv_to1(volume)");
+}
+
 extern "C" int mvsn_conv_to1_supported(int rows, int cols) { return (cols % 4 == 0 && rows > 0) ? 1 : 0; }
 
 extern "C" int mvsn_conv_to1(const float *in, const float *weight, const float *bias, const float *prior,
@@ -570,19 +621,7 @@ extern "C" int mvsn_conv_to1(const float *in, const float *weight, const float *
   MVSN_REQUIRE(cols % 4 == 0, MVSN_E_BADARG, "mvsn_conv_to1: cols must be a multiple of 4 (use mvsn_conv_forward)");
   MVSN_REQUIRE(!prior || (fx && depth == 1), MVSN_E_BADARG, "mvsn_conv_to1: refiner epilogue needs fx and 2-D input");
   if (kd == 3) {
-    using namespace mvsn;
-    // tap GEMM on the matrix cores; slabs of planes so that even one chain fills the chip
-    const int nty = (rows + T3_TY - 1) / T3_TY, ntx = (cols + T3_TX - 1) / T3_TX;
-    int nslab = 1;
-    while (nslab < 8 && (long)n * nty * ntx * nslab < 1024 && depth / (nslab * 2) >= 8) nslab *= 2;
-    const int zslab = (depth + nslab - 1) / nslab;
-    const int nz = (depth + zslab - 1) / zslab;
-    MVSN_REQUIRE(n <= 65535 && nz <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_to1: grid");
-    const size_t lds = (size_t)T3_LDS_FLOATS * sizeof(float);
-    static LdsOptIn opt;
-    if (int rc = ensure_lds(opt, (const void *)conv_to1_3d_mfma_kernel, lds, "mvsn_conv_to1")) return rc;
-    hipLaunchKernelGGL(conv_to1_3d_mfma_kernel, dim3(nty * ntx, nz, n), dim3(256), lds, (hipStream_t)stream, in, weight,
-                       bias, depth, rows, cols, ntx, zslab, out);
+    return conv_to1_volume(in, weight, bias, nullptr, nullptr, nullptr, n, depth, rows, cols, out, stream);
   } else {
     MVSN_REQUIRE(depth == 1, MVSN_E_BADARG, "mvsn_conv_to1: kd = 1 needs depth = 1");
     const int nty = (rows + mvsn::T2_TY - 1) / mvsn::T2_TY, ntx = (cols + mvsn::T2_TX - 1) / mvsn::T2_TX;
@@ -592,6 +631,16 @@ extern "C" int mvsn_conv_to1(const float *in, const float *weight, const float *
                        (const float *)nullptr, prior, fx, rows, cols, ntx, out);
   }
   return mvsn::check_launch("mvsn_conv_to1");
+}
+
+extern "C" int mvsn_conv_to1_volume_norm(const float *in_raw, const float *in_stats, const float *in_gamma,
+                                         const float *in_beta, const float *weight, const float *bias, int n, int depth,
+                                         int rows, int cols, float *out, mvsn_stream_t stream) {
+  MVSN_REQUIRE(in_raw && in_stats && in_gamma && in_beta && weight && out, MVSN_E_BADARG,
+               "mvsn_conv_to1_volume_norm: null pointer");
+  MVSN_REQUIRE(n > 0 && depth > 0 && rows > 0 && cols > 0, MVSN_E_BADARG, "mvsn_conv_to1_volume_norm: bad sizes");
+  MVSN_REQUIRE(cols % 4 == 0, MVSN_E_BADARG, "mvsn_conv_to1_volume_norm: cols must be a multiple of 4");
+  return conv_to1_volume(in_raw, weight, bias, in_stats, in_gamma, in_beta, n, depth, rows, cols, out, stream);
 }
 
 extern "C" int mvsn_conv_to1_block(const float *in_raw, const float *in_stats, const float *in_gamma,

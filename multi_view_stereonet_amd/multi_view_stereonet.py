@@ -413,8 +413,15 @@ class PlaneSweepEngine:
                 x, st = self.conv(self.vf_convs[i], x, in_stats=st, in_norm=self.vf_norms[i - 1], want_stats=True)
         last = self.vf_convs[4]
         if self.lib.mvsn_conv_to1_supported(x.shape[-2], x.shape[-1]):
-            x = self.gn_lrelu(x, st, self.vf_norms[3], out=x)     # materialise once, then the HBM-bound 32->1 pass
-            return self.conv_to1(last, x)[:, 0]
+            # the HBM-bound 32 -> 1 pass applies LReLU(GN(.)) of the fourth layer while it loads the raw volume
+            n, _, depth, rows, cols = x.shape
+            out = torch.empty((n, depth, rows, cols), dtype=torch.float32, device=x.device)
+            nrm = self.vf_norms[3]
+            self._call("mvsn_conv_to1_volume_norm", self.lib.mvsn_conv_to1_volume_norm, _native.ptr(x), _native.ptr(st),
+                       _native.ptr(nrm.gamma), _native.ptr(nrm.beta), _native.ptr(last.weight), _native.ptr(last.bias),
+                       n, depth, rows, cols, _native.ptr(out), _native.stream(),
+                       flops=2.0 * 32 * 27 * out.numel(), nbytes=4.0 * (x.numel() + out.numel()))
+            return out
         out, _ = self.conv(last, x, in_stats=st, in_norm=self.vf_norms[3])
         return out[:, 0]
 

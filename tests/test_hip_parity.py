@@ -552,6 +552,23 @@ def test_groupnorm_apply_beyond_one_grid():
     close(y2, want2, rtol=1e-5, atol=1e-5)
 
 
+def test_conv_to1_volume_with_groupnorm_on_load():
+    """mvsn_conv_to1_volume_norm == (LReLU(GN(raw)) materialised, then the 32 -> 1 volume layer)."""
+    eng = net_for("gta_sfm_150epochs").engine()
+    lib = eng.lib
+    g = torch.Generator().manual_seed(8)
+    n, D, rows, cols = 3, 9, 12, 20
+    raw = torch.randn(n, 32, D, rows, cols, generator=g).to(DEV)
+    stats = torch.stack([torch.randn(n, 4, generator=g) * 0.2, torch.rand(n, 4, generator=g) + 0.5], -1).to(DEV)
+    last, nrm = eng.vf_convs[4], eng.vf_norms[3]
+    want = eng.conv_to1(last, eng.gn_lrelu(raw, stats, nrm))
+    got = torch.empty(n, D, rows, cols, device=DEV)
+    _native.check(lib.mvsn_conv_to1_volume_norm(_native.ptr(raw), _native.ptr(stats), _native.ptr(nrm.gamma),
+                                                _native.ptr(nrm.beta), _native.ptr(last.weight), _native.ptr(last.bias),
+                                                n, D, rows, cols, _native.ptr(got), _native.stream()), "volume_norm")
+    close(got, want[:, 0].cpu(), rtol=1e-5, atol=1e-5)
+
+
 def test_cost_volume_filter_and_soft_argmin_golden_unit():
     fix = load_golden("g4_units.npz")
     eng = net_for("gta_sfm_150epochs").engine()
