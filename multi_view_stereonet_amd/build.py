@@ -17,14 +17,36 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+MANIFEST = LIB + ".sources"
+HEADERS = ["mvsn_common.h", "mvsn_conv_bf16x3.h", "mvsn_chain.h", "mvsn_conv_wino.h"]
+
+
+def source_digest() -> str:
+    """sha256 over every source the library is built from (+ the extra compiler flags): written next to the binary,
+    so "is this .so the build of THESE sources" is a content check, not a file-time check (a snapshot copied to
+    another box keeps its binary but not its mtimes)."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, x) for x in HEADERS] + \
+        [os.path.join(HERE, "..", "include", "mvsn_hip.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(os.environ.get("MVSN_HIPCC_FLAGS", "").encode())
+    return h.hexdigest()
+
+
+def built_from_current_sources() -> bool:
+    try:
+        with open(MANIFEST) as f:
+            return os.path.exists(LIB) and f.read().strip() == source_digest()
+    except OSError:
+        return False
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "mvsn_common.h"),
-                                                     os.path.join(CSRC, "mvsn_conv_bf16x3.h"), os.path.join(CSRC, "mvsn_chain.h"), os.path.join(CSRC, "mvsn_conv_wino.h"),
-                                                     os.path.join(HERE, "..", "include", "mvsn_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return not built_from_current_sources()
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -49,6 +71,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
             sys.stderr.write(out.decode())
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     subprocess.check_call(cmd)
+    with open(MANIFEST, "w") as f:
+        f.write(source_digest() + "\n")
     return LIB
 
 

@@ -151,3 +151,11 @@ def test_module_copies_and_pickles_with_a_live_engine():
     buf = io.BytesIO()
     torch.save(net, buf)
     assert net._engine is not None        # the original keeps its engine
+
+
+def test_library_is_the_build_of_the_sources_beside_it():
+    """__graft_entry__.build() rebuilds on a content mismatch (sha256 of the .hip / .h files in libmvsn_hip.so.sources),
+    so a binary that travelled with a snapshot is known to correspond to the snapshot's sources."""
+    from multi_view_stereonet_amd import build
+    assert build.built_from_current_sources(), "libmvsn_hip.so does not match csrc/: run __graft_entry__.build()"
+    assert len(build.source_digest()) == 64
