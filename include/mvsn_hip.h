@@ -258,6 +258,24 @@ int mvsn_area_downsample(const float *in, int n, int channels, int rows_in, int 
                          mvsn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Input preparation in two launches (multi_view_unpack_batch, multi_view_stereonet_utils.py:541-641):
+ * mvsn_image_pyramid: every level of the area pyramid in one pass over the frames, for sizes divisible by
+ * 2^(levels-1) (mvsn_image_pyramid_supported; otherwise mvsn_area_downsample level by level).
+ *   in (N,C,rows,cols)  out_levels[l-1] -> (N,C,rows>>l,cols>>l), l = 1..levels-1 (HOST array of device pointers)
+ * mvsn_prepare_cameras: K pyramid (:575-581: fx*=sx, fy*=sy, cx = sx(cx+0.5)-0.5, cy likewise, sx = w_l/w_0),
+ * the source poses and their inverses with the translations divided by the baseline to the FIRST source (:597-604),
+ * and that baseline.
+ *   K (B,4,4)  T_right_in_left (S,B,4,4) un-normalised  level_sizes_dev: DEVICE int[2*levels] = rows_0, cols_0, rows_1, ...
+ *   -> K_pyr (levels,B,4,4)  T_normalised, T_inverse_normalised (S,B,4,4)  baseline (B)
+ * ------------------------------------------------------------------------------------------- */
+int mvsn_image_pyramid_supported(int rows, int cols, int levels);
+int mvsn_image_pyramid(const float *in, int n, int channels, int rows, int cols, int levels, float *const *out_levels,
+                       mvsn_stream_t stream);
+int mvsn_prepare_cameras(const float *K, const float *T_right_in_left, int batch, int n_sources, int levels,
+                         const int *level_sizes_dev, float *K_pyr, float *T_normalised, float *T_inverse_normalised,
+                         float *baseline, mvsn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Multi-source fusion (multi_view_stereonet.py:615-627): per chain divide by its baseline, mean
  * over the S sources; mask = mean(mask) > 0.5.
  *   raw, refined (S*B,P)  baseline (S*B)  mask (S*B,D,P) u8

@@ -57,6 +57,9 @@ SIGNATURES = {
     "mvsn_refiner_epilogue": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p]),
     "mvsn_upsample_bilinear": (c_int, [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
     "mvsn_upsample_mask": (c_int, [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
+    "mvsn_image_pyramid_supported": (c_int, [c_int] * 3),
+    "mvsn_image_pyramid": (c_int, [c_void_p] + [c_int] * 5 + [POINTER(c_void_p), c_void_p]),
+    "mvsn_prepare_cameras": (c_int, [c_void_p] * 2 + [c_int] * 3 + [c_void_p] * 5 + [c_void_p]),
     "mvsn_area_downsample": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p, c_void_p]),
     "mvsn_fuse_sources": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p] * 3 + [c_void_p]),
     "mvsn_idepth_reproject_blocks": (c_int, [c_int]),

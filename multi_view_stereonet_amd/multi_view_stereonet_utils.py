@@ -26,6 +26,20 @@ def build_image_pyramid(image: torch.Tensor, num_levels: int) -> List[torch.Tens
     """
     if image.dim() != 4:
         raise AssertionError("image must be (batch, channels, rows, cols)")
+    if image.is_cuda and num_levels >= 2:
+        # device frames whose sizes halve exactly: every level in ONE pass over the frames (mvsn_image_pyramid)
+        import ctypes
+        from . import _native
+        lib = _native.load()
+        n, c, rows, cols = image.shape
+        if lib.mvsn_image_pyramid_supported(rows, cols, num_levels):
+            src = image.contiguous().float()
+            outs = [torch.empty((n, c, rows >> l, cols >> l), dtype=torch.float32, device=image.device)
+                    for l in range(1, num_levels)]
+            ptrs = (ctypes.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+            _native.check(lib.mvsn_image_pyramid(_native.ptr(src), n, c, rows, cols, num_levels, ptrs,
+                                                 _native.stream()), "mvsn_image_pyramid")
+            return [image] + outs
     levels = [image]
     while len(levels) < num_levels:
         prev = levels[-1]
@@ -66,6 +80,22 @@ def build_intrinsics_pyramid(K: torch.Tensor, image_pyr: List[torch.Tensor]) -> 
     return out
 
 
+def _prepare_cameras_on_device(K: torch.Tensor, poses, image_pyr: List[torch.Tensor], device):
+    from . import _native
+    lib = _native.load()
+    K = K.float().contiguous()
+    B, S, L = K.shape[0], len(poses), len(image_pyr)
+    T = torch.stack([p.to(device).squeeze(1).float() for p in poses], 0).contiguous()          # (S,B,4,4)
+    sizes = torch.tensor([v for lvl in image_pyr for v in lvl.shape[-2:]], dtype=torch.int32, device=device)
+    K_pyr = torch.empty((L, B, 4, 4), dtype=torch.float32, device=device)
+    Tn, Ti = torch.empty_like(T), torch.empty_like(T)
+    baseline = torch.empty((B,), dtype=torch.float32, device=device)
+    _native.check(lib.mvsn_prepare_cameras(_native.ptr(K), _native.ptr(T), B, S, L, _native.ptr(sizes), _native.ptr(K_pyr),
+                                           _native.ptr(Tn), _native.ptr(Ti), _native.ptr(baseline), _native.stream()),
+                  "mvsn_prepare_cameras")
+    return [K_pyr[l] for l in range(L)], [Tn[s] for s in range(S)], [Ti[s] for s in range(S)], baseline
+
+
 def multi_view_unpack_batch(batch: Dict[str, object], device, num_levels: int) -> Dict[str, object]:
     """DataLoader batch -> forward() inputs.
 
@@ -80,21 +110,24 @@ def multi_view_unpack_batch(batch: Dict[str, object], device, num_levels: int) -
 
     left_pyr = build_image_pyramid(left, num_levels)
     K = batch["K"].to(device).squeeze(1)
-    K_pyr = build_intrinsics_pyramid(K, left_pyr)
+    right_pyrs = [build_image_pyramid(r, num_levels) for r in rights]
 
-    T_r_in_l, T_l_in_r, right_pyrs = [], [], []
-    for idx, pose in enumerate(batch["T_right_in_left"]):
-        T = pose.to(device).squeeze(1).clone()
-        T_r_in_l.append(T)
-        T_l_in_r.append(torch.linalg.inv(T))
-        right_pyrs.append(build_image_pyramid(rights[idx], num_levels))
-
-    baseline = T_r_in_l[0][:, :3, 3].pow(2).sum(1).sqrt()
+    if K.is_cuda:
+        # cameras in one launch: K pyramid, poses and inverses normalised by the first source's baseline
+        K_pyr, T_r_in_l, T_l_in_r, baseline = _prepare_cameras_on_device(K, batch["T_right_in_left"], left_pyr, device)
+    else:
+        K_pyr = build_intrinsics_pyramid(K, left_pyr)
+        T_r_in_l, T_l_in_r = [], []
+        for pose in batch["T_right_in_left"]:
+            T = pose.to(device).squeeze(1).clone()
+            T_r_in_l.append(T)
+            T_l_in_r.append(torch.linalg.inv(T))
+        baseline = T_r_in_l[0][:, :3, 3].pow(2).sum(1).sqrt()
+        for T, Tinv in zip(T_r_in_l, T_l_in_r):
+            T[:, :3, 3] /= baseline[:, None]
+            Tinv[:, :3, 3] /= baseline[:, None]
     if not bool((baseline > 0).all()):
         raise AssertionError("baseline to the first source view must be positive")
-    for T, Tinv in zip(T_r_in_l, T_l_in_r):
-        T[:, :3, 3] /= baseline[:, None]
-        Tinv[:, :3, 3] /= baseline[:, None]
 
     inputs = {"left_filename": batch.get("left_filename"),
               "right_filename": batch.get("right_filename"),

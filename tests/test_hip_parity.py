@@ -824,6 +824,22 @@ def test_unpack_batch_on_device_matches_host():
     for a, b in zip(dev["K_pyr"], host["K_pyr"]):
         close(a, b, rtol=1e-6, atol=1e-6)
     close(dev["T_right_in_left"][1], host["T_right_in_left"][1], rtol=1e-6, atol=1e-7)
+    close(dev["T_left_in_right"][1], host["T_left_in_right"][1], rtol=1e-5, atol=1e-6)
+    close(dev["baseline"], host["baseline"], rtol=1e-6, atol=0)
+    # sizes that halve exactly: all levels in ONE launch (mvsn_image_pyramid) -- bit-identical to the host pyramid
+    # (exact 2x2 means), and the K pyramid / normalised poses of mvsn_prepare_cameras bit-identical too
+    batch = synthetic.make_batch(64, 160, 3, batch=3, seed=9, pose_jitter=0.3)
+    host = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
+    dev = snu.multi_view_unpack_batch(batch, torch.device(DEV), 5)
+    assert _native.load().mvsn_image_pyramid_supported(64, 160, 5) == 1
+    for a, b in zip(dev["left_image_pyr"] + dev["right_image_pyr"][2], host["left_image_pyr"] + host["right_image_pyr"][2]):
+        assert a.shape == b.shape and torch.equal(a.cpu(), b)
+    for a, b in zip(dev["K_pyr"], host["K_pyr"]):
+        assert torch.equal(a.cpu(), b)
+    for s_ in range(3):
+        assert torch.equal(dev["T_right_in_left"][s_].cpu(), host["T_right_in_left"][s_])
+        close(dev["T_left_in_right"][s_], host["T_left_in_right"][s_], rtol=1e-5, atol=1e-6)
+    assert torch.equal(dev["baseline"].cpu(), host["baseline"])
 
 
 def test_forward_properties_at_headline_size():
