@@ -414,8 +414,13 @@ def main():
                                      "min": round(min(windows), 1), "droop_last_vs_first": 1.0 - windows[-1] / windows[0],
                                      "timed_region_value": line["value"]}
             if not args.no_tiers:
-                line["pcie_inclusive"] = host_feed_rates(net, B, dev)
-                line["batch_latency"] = batch_latency(net)
+                # side legs: a failure in one of them must not cost the headline line
+                for key, leg in (("pcie_inclusive", lambda: host_feed_rates(net, B, dev)),
+                                 ("batch_latency", lambda: batch_latency(net))):
+                    try:
+                        line[key] = leg()
+                    except Exception as exc:   # noqa: BLE001
+                        line[key] = {"error": f"{type(exc).__name__}: {exc}"}
             if args.precision == "fp32" and not args.no_tiers:
                 # the two bf16-matrix-core tiers on the same resident inputs, reported beside the fp32 headline, never
                 # as it: the 3 x bf16 split (fp32-equivalent arithmetic) and plain bf16 operands
