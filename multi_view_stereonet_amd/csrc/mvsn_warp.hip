@@ -24,60 +24,32 @@ __global__ __launch_bounds__(256) void homography_warp_kernel(const float *__res
   Bilinear t = bilinear_taps(c.ix, c.iy, rows, cols);
   mask[((size_t)b * n_planes + plane) * P + p] = c.outside ? 1 : 0;
   const float keep = c.outside ? 0.0f : 1.0f;
-  const int o00 = t.y0 * cols + t.x0, o01 = t.y0 * cols + t.x1, o10 = t.y1 * cols + t.x0, o11 = t.y1 * cols + t.x1;
   const float *img = image + (size_t)b * C * P;
   float *out = volume + (((size_t)b * C) * n_planes + plane) * P + p;
+  if (cols >= 2) {
+    // The two taps of a row are neighbours in memory: ONE 8-byte load per row and channel (6 gathers per pixel
+    // instead of 12 -- the kernel is gather-issue-bound, a 4-pixel-per-thread form with 16-byte stores measured
+    // 185 us against 116).  At the right border (x1 clamped onto x0, weight exactly 0) the pair starts one texel
+    // earlier and the weights move to its second element: the same products, the same sum.
+    const int xb = t.x0 < cols - 1 ? t.x0 : cols - 2;
+    const bool sh = t.x0 != xb;
+    const float wa0 = sh ? 0.0f : t.w00, wb0 = sh ? t.w00 : t.w01;
+    const float wa1 = sh ? 0.0f : t.w10, wb1 = sh ? t.w10 : t.w11;
+    const int r0 = t.y0 * cols + xb, r1 = t.y1 * cols + xb;
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+    for (int ch = 0; ch < C; ++ch) {
+      const float *ic = img + (size_t)ch * P;
+      const f2u a = *reinterpret_cast<const f2u *>(ic + r0), bb = *reinterpret_cast<const f2u *>(ic + r1);
+      const float v = a.x * wa0 + a.y * wb0 + bb.x * wa1 + bb.y * wb1;
+      __builtin_nontemporal_store(keep * v, out + (size_t)ch * n_planes * P);   // keep*NaN stays NaN, as the reference
+    }
+    return;
+  }
+  const int o00 = t.y0 * cols + t.x0, o01 = t.y0 * cols + t.x1, o10 = t.y1 * cols + t.x0, o11 = t.y1 * cols + t.x1;
   for (int ch = 0; ch < C; ++ch) {
     const float *ic = img + (size_t)ch * P;
     float v = ic[o00] * t.w00 + ic[o01] * t.w01 + ic[o10] * t.w10 + ic[o11] * t.w11;
     out[(size_t)ch * n_planes * P] = keep * v;  // keep*NaN stays NaN, like the reference's multiply
-  }
-}
-
-// Four consecutive pixels of a row per thread (cols % 4 == 0, 16-byte aligned rows): the coordinate algebra per
-// pixel is unchanged (same fp32 expression order, so the mask flips on the same pixels), but the outputs leave as
-// one 16-byte store per channel and the four mask bytes as one dword -- a quarter of the store instructions of the
-// one-pixel form; the four footprints of a thread touch neighbouring texels (the full-resolution warps are near
-// the identity), i.e. the same cache lines.
-__global__ __launch_bounds__(256) void homography_warp4_kernel(const float *__restrict__ image,
-                                                               const float *__restrict__ H, int C, int n_planes,
-                                                               int rows, int cols, float *__restrict__ volume,
-                                                               uint8_t *__restrict__ mask) {
-  const int P = rows * cols, Q = P >> 2;
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  const int plane = blockIdx.y;
-  const int b = blockIdx.z;
-  if (q >= Q) return;
-  const float *Hp = H + ((size_t)b * n_planes + plane) * 9;
-  float Hl[9];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) Hl[i] = Hp[i];
-  const int p = q * 4;
-  const int y = p / cols, x = p - y * cols;
-  int o00[4], o01[4], o10[4], o11[4];
-  float w00[4], w01[4], w10[4], w11[4];
-  unsigned mbits = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    WarpCoord c = warp_coord(Hl, (float)(x + k), (float)y, (float)rows, (float)cols);
-    Bilinear t = bilinear_taps(c.ix, c.iy, rows, cols);
-    mbits |= (c.outside ? 1u : 0u) << (8 * k);
-    o00[k] = t.y0 * cols + t.x0, o01[k] = t.y0 * cols + t.x1, o10[k] = t.y1 * cols + t.x0, o11[k] = t.y1 * cols + t.x1;
-    // keep * (sum) as in the one-pixel kernel: the weights stay separate so that keep*NaN stays NaN
-    w00[k] = t.w00, w01[k] = t.w01, w10[k] = t.w10, w11[k] = t.w11;
-  }
-  *reinterpret_cast<unsigned *>(mask + ((size_t)b * n_planes + plane) * P + p) = mbits;
-  const float *img = image + (size_t)b * C * P;
-  float *out = volume + (((size_t)b * C) * n_planes + plane) * P + p;
-  for (int ch = 0; ch < C; ++ch) {
-    const float *ic = img + (size_t)ch * P;
-    floatx4 v;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float keep = ((mbits >> (8 * k)) & 1u) ? 0.0f : 1.0f;
-      v[k] = keep * (ic[o00[k]] * w00[k] + ic[o01[k]] * w01[k] + ic[o10[k]] * w10[k] + ic[o11[k]] * w11[k]);
-    }
-    __builtin_nontemporal_store(v, reinterpret_cast<floatx4 *>(out + (size_t)ch * n_planes * P));
   }
 }
 
@@ -90,12 +62,6 @@ extern "C" int mvsn_homography_warp(const float *image, const float *H, int batc
                "mvsn_homography_warp: bad sizes");
   MVSN_REQUIRE(n_planes <= 65535 && batch <= 65535, MVSN_E_TOOLARGE, "mvsn_homography_warp: grid too large");
   const int P = rows * cols;
-  if ((cols & 3) == 0 && ((((size_t)volume) | ((size_t)mask)) & 15) == 0 && P >= 4096) {   // full-resolution warps
-    dim3 grid((P / 4 + 255) / 256, n_planes, batch);
-    hipLaunchKernelGGL(mvsn::homography_warp4_kernel, grid, dim3(256), 0, (hipStream_t)stream, image, H, channels,
-                       n_planes, rows, cols, volume, mask);
-    return mvsn::check_launch("mvsn_homography_warp");
-  }
   dim3 grid((P + 255) / 256, n_planes, batch);
   hipLaunchKernelGGL(mvsn::homography_warp_kernel, grid, dim3(256), 0, (hipStream_t)stream, image, H, channels,
                      n_planes, rows, cols, volume, mask);
