@@ -478,13 +478,21 @@ __global__ __launch_bounds__(256, 2) void conv_to1_3d_mfma_kernel(const float *_
 // fragments in registers (zero outside the image, as the padding of the materialised tensor would be),
 // i.e. the last residual block's normalise/activate/add pass is folded into this layer's load.
 // Epilogue (optional): the refiner's relu(prior * fx + conv + bias) / fx.
-constexpr int T2_TY = 16, T2_TX = 32;          // measured: 8 x 64 tiles (288-byte rows) are within 1 %
-constexpr int T2_HY = T2_TY + 2, T2_XS = T2_TX + 8;
-constexpr int T2_SLOTS = T2_HY * T2_XS;        // 720
-constexpr int T2_GROUPS = (T2_SLOTS + 63) / 64;
-constexpr int T2_LDS_FLOATS = 9 * T2_SLOTS;   // 25,920 bytes
+// Output tiles of 16 x TX: 16 x 64 (an 18 x 72-slot haloed tile = 1.27x the outputs) when there are enough tiles to
+// fill the chip, 16 x 32 (1.41x, twice the workgroups) otherwise.  The halo lines of a 32-channel x 2-tensor stream
+// do not all stay in the 4 MB L2, so the ratio is HBM traffic: level-0 folded block at batch 128 1.36 -> 1.12 ms
+// (3.1 -> 3.9 TB/s algorithmic); 16 x 128 tiles 1.18 ms; round 1 measured 8 x 64 (the same 1.41x) within 1 % of 16 x 32.
+constexpr int T2_TY = 16;
+template <int TX>
+struct T2 {
+  static constexpr int XS = TX + 8, SLOTS = (T2_TY + 2) * XS, GROUPS = (SLOTS + 63) / 64, LDS_FLOATS = 9 * SLOTS;
+};
+// wide tiles once they alone give every CU four workgroups
+static inline bool to1_wide_tiles(int n, int rows, int cols) {
+  return (long)n * ((rows + T2_TY - 1) / T2_TY) * ((cols + 63) / 64) >= 4L * device_cus();
+}
 
-template <bool XFORM>
+template <bool XFORM, int T2_TX>
 __global__ __launch_bounds__(256) void conv_to1_2d_mfma_kernel(const float *__restrict__ in, const float *__restrict__ w,
                                                                const float *__restrict__ bias,
                                                                const float *__restrict__ in_stats,
@@ -493,7 +501,8 @@ __global__ __launch_bounds__(256) void conv_to1_2d_mfma_kernel(const float *__re
                                                                const float *__restrict__ in_residual,
                                                                const float *__restrict__ prior, const float *__restrict__ fx,
                                                                int H, int W, int ntx, float *__restrict__ out) {
-  __shared__ __attribute__((aligned(16))) float P[T2_LDS_FLOATS];
+  constexpr int T2_XS = T2<T2_TX>::XS, T2_SLOTS = T2<T2_TX>::SLOTS, T2_GROUPS = T2<T2_TX>::GROUPS;
+  __shared__ __attribute__((aligned(16))) float P[T2<T2_TX>::LDS_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = blockIdx.y;
@@ -519,9 +528,10 @@ __global__ __launch_bounds__(256) void conv_to1_2d_mfma_kernel(const float *__re
     }
   }
 
-  constexpr int GPW = T2_GROUPS / 4;   // 3 groups of 64 slots per wave
+  constexpr int GPW = (T2_GROUPS + 3) / 4;   // groups of 64 slots per wave (the last round may be partial)
 #pragma unroll
   for (int u = 0; u < GPW; ++u) {
+    if ((wave + 4 * u) * 64 >= T2_SLOTS) break;   // wave-uniform
     const int s0 = (wave + 4 * u) * 64 + 4 * (lane & 15);
     const int row = s0 / T2_XS, col = s0 - row * T2_XS;
     const int gy = y0 - 1 + row, gx = x0 - 4 + col;
@@ -557,28 +567,32 @@ __global__ __launch_bounds__(256) void conv_to1_2d_mfma_kernel(const float *__re
     }
   }
   __syncthreads();
-  const int oy = tid / (T2_TX / 2), ox = (tid % (T2_TX / 2)) * 2;
-  if (y0 + oy >= H || x0 + ox >= W) return;
-  const float *pg = P + oy * T2_XS + ox + 3;
-  float acc0 = 0.f, acc1 = 0.f;
-#pragma unroll
-  for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const float *q = pg + (dy * 3 + dx) * T2_SLOTS + dy * T2_XS + dx;
-      acc0 += q[0];
-      acc1 += q[1];
-    }
   const float b = bias ? bias[0] : 0.0f;
-  const size_t o = (size_t)n * plane + (size_t)(y0 + oy) * W + x0 + ox;
-  float2 res = make_float2(acc0 + b, acc1 + b);
-  if (prior) {
-    const float g = fx[n];
-    const float2 pv = *reinterpret_cast<const float2 *>(prior + o);
-    const float s0v = pv.x * g + res.x, s1v = pv.y * g + res.y;
-    res = make_float2((s0v > 0.0f ? s0v : 0.0f) / g, (s1v > 0.0f ? s1v : 0.0f) / g);
+#pragma unroll
+  for (int k = 0; k < T2_TY * T2_TX / 512; ++k) {   // two neighbouring outputs per thread and round
+    const int idx = tid + 256 * k;
+    const int oy = idx / (T2_TX / 2), ox = (idx % (T2_TX / 2)) * 2;
+    if (y0 + oy >= H || x0 + ox >= W) continue;
+    const float *pg = P + oy * T2_XS + ox + 3;
+    float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const float *q = pg + (dy * 3 + dx) * T2_SLOTS + dy * T2_XS + dx;
+        acc0 += q[0];
+        acc1 += q[1];
+      }
+    const size_t o = (size_t)n * plane + (size_t)(y0 + oy) * W + x0 + ox;
+    float2 res = make_float2(acc0 + b, acc1 + b);
+    if (prior) {
+      const float g = fx[n];
+      const float2 pv = *reinterpret_cast<const float2 *>(prior + o);
+      const float s0v = pv.x * g + res.x, s1v = pv.y * g + res.y;
+      res = make_float2((s0v > 0.0f ? s0v : 0.0f) / g, (s1v > 0.0f ? s1v : 0.0f) / g);
+    }
+    *reinterpret_cast<float2 *>(out + o) = res;
   }
-  *reinterpret_cast<float2 *>(out + o) = res;
 }
 
 }  // namespace mvsn
@@ -624,11 +638,19 @@ extern "C" int mvsn_conv_to1(const float *in, const float *weight, const float *
     return conv_to1_volume(in, weight, bias, nullptr, nullptr, nullptr, n, depth, rows, cols, out, stream);
   } else {
     MVSN_REQUIRE(depth == 1, MVSN_E_BADARG, "mvsn_conv_to1: kd = 1 needs depth = 1");
-    const int nty = (rows + mvsn::T2_TY - 1) / mvsn::T2_TY, ntx = (cols + mvsn::T2_TX - 1) / mvsn::T2_TX;
     MVSN_REQUIRE(n <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_to1: grid");
-    hipLaunchKernelGGL(mvsn::conv_to1_2d_mfma_kernel<false>, dim3(nty * ntx, n), dim3(256), 0, (hipStream_t)stream, in,
-                       weight, bias, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
-                       (const float *)nullptr, prior, fx, rows, cols, ntx, out);
+    const int nty = (rows + mvsn::T2_TY - 1) / mvsn::T2_TY;
+    if (mvsn::to1_wide_tiles(n, rows, cols)) {
+      const int ntx = (cols + 63) / 64;
+      hipLaunchKernelGGL((mvsn::conv_to1_2d_mfma_kernel<false, 64>), dim3(nty * ntx, n), dim3(256), 0,
+                         (hipStream_t)stream, in, weight, bias, (const float *)nullptr, (const float *)nullptr,
+                         (const float *)nullptr, (const float *)nullptr, prior, fx, rows, cols, ntx, out);
+    } else {
+      const int ntx = (cols + 31) / 32;
+      hipLaunchKernelGGL((mvsn::conv_to1_2d_mfma_kernel<false, 32>), dim3(nty * ntx, n), dim3(256), 0,
+                         (hipStream_t)stream, in, weight, bias, (const float *)nullptr, (const float *)nullptr,
+                         (const float *)nullptr, (const float *)nullptr, prior, fx, rows, cols, ntx, out);
+    }
   }
   return mvsn::check_launch("mvsn_conv_to1");
 }
@@ -653,8 +675,15 @@ extern "C" int mvsn_conv_to1_block(const float *in_raw, const float *in_stats, c
   MVSN_REQUIRE(cols % 4 == 0, MVSN_E_BADARG, "mvsn_conv_to1_block: cols must be a multiple of 4");
   MVSN_REQUIRE(!prior || fx, MVSN_E_BADARG, "mvsn_conv_to1_block: refiner epilogue needs fx");
   MVSN_REQUIRE(n <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_to1_block: grid");
-  const int nty = (rows + mvsn::T2_TY - 1) / mvsn::T2_TY, ntx = (cols + mvsn::T2_TX - 1) / mvsn::T2_TX;
-  hipLaunchKernelGGL(mvsn::conv_to1_2d_mfma_kernel<true>, dim3(nty * ntx, n), dim3(256), 0, (hipStream_t)stream, in_raw,
-                     weight, bias, in_stats, in_gamma, in_beta, in_residual, prior, fx, rows, cols, ntx, out);
+  const int nty = (rows + mvsn::T2_TY - 1) / mvsn::T2_TY;
+  if (mvsn::to1_wide_tiles(n, rows, cols)) {
+    const int ntx = (cols + 63) / 64;
+    hipLaunchKernelGGL((mvsn::conv_to1_2d_mfma_kernel<true, 64>), dim3(nty * ntx, n), dim3(256), 0, (hipStream_t)stream,
+                       in_raw, weight, bias, in_stats, in_gamma, in_beta, in_residual, prior, fx, rows, cols, ntx, out);
+  } else {
+    const int ntx = (cols + 31) / 32;
+    hipLaunchKernelGGL((mvsn::conv_to1_2d_mfma_kernel<true, 32>), dim3(nty * ntx, n), dim3(256), 0, (hipStream_t)stream,
+                       in_raw, weight, bias, in_stats, in_gamma, in_beta, in_residual, prior, fx, rows, cols, ntx, out);
+  }
   return mvsn::check_launch("mvsn_conv_to1_block");
 }
