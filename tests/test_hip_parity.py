@@ -115,6 +115,8 @@ CONV_CASES = [
     (32, 32, 3, 1, 8, 64, 96, 1), (3, 32, 5, 2, 1, 64, 128, 2), (32, 32, 5, 2, 1, 30, 45, 1),
     (32, 32, 5, 2, 1, 15, 23, 1), (36, 32, 3, 1, 1, 8, 12, 2), (4, 32, 3, 1, 1, 40, 70, 1),
     (35, 32, 3, 1, 1, 4, 8, 1), (32, 1, 3, 1, 1, 16, 32, 2), (32, 1, 3, 1, 1, 9, 5, 1),
+    # the extractor head's dedicated kernel (3 -> 32, 5x5, stride 2, cols % 8 == 0): partial tiles, odd rows, one row
+    (3, 32, 5, 2, 1, 37, 72, 2), (3, 32, 5, 2, 1, 64, 128, 3), (3, 32, 5, 2, 1, 1, 8, 1), (3, 32, 5, 2, 1, 50, 136, 1),
 ]
 
 
