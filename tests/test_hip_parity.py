@@ -728,6 +728,25 @@ def test_forward_headline_golden(name, wname, smooth):
     _check_mask4(name, out, fix)
 
 
+def test_forward_headline_golden_direct_chain_form():
+    """The headline fixture once more with the chain's convolutions in their DIRECT form (the path of the coarse grids
+    the Winograd plan does not cover): both forms sit inside the contract, and agree with each other far below it."""
+    fix = load_golden("g2_gta_512x256_d64_s2.npz")
+    net = net_for("gta_sfm_150epochs")
+    wino = _forward(net, fix)["left_idepthmap_pyr"][0]
+    net.options.chain_form = "direct"
+    try:
+        out = _forward(net, fix)
+    finally:
+        net.options.chain_form = "auto"
+    mean_rel, max_rel = rel_err(out["left_idepthmap_pyr"][0].cpu(), fix["idepth_0"])
+    assert mean_rel < 2e-4 and max_rel < 1e-3, (mean_rel, max_rel)
+    mean_rel, max_rel = rel_err(out["left_idepthmap_pyr"][0].cpu(), wino.cpu())
+    print(f"direct vs Winograd chain, final idepth: mean-rel {mean_rel:.3e} max-rel {max_rel:.3e}")
+    assert mean_rel < 2e-5 and max_rel < 2e-4
+    _check_mask4("g2 (direct chain)", out, fix)
+
+
 def _check_mask4(name, out, fix):
     """The stored level-4 mask of the reference, voxel by voxel: mismatches are counted and printed, and only
     voxels whose normalised coordinate sits within an ulp of the |n| > 1 predicate may differ."""
