@@ -45,7 +45,10 @@ _networks: Dict[tuple, object] = {}
 def _network_for(params: List[Tensor]):
     """The eager HIP module whose parameters ALIAS `params` (no copy); cached per parameter storage."""
     from .multi_view_stereonet import MultiViewStereoNet
-    key = tuple(p.data_ptr() for p in params)
+    # storage address AND version counter: the cached module aliases the caller's storages (which also keeps them
+    # alive, so an address cannot be recycled under a cached key), but its own version counters do not follow in-place
+    # updates of the caller's tensors (load_state_dict on the loaded archive) -- those show up here
+    key = tuple((p.data_ptr(), p._version) for p in params)
     net = _networks.get(key)
     if net is None:
         names = parameter_names()

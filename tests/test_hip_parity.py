@@ -1000,6 +1000,12 @@ def test_torchscript_archive_matches_eager(tmp_path):
     # a second call reuses the cached engine (same parameter storage), a flag variant goes through the same operator
     again = snu.multi_view_forward(stereo_network, inputs, dict(params, refiners=[False, True, True, True, True]))
     assert torch.equal(again["left_idepthmap_pyr"][1], out["left_idepthmap_pyr"][1])
+    # weights changed in place on the loaded archive (load_state_dict): the operator must not serve stale packed copies
+    stereo_network.load_state_dict({k: v.to(DEV) for k, v in load_weights("demon_45epochs").items()})
+    other = snu.multi_view_forward(stereo_network, inputs, params)
+    want = snu.multi_view_forward(net_for("demon_45epochs"), inputs, params)
+    assert torch.equal(other["left_idepthmap_pyr"][0], want["left_idepthmap_pyr"][0])
+    assert not torch.equal(other["left_idepthmap_pyr"][0], out["left_idepthmap_pyr"][0])
 
 
 def test_two_view_consistency_ops_golden():
