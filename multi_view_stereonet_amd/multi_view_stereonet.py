@@ -651,12 +651,12 @@ class MultiViewStereoNet(nn.Module):
     def engine(self) -> PlaneSweepEngine:
         # The packed copies go stale when a parameter is rebound (.to(), load_state_dict: both invalidate above) or
         # updated in place (bumps its version counter).  Walking the module tree for 202 (data_ptr, version) pairs on
-        # every forward cost ~0.1 ms of a 4 ms batch-1 forward: the parameter list is cached, the key is the version
-        # sum plus two storage addresses.
+        # every forward cost ~0.1 ms of a 4 ms batch-1 forward: the parameter list is cached; the key is the version
+        # sum (versions only grow) plus the storage addresses (a rebound .data).
         plist = self.__dict__.get("_plist")
         if plist is None:
             plist = self.__dict__["_plist"] = list(self.parameters())
-        key = (sum(p._version for p in plist), plist[0].data_ptr(), plist[-1].data_ptr(), len(plist))
+        key = (sum(p._version for p in plist), tuple(p.data_ptr() for p in plist))
         if self._engine is None or key != self._engine_key:
             self._engine = PlaneSweepEngine(self)
             self._engine_key = key
