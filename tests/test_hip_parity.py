@@ -610,6 +610,8 @@ def test_upsamplers_golden_units():
 @pytest.mark.parametrize("rows,cols,D,S,B,wname", [(64, 128, 16, 1, 1, "gta_sfm_150epochs"),
                                                    (256, 512, 64, 2, 1, "gta_sfm_150epochs"),
                                                    (80, 96, 8, 2, 2, "gta_sfm_150epochs"),
+                                                   (192, 320, 10, 1, 2, "gta_sfm_150epochs"),    # 12x20: 60 patches, 4 tiles, last partial
+                                                   (128, 256, 9, 2, 1, "gta_sfm_150epochs"),     # 8x16: two full tiles
                                                    (480, 640, 12, 1, 1, "demon_45epochs"),
                                                    (512, 1024, 6, 1, 1, "gta_sfm_150epochs")])
 @pytest.mark.parametrize("form", ["direct", "winograd"])
