@@ -176,6 +176,26 @@ int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, const float *
 int mvsn_conv_forward_blocks(const mvsn_conv_desc *desc, const float *const *in_blocks, const int *block_channels,
                              int num_blocks, const float *weight_packed, const float *bias, float *out,
                              float *out_partials, mvsn_stream_t stream);
+/* A normalise / activate / add pass handed over as a job: the arguments of mvsn_groupnorm_lrelu_apply (r_stats NULL,
+ * residual optional) or of mvsn_groupnorm_lrelu_add2 (r_stats / r_gamma / r_beta set: the residual is a raw conv output). */
+typedef struct mvsn_apply_job {
+  const float *x, *stats, *gamma, *beta;
+  const float *residual, *r_stats, *r_gamma, *r_beta;
+  float *out;      /* may alias x */
+  int n;           /* samples: (n, 32, spatial) */
+  long spatial;
+} mvsn_apply_job;
+/* mvsn_conv_forward (no in_residual / out_staged) AND an independent apply job in one call.  The residual blocks
+ * x + LeakyReLU(GroupNorm(conv(x))) (multi_view_stereonet.py:38-48, used :448-474) alternate a convolution bound by the
+ * matrix pipe with a pass bound by HBM; with the batch cut in two slices, slice B's convolution can carry slice A's
+ * pass in its own launch (the job's 16-byte loads / stores are issued by the convolution's waves between their
+ * multiplies).  The job must not depend on this convolution's output, nor the convolution on the job's.  Where the
+ * layer's kernel cannot carry it (not a Winograd 32 -> 32 2-D layer, spatial % 256 != 0, job larger than the layer's
+ * own output) the job runs as its own launch first: results are bit-identical either way; *carried (may be NULL)
+ * says which it was. */
+int mvsn_conv_forward_carry(const mvsn_conv_desc *desc, const float *in, const float *weight_packed, const float *bias,
+                            const float *in_stats, const float *in_gamma, const float *in_beta, float *out,
+                            float *out_partials, const mvsn_apply_job *job, int *carried, mvsn_stream_t stream);
 /* partials (N,R,4,3) {count, mean, M2} per record and group (R = mvsn_conv_num_tiles records per sample, passed as
  * `tiles`) -> stats (N,4,2) = {mean, rstd}, eps 1e-5, biased variance; records are 48 bytes, 16-byte aligned */
 int mvsn_groupnorm_finalize(const float *partials, int n, int tiles, float *stats, mvsn_stream_t stream);

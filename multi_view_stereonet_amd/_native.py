@@ -21,6 +21,13 @@ class ConvDesc(Structure):
                 ("dilation", c_int), ("precision", c_int)]
 
 
+class ApplyJob(Structure):
+    """mvsn_apply_job"""
+    _fields_ = [("x", c_void_p), ("stats", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
+                ("residual", c_void_p), ("r_stats", c_void_p), ("r_gamma", c_void_p), ("r_beta", c_void_p),
+                ("out", c_void_p), ("n", c_int), ("spatial", c_long)]
+
+
 CONV_FP32, CONV_BF16X3, CONV_FP32_WINO, CONV_BF16 = 0, 1, 2, 3
 CHAIN_AUTO, CHAIN_DIRECT, CHAIN_WINOGRAD = 0, 1, 2
 ABI_VERSION = 2
@@ -44,6 +51,7 @@ SIGNATURES = {
     "mvsn_conv_num_tiles": (c_int, [POINTER(ConvDesc)]),
     "mvsn_conv_forward": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 10 + [c_void_p]),
     "mvsn_conv_forward_blocks": (c_int, [POINTER(ConvDesc), c_void_p, POINTER(c_int), c_int] + [c_void_p] * 4 + [c_void_p]),
+    "mvsn_conv_forward_carry": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 8 + [POINTER(ApplyJob), POINTER(c_int), c_void_p]),
     "mvsn_groupnorm_finalize": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mvsn_groupnorm_lrelu_apply": (c_int, [c_void_p] * 5 + [c_int, c_long, c_void_p, c_void_p]),
     "mvsn_groupnorm_lrelu_add2": (c_int, [c_void_p] * 8 + [c_int, c_long, c_void_p, c_void_p]),

@@ -1228,6 +1228,35 @@ extern "C" int mvsn_groupnorm_lrelu_add2(const float *x, const float *stats, con
   return mvsn::check_launch("mvsn_groupnorm_lrelu_add2");
 }
 
+extern "C" int mvsn_conv_forward_carry(const mvsn_conv_desc *desc, const float *in, const float *weight_packed,
+                                       const float *bias, const float *in_stats, const float *in_gamma,
+                                       const float *in_beta, float *out, float *out_partials,
+                                       const mvsn_apply_job *job, int *carried, mvsn_stream_t stream) {
+  using namespace mvsn;
+  if (carried) *carried = 0;
+  if (!job)
+    return mvsn_conv_forward(desc, in, weight_packed, bias, in_stats, in_gamma, in_beta, nullptr, nullptr, out,
+                             out_partials, stream);
+  MVSN_REQUIRE(job->x && job->stats && job->gamma && job->beta && job->out && job->n > 0 && job->spatial > 0,
+               MVSN_E_BADARG, "mvsn_conv_forward_carry: bad job");
+  MVSN_REQUIRE(in && weight_packed && out, MVSN_E_BADARG, "mvsn_conv_forward_carry: null pointer");
+  WinoGeom wg;
+  if (desc && desc->precision == MVSN_CONV_FP32_WINO && wino_geom(desc, &wg) && wino_can_carry(wg, job) &&
+      (!in_stats || (in_gamma && in_beta)) && wg.n <= 65535) {
+    if (carried) *carried = 1;
+    return wino_launch(wg, in, weight_packed, bias, in_stats, in_gamma, in_beta, out, out_partials,
+                       (hipStream_t)stream, nullptr, job);
+  }
+  const int rc = job->r_stats
+                     ? mvsn_groupnorm_lrelu_add2(job->x, job->stats, job->gamma, job->beta, job->residual, job->r_stats,
+                                                 job->r_gamma, job->r_beta, job->n, job->spatial, job->out, stream)
+                     : mvsn_groupnorm_lrelu_apply(job->x, job->stats, job->gamma, job->beta, job->residual, job->n,
+                                                  job->spatial, job->out, stream);
+  if (rc) return rc;
+  return mvsn_conv_forward(desc, in, weight_packed, bias, in_stats, in_gamma, in_beta, nullptr, nullptr, out,
+                           out_partials, stream);
+}
+
 extern "C" int mvsn_selftest_mfma(mvsn_stream_t stream) {
   int *dbad = nullptr;
   hipError_t e = hipMalloc(&dbad, sizeof(int));

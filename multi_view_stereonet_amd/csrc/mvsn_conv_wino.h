@@ -24,6 +24,8 @@ struct WinoBlocks {
 };
 int wino_launch(const WinoGeom &g, const float *in, const float *upk, const float *bias, const float *in_stats,
                 const float *in_gamma, const float *in_beta, float *out, float *out_partials, hipStream_t stream,
-                const WinoBlocks *blocks = nullptr);
+                const WinoBlocks *blocks = nullptr, const mvsn_apply_job *job = nullptr);
+// a normalise / activate / add job can travel inside this layer's launch (mvsn_conv_forward_carry)
+bool wino_can_carry(const WinoGeom &g, const mvsn_apply_job *job);
 
 }  // namespace mvsn

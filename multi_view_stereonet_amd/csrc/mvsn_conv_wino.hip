@@ -61,6 +61,10 @@ __device__ floatx4 g_wn_zero16 = {0.f, 0.f, 0.f, 0.f};
 #define MVSN_WN_ABLATE 0
 #endif
 
+#ifndef MVSN_RD_ABLATE   // tuning aid, carried jobs: bit 0 no loads, 1 no arithmetic / stores, 2 no residual fetch
+#define MVSN_RD_ABLATE 0
+#endif
+
 #ifndef MVSN_WN_SHIFT
 #define MVSN_WN_SHIFT 1
 #endif
@@ -93,6 +97,22 @@ struct WinoArgs {
   const float *in1, *in2;
   int D;   // planes per sample (volume form; 1 for the 2-D layers)
 };
+
+// A normalise / activate / add pass over ANOTHER tensor that this launch's waves carry along (template RIDE = 256-float
+// units per wave and step): out = LReLU(GN(x)) [+ residual | + LReLU(GN_r(residual))], the arithmetic of
+// gn_apply_kernel.  The convolution is bound by the matrix pipe and leaves most of the HBM bandwidth unused; the pass
+// is pure streaming.  Unit u of the job belongs to step (tile, chunk) of wave w: u = ((tile * nsteps + chunk) * 8 + w)
+// * RIDE + j -- a tile's steps cover 64 KB of the job, the size of the tile's own output.  A unit is loaded at the
+// start of a step (two 16-byte loads per lane) and normalised / stored at the start of the next one.
+struct RideArgs {
+  const float *x, *stats, *gamma, *beta;
+  const float *res, *r_stats, *r_gamma, *r_beta;   // res: optional; r_stats: the residual is itself a raw conv output
+  float *out;
+  int units;        // 256-float units of the job (spatial % 256 == 0: a unit lies inside one (sample, channel) plane)
+  WinoDiv fd_upp;   // units per plane
+};
+typedef const __attribute__((address_space(4))) float *wn_cfloat;   // uniform reads through the scalar cache
+__device__ __forceinline__ float wn_sload(const float *p, size_t i) { return ((wn_cfloat)(size_t)p)[i]; }
 
 // U = G g G^T per (cout, cin), packed [chunk of 4 cin][xi = 4i + j][cout tile][lane]; lane = k*16 + c holds
 // U_xi[cin = chunk*4 + k][cout = t*16 + c] (the B fragment of the MFMA), zero outside (c_in, 32).
@@ -127,7 +147,8 @@ __global__ void wino_pack_kernel(const float *__restrict__ w, int cin, int cout,
 //         tile); its 3 x 4 steps accumulate into one set of registers.  The 192 KB of transformed weights do not
 //         fit next to the raw ring, so each step's 16 KB of U travel through a second ring one step behind the
 //         raw tiles (the slot of step s is free once every wave has passed the barrier of step s + 1).
-template <int MODE, int KS, int NSTAGE, int DIL, bool VOL = false>
+// RIDE    256-float units of a carried normalise / activate / add job per wave and step (0: none), see RideArgs
+template <int MODE, int KS, int NSTAGE, int DIL, bool VOL = false, int RIDE = 0>
 __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, const float *__restrict__ in,
                                                                   const float *__restrict__ upk,
                                                                   const float *__restrict__ bias,
@@ -135,7 +156,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
                                                                   const float *__restrict__ in_gamma,
                                                                   const float *__restrict__ in_beta,
                                                                   float *__restrict__ out,
-                                                                  float *__restrict__ out_partials) {
+                                                                  float *__restrict__ out_partials, RideArgs rd) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int PA = wn_pa(DIL), XS = wn_xs(DIL), DQ = XS / 4, GROUPS = wn_groups(DIL), PIECES = wn_pieces(DIL);
   constexpr int RCST = wn_rcst(DIL);
@@ -190,6 +211,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   int pf_goff[PER];
   int pf_n = 0, pf_z = 0;
   bool pf_live = slot < total;
+  bool pf_did = false;   // RIDE: the previous step issued its DMA pieces
   auto pf_plan = [&]() {   // DMA plan of the prefetcher's current item
     const int flat = pf_round * G + slot;
     const int n = flat / ptiles;
@@ -211,6 +233,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   };
   auto pf_issue = [&]() {   // issue the DMA of the prefetcher's step and advance it
     if (!pf_live) return;
+    pf_did = true;
     bool cok;
     const float *src;
     if constexpr (VOL) {   // step = (depth tap, 8 channels): plane pf_z + kz - 1 of channel c, zeros outside the volume
@@ -275,6 +298,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   // (vmcnt retires in order; waves 0-3 issue two pieces per step, waves 4-7 one)
   constexpr int PERV = PER + (VOL ? 2 : 0);   // + the step's two U pieces
   static_assert(!VOL || EVEN, "volume form: every wave issues the same number of pieces");
+  static_assert(RIDE == 0 || (!VOL && EVEN), "carried jobs: 2-D layers with an even DMA split");
   auto wait_landed = [&](int younger) {
 #define WN_WAIT_CASE(K)                                                              \
   case K:                                                                            \
@@ -442,6 +466,67 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     }
   };
 
+  // ---- RIDE: the carried job.  A step's RIDE consecutive units (one plane: units per plane % RIDE == 0) are fetched
+  // at its start -- x into registers, the residual by LDS-DMA into the wave's own 1 KB slots behind U (no registers
+  // held across the multiplies, no other wave reads them: no barrier) -- and normalised / stored at the start of
+  // the next step: the only entries of the (in-order) vmcnt queue younger than them are that step's DMA pieces.
+  constexpr int RN = RIDE > 0 ? RIDE : 1;
+  floatx4 rd_v[RN];
+  float rd_sc = 0.f, rd_sh = 0.f, rd_rsc = 0.f, rd_rsh = 0.f;   // wave-uniform
+  int rd_u = -1;                                                // first unit in flight, -1: none
+  float *rds = U + g.nchunks * WN_UFLOATS + wave * (RN * 256);
+  auto rd_issue = [&](int flat, int chunk) {
+    if constexpr (RIDE > 0) {
+      const int u = ((flat * nsteps + chunk) * WN_WAVES + wave) * RN;
+      if (u < rd.units) {   // uniform
+        rd_u = u;
+        const int pl = wdiv(u, rd.fd_upp), c = pl & 31, n = pl >> 5;
+        const float mean = wn_sload(rd.stats, ((size_t)n * 4 + (c >> 3)) * 2 + 0);
+        const float rstd = wn_sload(rd.stats, ((size_t)n * 4 + (c >> 3)) * 2 + 1);
+        rd_sc = rstd * wn_sload(rd.gamma, c);
+        rd_sh = wn_sload(rd.beta, c) - mean * rd_sc;
+        const size_t off = (size_t)u * 256 + lane * 4;
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+          if (!(MVSN_RD_ABLATE & 1))
+            rd_v[j] = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(rd.x + off + j * 256));
+        if (rd.res && !(MVSN_RD_ABLATE & 4)) {
+#pragma unroll
+          for (int j = 0; j < RN; ++j)
+            __builtin_amdgcn_global_load_lds(WN_GPTR(rd.res + off + j * 256), WN_LPTR(rds + j * 256), 16, 0, 0);
+        }
+        if (rd.r_stats) {
+          const float rm = wn_sload(rd.r_stats, ((size_t)n * 4 + (c >> 3)) * 2 + 0);
+          rd_rsc = wn_sload(rd.r_stats, ((size_t)n * 4 + (c >> 3)) * 2 + 1) * wn_sload(rd.r_gamma, c);
+          rd_rsh = wn_sload(rd.r_beta, c) - rm * rd_rsc;
+        }
+      }
+    }
+  };
+  auto rd_consume = [&]() {
+    if constexpr (RIDE > 0) {
+#pragma unroll
+      for (int j = 0; j < RN; ++j) {
+        if (MVSN_RD_ABLATE & 2) continue;
+        floatx4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = lrelu02(rd_v[j][k] * rd_sc + rd_sh);
+        if (rd.res) {
+          const floatx4 r = *reinterpret_cast<const floatx4 *>(rds + j * 256 + lane * 4);
+          if (rd.r_stats) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] += lrelu02(r[k] * rd_rsc + rd_rsh);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] += r[k];
+          }
+        }
+        __builtin_nontemporal_store(o, reinterpret_cast<floatx4 *>(rd.out + (size_t)rd_u * 256 + j * 256 + lane * 4));
+      }
+      rd_u = -1;
+    }
+  };
+
   float v[KS][16];
   if (total_steps > 0) {
     tr_setup();
@@ -582,15 +667,27 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     int chunk = 0;
     auto do_step = [&](auto firstc) {
       const bool has_next = step + 1 < total_steps;   // uniform
+      bool waited = false;
+      if constexpr (RIDE > 0) {
+        if (rd_u >= 0) {   // uniform.  Everything up to the carried loads has landed once only the previous step's
+          // DMA pieces are outstanding -- which covers step + 1 (issued NSTAGE - 1 >= 2 steps ago) as well.
+          if (pf_did) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PERV) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          rd_consume();
+          waited = true;
+        }
+        pf_did = false;
+      }
       if (has_next) {
         const int rest = total_steps - (step + 2);     // steps issued after step + 1 so far
-        wait_landed(rest < 0 ? 0 : (rest < NSTAGE - 2 ? rest : NSTAGE - 2));   // step + 1 has landed
+        if (!waited) wait_landed(rest < 0 ? 0 : (rest < NSTAGE - 2 ? rest : NSTAGE - 2));   // step + 1 has landed
         xf_apply();        // step + 1
         WN_STAMP();   // landed
         if (!(MVSN_WN_ABLATE & 8)) __syncthreads();   // ... for everyone; everyone has read the raw tile of `step`
         WN_STAMP();   // barrier
         xf_prepare();      // step + 2: its scalar loads travel behind this step's multiplies
       }
+      rd_issue(flat, chunk);
       // multiplies of `step` with the transform of `step + 1` slotted between them
       float dn[KS][4][4];
       if (has_next && !(MVSN_WN_ABLATE & 32)) tr_load(dn);
@@ -653,6 +750,12 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     for (chunk = 1; chunk < nsteps; ++chunk) do_step(std::false_type{});
     if (!(MVSN_WN_ABLATE & 16) || n < 0) finish_tile(n, z, tile_id, y0, x0);
   }
+  if constexpr (RIDE > 0) {
+    if (rd_u >= 0) {   // the last step's units
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      rd_consume();
+    }
+  }
 #ifdef MVSN_WN_STAMPS
   if (dbg)
     for (int i = 0; i < dbg_i; ++i) dbg[i] = dbg_lds[i];
@@ -695,9 +798,39 @@ int wino_pack(const mvsn_conv_desc *d, const float *weight, float *packed, hipSt
   return check_launch("mvsn_conv_pack_weights(winograd)");
 }
 
+// RIDE units per wave and step of the instantiation a layer runs on (0: that kernel carries nothing)
+static int wino_ride_units(const WinoGeom &g) {
+  if (g.vol || g.nchunks != 8) return 0;
+  if (g.dil == 4) return 0;    // 94 KB of raw ring + 64 KB of U: no room for the residual slots
+  return g.dil == 8 ? 1 : 2;   // 8 steps of one k-step / 4 steps of two: 64 units = 64 KB per tile either way
+}
+
+bool wino_can_carry(const WinoGeom &g, const mvsn_apply_job *job) {
+  const int r = wino_ride_units(g);
+  if (!r || !job || !job->x || !job->stats || !job->gamma || !job->beta || !job->out || job->n <= 0) return false;
+  if (job->spatial <= 0 || job->spatial % (256 * r) != 0) return false;   // a step's units lie in one plane
+  if (job->r_stats && !(job->residual && job->r_gamma && job->r_beta)) return false;
+  if ((((size_t)job->x | (size_t)job->out | (size_t)job->residual) & 15) != 0) return false;
+  const long units = (long)job->n * 32 * (job->spatial / 256);
+  const int nsteps = g.dil == 8 ? 8 : 4;
+  return units <= (long)g.n * g.tiles * nsteps * WN_WAVES * r && units < (1L << 30);
+}
+
 int wino_launch(const WinoGeom &g, const float *in, const float *upk, const float *bias, const float *in_stats,
                 const float *in_gamma, const float *in_beta, float *out, float *out_partials, hipStream_t stream,
-                const WinoBlocks *blocks) {
+                const WinoBlocks *blocks, const mvsn_apply_job *job) {
+  RideArgs rd = {};
+  if (job) {
+    if (blocks || !wino_can_carry(g, job)) {
+      set_error("mvsn_conv_forward(winograd): this launch cannot carry the job");
+      return MVSN_E_BADARG;
+    }
+    rd.x = job->x, rd.stats = job->stats, rd.gamma = job->gamma, rd.beta = job->beta;
+    rd.res = job->residual, rd.r_stats = job->r_stats, rd.r_gamma = job->r_gamma, rd.r_beta = job->r_beta;
+    rd.out = job->out;
+    rd.units = (int)((long)job->n * 32 * (job->spatial / 256));
+    rd.fd_upp = wino_div((unsigned)(job->spatial / 256));
+  }
   WinoArgs a;
   a.n = g.n, a.cin = g.cin, a.H = g.H, a.W = g.W, a.ntx = g.ntx, a.tiles = g.tiles, a.nchunks = g.nchunks;
   a.fd_ntx = wino_div((unsigned)g.ntx);
@@ -710,9 +843,11 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   //   volume form: 2 x 3 raw stages + 3 stages of U (118 KB)
   const bool head = g.nchunks == 1;
   const int ks = (head || g.dil == 8) ? 1 : 2;
-  const int nstage = head ? 6 : ((g.dil == 1 && g.nchunks <= 8) ? 4 : 3);
+  // (a carrying launch waits with one step of DMA in flight, see RideArgs: a fourth stage would never be used)
+  const int nstage = head ? 6 : ((g.dil == 1 && g.nchunks <= 8 && !job) ? 4 : 3);
   size_t lds = ((size_t)nstage * ks * 4 * wn_rcst(g.dil) +
                 (g.vol ? (size_t)nstage * ks : (size_t)g.nchunks) * WN_UFLOATS) * sizeof(float);
+  if (job) lds += (size_t)WN_WAVES * wino_ride_units(g) * 1024;   // the carried job's residual slots
 #ifdef MVSN_WN_STAMPS
   lds += 1024;   // stamp area
 #endif
@@ -733,11 +868,16 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
       return rc;                                                                                                   \
     hipLaunchKernelGGL((conv_wino_kernel<M, K, N, D, ##__VA_ARGS__>), grid, dim3(WN_THREADS), lds, stream, a, in,  \
                        upk, bias,                                                                                  \
-                       in_stats, in_gamma, in_beta, out, out_partials);                                            \
+                       in_stats, in_gamma, in_beta, out, out_partials, rd);                                        \
   } while (0)
   const long total = (long)g.n * g.D * g.tiles;
   grid = dim3((unsigned)(total < cus ? total : cus));   // persistent: one workgroup per CU walks items grid-strided
   const bool xf = in_stats != nullptr;
+  if (job) {   // the same kernels with the carried job's loads / stores in their steps
+    if (g.dil == 1) { if (xf) WN_CASE(1, 2, 3, 1, false, 2); else WN_CASE(0, 2, 3, 1, false, 2); }
+    else if (g.dil == 2) { if (xf) WN_CASE(1, 2, 3, 2, false, 2); else WN_CASE(0, 2, 3, 2, false, 2); }
+    else { if (xf) WN_CASE(1, 1, 3, 8, false, 1); else WN_CASE(0, 1, 3, 8, false, 1); }
+  } else
   if (g.vol) { if (xf) WN_CASE(1, 2, 3, 1, true); else WN_CASE(0, 2, 3, 1, true); }
   else if (head) { if (xf) WN_CASE(1, 1, 6, 1); else WN_CASE(0, 1, 6, 1); }
   else if (g.dil == 1 && g.nchunks > 8) { if (xf) WN_CASE(1, 2, 3, 1); else WN_CASE(0, 2, 3, 1); }

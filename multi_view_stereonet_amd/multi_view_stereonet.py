@@ -110,9 +110,34 @@ class EngineOptions:
         # The fused chain's three 3x3 convolutions: "auto" = Winograd F(2x2,3x3) where the coarse grid has a plan
         # (16x32 at 512x256 frames), the direct implicit GEMM elsewhere; "direct" / "winograd" force one form.
         self.chain_form = "auto"
+        # Refiner towers on two batch slices, software-pipelined: slice B's convolution (matrix-pipe-bound) carries
+        # slice A's normalise/activate/add pass (HBM-bound) inside its own launch (mvsn_conv_forward_carry).  Used
+        # where a slice's activation tensor has at least `carry_min_bytes` bytes (small levels are launch-bound).
+        self.carry_passes = True
+        self.carry_min_bytes = 32 << 20
 
-    NAMES = ("chain_form", "fold_residual_blocks", "conv_precision", "winograd", "winograd_with_input_transform",
+    NAMES = ("carry_passes", "carry_min_bytes", "chain_form", "fold_residual_blocks", "conv_precision", "winograd", "winograd_with_input_transform",
              "winograd_volume", "volume_materialise", "trim_tower_ends", "cat_free_heads")
+
+
+class _Job:
+    """mvsn_apply_job + the tensors it points at: out = LReLU(GN(r)) [+ residual | + LReLU(GN_0(residual))], in place."""
+
+    def __init__(self, r, stats, norm, residual=None, r_stats=None, r_norm=None):
+        self.keep = (r, stats, norm, residual, r_stats, r_norm)
+        n, spatial = r.shape[0], r[0, 0].numel()
+        P = _native.ptr
+        self.job = _native.ApplyJob(P(r), P(stats), P(norm.gamma), P(norm.beta), P(residual), P(r_stats),
+                                    P(r_norm.gamma) if r_norm else None, P(r_norm.beta) if r_norm else None,
+                                    P(r), n, spatial)
+        self.nbytes = 4.0 * r.numel() * (2 if residual is None else 3)
+
+    def run_alone(self, eng):
+        r, stats, norm, residual, r_stats, r_norm = self.keep
+        if r_stats is not None:
+            eng.gn_lrelu_add2(r, stats, norm, residual, r_stats, r_norm, out=r)
+        else:
+            eng.gn_lrelu(r, stats, norm, residual=residual, out=r)
 
 
 class PlaneSweepEngine:
@@ -132,6 +157,7 @@ class PlaneSweepEngine:
 
     def __init__(self, net: "MultiViewStereoNet"):
         self.lib = lib = _native.load()
+        self.carried_jobs = 0          # normalise/activate/add passes that travelled inside a convolution launch
         # tuning switches live on the module (EngineOptions), so they survive every rebuild of this object
         # (.to(), load_state_dict, in-place parameter updates); `engine.<switch>` reads and writes through
         object.__setattr__(self, "opt", net.options)
@@ -181,20 +207,25 @@ class PlaneSweepEngine:
         self.timeline.append((kernel, a, b, float(flops), float(nbytes)))
 
     def conv(self, c: _Conv, x: torch.Tensor, in_stats=None, in_norm: Optional[_Norm] = None, want_stats=False,
-             in_residual: Optional[torch.Tensor] = None, write_staged: bool = False):
+             in_residual: Optional[torch.Tensor] = None, write_staged: bool = False, carry: Optional["_Job"] = None,
+             out: Optional[torch.Tensor] = None):
         """x (N,C,[D,]H,W) -> (out, stats or None[, staged]).
 
         `in_stats`/`in_norm` fold LReLU(GN(x)) into the tile load; `in_residual` adds the residual
         branch on top (a whole SimpleBasicBlock folded into the NEXT layer's load); `write_staged`
         returns that folded input as a tensor (it is the block's output, needed as the next residual).
+        `carry`: an independent normalise/activate/add job executed with this launch (inside it where the
+        layer's kernel can, as its own launch otherwise); `out`: write into this tensor.
         """
         lib = self.lib
         if isinstance(x, (list, tuple)):
             # input as channel blocks: the Winograd head reads them in place, anything else gets the concatenation
-            out = self.conv_blocks(c, x, want_stats) if (in_stats is None and in_residual is None and
-                                                         not write_staged) else None
-            if out is not None:
-                return out
+            res = self.conv_blocks(c, x, want_stats, out=out) if (in_stats is None and in_residual is None and
+                                                                  not write_staged) else None
+            if res is not None:
+                if carry is not None:
+                    carry.run_alone(self)
+                return res
             x = torch.cat(list(x), 1)
         n = x.shape[0]
         depth = x.shape[2] if c.dims == 3 else 1
@@ -215,7 +246,9 @@ class PlaneSweepEngine:
                 d, packed = dwn, c.packed_wino
         ro, co = (rows - 1) // c.stride + 1, (cols - 1) // c.stride + 1
         shape = (n, c.cout, depth, ro, co) if c.dims == 3 else (n, c.cout, ro, co)
-        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        assert tuple(out.shape) == shape and out.is_contiguous()
         staged = torch.empty_like(x) if write_staged else None
         partials = None
         if want_stats:
@@ -229,11 +262,22 @@ class PlaneSweepEngine:
                (" wino" if d.precision == _native.CONV_FP32_WINO else ""))
         nbytes = 4.0 * (x.numel() * (2 if in_residual is not None else 1) + out.numel() +
                         (staged.numel() if staged is not None else 0))
-        self._call("mvsn_conv_forward[" + tag + "]", lib.mvsn_conv_forward, ctypes.byref(d), _native.ptr(x),
-                   _native.ptr(packed), _native.ptr(c.bias), _native.ptr(in_stats),
-                   _native.ptr(in_norm.gamma) if in_norm else None, _native.ptr(in_norm.beta) if in_norm else None,
-                   _native.ptr(in_residual), _native.ptr(staged), _native.ptr(out), _native.ptr(partials),
-                   _native.stream(), flops=2.0 * c.cin * taps * c.cout * out[:, 0].numel(), nbytes=nbytes)
+        if carry is not None:
+            assert in_residual is None and not write_staged
+            carried = ctypes.c_int(0)
+            self._call("mvsn_conv_forward_carry[" + tag + "]", lib.mvsn_conv_forward_carry, ctypes.byref(d),
+                       _native.ptr(x), _native.ptr(packed), _native.ptr(c.bias), _native.ptr(in_stats),
+                       _native.ptr(in_norm.gamma) if in_norm else None, _native.ptr(in_norm.beta) if in_norm else None,
+                       _native.ptr(out), _native.ptr(partials), ctypes.byref(carry.job), ctypes.byref(carried),
+                       _native.stream(), flops=2.0 * c.cin * taps * c.cout * out[:, 0].numel(),
+                       nbytes=nbytes + carry.nbytes)
+            self.carried_jobs += carried.value
+        else:
+            self._call("mvsn_conv_forward[" + tag + "]", lib.mvsn_conv_forward, ctypes.byref(d), _native.ptr(x),
+                       _native.ptr(packed), _native.ptr(c.bias), _native.ptr(in_stats),
+                       _native.ptr(in_norm.gamma) if in_norm else None, _native.ptr(in_norm.beta) if in_norm else None,
+                       _native.ptr(in_residual), _native.ptr(staged), _native.ptr(out), _native.ptr(partials),
+                       _native.stream(), flops=2.0 * c.cin * taps * c.cout * out[:, 0].numel(), nbytes=nbytes)
         stats = None
         if want_stats:
             stats = torch.empty((n, 4, 2), dtype=torch.float32, device=x.device)
@@ -243,7 +287,7 @@ class PlaneSweepEngine:
             return out, stats, staged
         return out, stats
 
-    def conv_blocks(self, c: _Conv, blocks, want_stats=False):
+    def conv_blocks(self, c: _Conv, blocks, want_stats=False, out: Optional[torch.Tensor] = None):
         """3x3 layer on the channel-wise concatenation of up to three tensors without assembling it
         (mvsn_conv_forward_blocks); None when the layer / shape has no such path."""
         lib = self.lib
@@ -259,7 +303,9 @@ class PlaneSweepEngine:
         blocks = [b.contiguous() for b in blocks]
         if any(b.data_ptr() % 16 for b in blocks):
             return None
-        out = torch.empty((n, c.cout, rows, cols), dtype=torch.float32, device=x0.device)
+        if out is None:
+            out = torch.empty((n, c.cout, rows, cols), dtype=torch.float32, device=x0.device)
+        assert tuple(out.shape) == (n, c.cout, rows, cols) and out.is_contiguous()
         partials = None
         if want_stats:
             partials = torch.empty((n, lib.mvsn_conv_num_tiles(ctypes.byref(d)), 4, 3), dtype=torch.float32,
@@ -332,6 +378,47 @@ class PlaneSweepEngine:
         out, _ = self.conv(final, x)
         return out, False
 
+    def residual_tower_sliced(self, blocks_in, first, blocks, final: _Conv, prior, fx):
+        """residual_tower_unfused (trimmed ends, 32 -> 1 tail with the refiner epilogue) on TWO batch slices,
+        software-pipelined so that every stand-alone normalise/activate/add pass of one slice travels inside the
+        other slice's next convolution launch (`carry`): the launch order is
+            head(A) head(B) c1(A) c1(B)+p1(A) c2(A)+p1(B) c2(B)+p2(A) ... c6(A)+p5(B) c6(B) tail(A) tail(B)
+        with p_k = the pass that turns block k's raw output into its activation.  Same kernels, same arithmetic
+        per sample as the unsliced tower: bit-identical results."""
+        n = blocks_in[0].shape[0]
+        h = (n + 1) // 2
+        bounds = ((0, h), (h, n))
+        rows, cols = blocks_in[0].shape[-2], blocks_in[0].shape[-1]
+        dev = blocks_in[0].device
+        conv0, bn0 = first
+        r0 = torch.empty((n, 32, rows, cols), dtype=torch.float32, device=dev)
+        st0 = [self.conv(conv0, [b[a:e] for b in blocks_in], want_stats=True, out=r0[a:e])[1] for a, e in bounds]
+        x = [None, None]                 # the slice's current block input (materialised by a carried pass)
+        job = None
+        last = len(blocks) - 1
+        tails = []
+        for i, (conv, norm) in enumerate(blocks):
+            r = torch.empty((n, 32, rows, cols), dtype=torch.float32, device=dev)
+            for s_, (a, e) in enumerate(bounds):
+                if i == 0:
+                    _, st = self.conv(conv, r0[a:e], in_stats=st0[s_], in_norm=bn0, want_stats=True, carry=job,
+                                      out=r[a:e])
+                else:
+                    _, st = self.conv(conv, x[s_], want_stats=True, carry=job, out=r[a:e])
+                if i == last:
+                    job = None
+                    tails.append((r[a:e], st, norm, x[s_]))
+                elif i == 0:
+                    job = _Job(r[a:e], st, norm, r0[a:e], st0[s_], bn0)      # x1 = LReLU(GN(r1)) + LReLU(GN(r0))
+                    x[s_] = r[a:e]
+                else:
+                    job = _Job(r[a:e], st, norm, x[s_])                      # x_k = x_{k-1} + LReLU(GN(r_k))
+                    x[s_] = r[a:e]
+        out = torch.empty((n, 1, rows, cols), dtype=torch.float32, device=dev)
+        for (a, e), (r_, st, norm, x_) in zip(bounds, tails):
+            self.conv_to1_block(final, r_, st, norm, x_, prior[a:e], fx[a:e], out=out[a:e])
+        return out
+
     def gn_lrelu_add2(self, r, st, norm: _Norm, r0, st0, norm0: _Norm, out=None):
         n, spatial = r.shape[0], r[0, 0].numel()
         out = torch.empty_like(r) if out is None else out
@@ -341,10 +428,12 @@ class PlaneSweepEngine:
                    nbytes=4.0 * r.numel() * 3)
         return out
 
-    def conv_to1_block(self, c: _Conv, r, st, norm: _Norm, x, prior=None, fx=None):
+    def conv_to1_block(self, c: _Conv, r, st, norm: _Norm, x, prior=None, fx=None, out=None):
         """conv_to1 on x + LReLU(GN(r)) without materialising it."""
         n, rows, cols = r.shape[0], r.shape[-2], r.shape[-1]
-        out = torch.empty((n, 1, rows, cols), dtype=torch.float32, device=r.device)
+        if out is None:
+            out = torch.empty((n, 1, rows, cols), dtype=torch.float32, device=r.device)
+        assert tuple(out.shape) == (n, 1, rows, cols) and out.is_contiguous()
         self._call("mvsn_conv_to1_block", self.lib.mvsn_conv_to1_block, _native.ptr(r), _native.ptr(st),
                    _native.ptr(norm.gamma), _native.ptr(norm.beta), _native.ptr(x), _native.ptr(c.weight),
                    _native.ptr(c.bias), _native.ptr(prior), _native.ptr(fx), n, rows, cols, _native.ptr(out),
@@ -435,6 +524,13 @@ class PlaneSweepEngine:
         self._call("mvsn_idepth_scale", self.lib.mvsn_idepth_scale, _native.ptr(prior), _native.ptr(fx), n, pixels,
                    _native.ptr(scaled), _native.stream(), nbytes=8.0 * prior.numel())
         x_in = (list(guide) if isinstance(guide, (list, tuple)) else [guide]) + [scaled]
+        rows, cols = prior.shape[-2], prior.shape[-1]
+        if (self.carry_passes and not self.fold_residual_blocks and self.trim_tower_ends and n >= 2 and
+                len(x_in) <= 3 and self.winograd and self.cat_free_heads and len(p["res"]) >= 2 and
+                (n // 2) * 128 * rows * cols >= self.carry_min_bytes and (rows * cols) % 512 == 0 and
+                all(b.dtype == torch.float32 and b.is_contiguous() for b in x_in) and
+                self.lib.mvsn_conv_to1_supported(rows, cols) and p["final"].dilation == 1):
+            return self.residual_tower_sliced(x_in, (p["conv0"], p["bn0"]), p["res"], p["final"], prior, fx)
         if self.fold_residual_blocks or len(x_in) > 3:
             x_in = torch.cat(x_in, 1)       # those towers take one tensor
         if self.fold_residual_blocks:

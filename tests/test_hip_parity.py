@@ -1095,3 +1095,75 @@ def test_forward_ragged_sizes_vs_oracle(rows, cols, S, D):
         assert got.shape == ref["left_idepthmap_pyr"][lvl].shape
         mean_rel, max_rel = rel_err(got, ref["left_idepthmap_pyr"][lvl])
         assert mean_rel < 2e-4 and max_rel < 1e-3, (lvl, mean_rel, max_rel)
+
+
+def _gn_stats(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.stack([torch.randn(n, 4, generator=g) * 0.1, 1.0 + torch.rand(n, 4, generator=g)], -1).contiguous().to(DEV)
+
+
+@pytest.mark.parametrize("block,mode1,add2,n,jn,rows,cols,expect", [
+    (0, False, False, 2, 2, 32, 64, 1),      # dilation 1, plain residual pass, job = the layer's own size
+    (1, False, True, 2, 2, 32, 64, 1),       # dilation 2, the two-raw-tensor form (a refiner's first block)
+    (3, False, False, 3, 2, 48, 64, 1),      # dilation 8 (one k-step per step), job smaller than the capacity
+    (0, True, True, 2, 1, 32, 64, 1),        # carrier applies the previous layer's LReLU(GN(.)) on load
+    (4, False, False, 2, 2, 40, 72, 1),      # partial tiles (40 x 72 pixels = 5.6 units of 512: 2880 % 512 != 0 -> own launch)
+    (2, False, False, 2, 2, 32, 64, 0),      # dilation 4: no room in LDS, the job runs as its own launch
+    (0, False, False, 1, 2, 32, 64, 0),      # job larger than the carrying layer
+    (5, False, False, 5, 5, 16, 32, 1),      # 512-pixel planes: one unit pair per plane
+])
+def test_conv_forward_carry_is_bit_identical(block, mode1, add2, n, jn, rows, cols, expect):
+    """mvsn_conv_forward_carry = mvsn_conv_forward + the stand-alone pass, bit for bit, whether the job travels
+    inside the convolution's launch or not (`carried` says which)."""
+    eng = net_for("gta_sfm_150epochs").engine()
+    lib = eng.lib
+    conv, norm = eng.refiners[0]["res"][block]
+    norm0 = eng.refiners[0]["bn0"]
+    g = torch.Generator().manual_seed(100 + block)
+    x = torch.randn(n, 32, rows, cols, generator=g).to(DEV)
+    jr = torch.randn(jn, 32, rows, cols, generator=g).to(DEV)
+    jres = torch.randn(jn, 32, rows, cols, generator=g).to(DEV)
+    st, st0, ist = _gn_stats(jn, 1), _gn_stats(jn, 2), _gn_stats(n, 3)
+    if (rows * cols) % 512 != 0:
+        expect = 0
+    # reference: the two calls
+    want_out, want_st = eng.conv(conv, x, in_stats=ist if mode1 else None, in_norm=norm0 if mode1 else None, want_stats=True)
+    if add2:
+        want_job = eng.gn_lrelu_add2(jr, st, norm, jres, st0, norm0)
+    else:
+        want_job = eng.gn_lrelu(jr, st, norm, residual=jres)
+    from multi_view_stereonet_amd.multi_view_stereonet import _Job
+    jr2 = jr.clone()
+    job = _Job(jr2, st, norm, jres, st0 if add2 else None, norm0 if add2 else None)     # in place, as the towers use it
+    before = eng.carried_jobs
+    got_out, got_st = eng.conv(conv, x, in_stats=ist if mode1 else None, in_norm=norm0 if mode1 else None,
+                               want_stats=True, carry=job)
+    torch.cuda.synchronize()
+    assert eng.carried_jobs - before == expect
+    assert torch.equal(got_out, want_out) and torch.equal(got_st, want_st)
+    assert torch.equal(jr2, want_job)
+
+
+def test_sliced_refiner_tower_is_bit_identical():
+    """The two-slice software-pipelined refiner tower (carried passes) against the one-batch tower: same kernels per
+    sample, so the same bits -- at an even and an odd batch (odd: one slice's jobs exceed the other's capacity)."""
+    net = net_for("gta_sfm_150epochs")
+    eng = net.engine()
+    g = torch.Generator().manual_seed(5)
+    old = (net.options.carry_passes, net.options.carry_min_bytes)
+    try:
+        for n, lvl, rows, cols in ((4, 0, 64, 128), (3, 1, 32, 64), (2, 2, 48, 64)):
+            img = torch.rand(n, 3, rows, cols, generator=g).to(DEV)
+            guide = [img] if lvl == 0 else [img, torch.randn(n, 32, rows, cols, generator=g).to(DEV)]
+            prior = (0.1 + torch.rand(n, 1, rows, cols, generator=g)).to(DEV)
+            fx = (100.0 + 50.0 * torch.rand(n, generator=g)).to(DEV)
+            net.options.carry_passes = False
+            want = eng.idepth_refiner(lvl, guide, prior, fx)
+            net.options.carry_passes, net.options.carry_min_bytes = True, 0
+            before = eng.carried_jobs
+            got = eng.idepth_refiner(lvl, guide, prior, fx)
+            torch.cuda.synchronize()
+            assert eng.carried_jobs > before, "no pass travelled inside a convolution launch"
+            assert torch.equal(got, want), (n, lvl)
+    finally:
+        net.options.carry_passes, net.options.carry_min_bytes = old
