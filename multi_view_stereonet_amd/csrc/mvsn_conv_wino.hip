@@ -77,6 +77,30 @@ __device__ unsigned long long *g_wn_stamps = nullptr;
 #define WN_STAMP() do { } while (0)
 #endif
 
+// Workgroup barrier that publishes LDS traffic only: __syncthreads() is a release fence and the compiler puts
+// s_waitcnt vmcnt(0) in front of it -- every step would wait for ALL DMA pieces and output stores in flight, and the
+// ring's run-ahead (wait_landed's counts) would never happen.  A wave's own pieces are covered by wait_landed.
+#ifndef MVSN_WN_SYNCTHREADS
+__device__ __forceinline__ void wn_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#else
+__device__ __forceinline__ void wn_barrier() { __syncthreads(); }
+#endif
+
+// One LDS-DMA piece: lane i's 16 bytes at g go to l + 16 i (l wave-uniform).  Issued as inline assembly on purpose: the
+// compiler orders every LDS read behind a __builtin_amdgcn_global_load_lds it has seen with s_waitcnt vmcnt(0) (it cannot
+// tell the ring stage being filled from the one being read), which drains the whole ring once per step.  The waits that
+// matter are wait_landed's counted ones.  (M0 = LDS address; one wait state between the M0 write and the DMA.)
+#ifndef MVSN_WN_BUILTIN_DMA
+__device__ __forceinline__ void wn_dma16(const float *g, const float *l) {
+  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)WN_LPTR(l));
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory", "m0");
+}
+#else
+__device__ __forceinline__ void wn_dma16(const float *g, const float *l) {
+  __builtin_amdgcn_global_load_lds(WN_GPTR(g), WN_LPTR(l), 16, 0, 0);
+}
+#endif
+
 struct WinoDiv {
   unsigned mul, shift;
 };
@@ -181,8 +205,8 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   const int slot = xcd_tile_index(blockIdx.x, G);
 #ifdef MVSN_WN_STAMPS
   unsigned long long *dbg = (blockIdx.x == gridDim.x / 3 && tid == 0) ? g_wn_stamps : nullptr;
-  unsigned long long *dbg_lds =
-      reinterpret_cast<unsigned long long *>(U + (VOL ? NSTAGE * UST : g.nchunks * WN_UFLOATS));
+  unsigned long long *dbg_lds = reinterpret_cast<unsigned long long *>(
+      U + (VOL ? NSTAGE * UST : g.nchunks * WN_UFLOATS) + 32 + (RIDE > 0 ? WN_WAVES * RIDE * 256 : 0));
   int dbg_i = 0;
   bool dbg_on = true;
 #endif
@@ -192,8 +216,13 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   if constexpr (!VOL) {
     const int runs = g.nchunks * (WN_UFLOATS / 256);
     for (int run = wave; run < runs; run += WN_WAVES)
-      __builtin_amdgcn_global_load_lds(WN_GPTR(upk + (size_t)run * 256 + lane * 4), WN_LPTR(U + run * 256), 16, 0, 0);
+      wn_dma16(upk + (size_t)run * 256 + lane * 4, U + run * 256);
   }
+
+  // the bias is read from LDS in the tile epilogue: as a global load its s_waitcnt vmcnt(0) would drain the DMA ring
+  // (which runs ahead into the next tile) once per tile
+  float *bias_lds = U + (VOL ? NSTAGE * UST : g.nchunks * WN_UFLOATS);
+  if (tid < 32) bias_lds[tid] = bias ? bias[tid] : 0.0f;   // published by the first barrier
 
   // ---- prefetcher state: DMA of (item, chunk) steps runs two steps ahead of the multiplies
   // the step's KS * 4 * PIECES pieces are dealt to the 8 waves in order (channel-major); where they do not
@@ -254,7 +283,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       if (i < dpn) {   // uniform
         const float *p = (cok && pf_goff[i] >= 0) ? src + pf_goff[i] : zero;
         if ((dp0 + i) * 64 + lane < GROUPS)   // lanes past the tile's last 16-byte group stay out of the slot
-          __builtin_amdgcn_global_load_lds(WN_GPTR(p), WN_LPTR(dst + (dp0 + i) * 256), 16, 0, 0);
+          wn_dma16(p, dst + (dp0 + i) * 256);
       }
     }
     pf_stage = pf_stage + 1 == NSTAGE ? 0 : pf_stage + 1;
@@ -273,8 +302,8 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       --uq_left;
       const float *src = upk + (size_t)uq_chunk * UST + wave * 512 + lane * 4;
       float *dst = U + uq_stage * UST + wave * 512;
-      __builtin_amdgcn_global_load_lds(WN_GPTR(src), WN_LPTR(dst), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(WN_GPTR(src + 256), WN_LPTR(dst + 256), 16, 0, 0);
+      wn_dma16(src, dst);
+      wn_dma16(src + 256, dst + 256);
       uq_stage = uq_stage + 1 == NSTAGE ? 0 : uq_stage + 1;
       uq_chunk = uq_chunk + 1 == nsteps ? 0 : uq_chunk + 1;
     }
@@ -467,63 +496,71 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   };
 
   // ---- RIDE: the carried job.  A step's RIDE consecutive units (one plane: units per plane % RIDE == 0) are fetched
-  // at its start -- x into registers, the residual by LDS-DMA into the wave's own 1 KB slots behind U (no registers
+  // during it -- x into registers, the residual by LDS-DMA into the wave's own 1 KB slots behind U (no registers
   // held across the multiplies, no other wave reads them: no barrier) -- and normalised / stored at the start of
   // the next step: the only entries of the (in-order) vmcnt queue younger than them are that step's DMA pieces.
+  // Every step fetches and every step consumes (steps without a unit re-read unit 0 and store nothing): with the
+  // use conditional the compiler has to assume loads pending on the other path and drains the queue before it
+  // reuses their registers.
   constexpr int RN = RIDE > 0 ? RIDE : 1;
   floatx4 rd_v[RN];
   float rd_sc = 0.f, rd_sh = 0.f, rd_rsc = 0.f, rd_rsh = 0.f;   // wave-uniform
-  int rd_u = -1;                                                // first unit in flight, -1: none
-  float *rds = U + g.nchunks * WN_UFLOATS + wave * (RN * 256);
-  auto rd_issue = [&](int flat, int chunk) {
+  int rd_u = 0;                                                 // first unit in flight
+  bool rd_ok = false;                                           // ... is one of the job's
+  float *rds = U + g.nchunks * WN_UFLOATS + 32 + wave * (RN * 256);
+  auto rd_issue = [&](int flat, int chunk) {   // flat < 0: nothing to fetch (the set-up's and the last step's)
     if constexpr (RIDE > 0) {
       const int u = ((flat * nsteps + chunk) * WN_WAVES + wave) * RN;
-      if (u < rd.units) {   // uniform
-        rd_u = u;
-        const int pl = wdiv(u, rd.fd_upp), c = pl & 31, n = pl >> 5;
-        const float mean = wn_sload(rd.stats, ((size_t)n * 4 + (c >> 3)) * 2 + 0);
-        const float rstd = wn_sload(rd.stats, ((size_t)n * 4 + (c >> 3)) * 2 + 1);
-        rd_sc = rstd * wn_sload(rd.gamma, c);
-        rd_sh = wn_sload(rd.beta, c) - mean * rd_sc;
-        const size_t off = (size_t)u * 256 + lane * 4;
+      rd_ok = flat >= 0 && u < rd.units;
+      rd_u = rd_ok ? u : 0;
+      const int pl = wdiv(rd_u, rd.fd_upp), c = pl & 31, n = pl >> 5;
+      const float mean = wn_sload(rd.stats, ((size_t)n * 4 + (c >> 3)) * 2 + 0);
+      const float rstd = wn_sload(rd.stats, ((size_t)n * 4 + (c >> 3)) * 2 + 1);
+      rd_sc = rstd * wn_sload(rd.gamma, c);
+      rd_sh = wn_sload(rd.beta, c) - mean * rd_sc;
+      const size_t off = (size_t)rd_u * 256 + lane * 4;
 #pragma unroll
-        for (int j = 0; j < RN; ++j)
-          if (!(MVSN_RD_ABLATE & 1))
-            rd_v[j] = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(rd.x + off + j * 256));
-        if (rd.res && !(MVSN_RD_ABLATE & 4)) {
+      for (int j = 0; j < RN; ++j)
+        if (!(MVSN_RD_ABLATE & 1))
+          rd_v[j] = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(rd.x + off + j * 256));
+      if (rd.res && !(MVSN_RD_ABLATE & 4)) {
 #pragma unroll
-          for (int j = 0; j < RN; ++j)
-            __builtin_amdgcn_global_load_lds(WN_GPTR(rd.res + off + j * 256), WN_LPTR(rds + j * 256), 16, 0, 0);
-        }
-        if (rd.r_stats) {
-          const float rm = wn_sload(rd.r_stats, ((size_t)n * 4 + (c >> 3)) * 2 + 0);
-          rd_rsc = wn_sload(rd.r_stats, ((size_t)n * 4 + (c >> 3)) * 2 + 1) * wn_sload(rd.r_gamma, c);
-          rd_rsh = wn_sload(rd.r_beta, c) - rm * rd_rsc;
-        }
+        for (int j = 0; j < RN; ++j) wn_dma16(rd.res + off + j * 256, rds + j * 256);
+      }
+      if (rd.r_stats) {
+        const float rm = wn_sload(rd.r_stats, ((size_t)n * 4 + (c >> 3)) * 2 + 0);
+        rd_rsc = wn_sload(rd.r_stats, ((size_t)n * 4 + (c >> 3)) * 2 + 1) * wn_sload(rd.r_gamma, c);
+        rd_rsh = wn_sload(rd.r_beta, c) - rm * rd_rsc;
       }
     }
   };
   auto rd_consume = [&]() {
     if constexpr (RIDE > 0) {
+      // all arithmetic first, then the stores: a store in flight next to a load still awaited makes the compiler
+      // drain the queue (it treats mixed loads / stores as unordered) -- the store's whole latency, every step
+      floatx4 o[RN];
 #pragma unroll
       for (int j = 0; j < RN; ++j) {
+        if (MVSN_RD_ABLATE & 16) asm volatile("" ::"v"(rd_v[j]));   // loads kept, nothing done with them
         if (MVSN_RD_ABLATE & 2) continue;
-        floatx4 o;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = lrelu02(rd_v[j][k] * rd_sc + rd_sh);
+        for (int k = 0; k < 4; ++k) o[j][k] = lrelu02(rd_v[j][k] * rd_sc + rd_sh);
         if (rd.res) {
           const floatx4 r = *reinterpret_cast<const floatx4 *>(rds + j * 256 + lane * 4);
           if (rd.r_stats) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] += lrelu02(r[k] * rd_rsc + rd_rsh);
+            for (int k = 0; k < 4; ++k) o[j][k] += lrelu02(r[k] * rd_rsc + rd_rsh);
           } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] += r[k];
+            for (int k = 0; k < 4; ++k) o[j][k] += r[k];
           }
         }
-        __builtin_nontemporal_store(o, reinterpret_cast<floatx4 *>(rd.out + (size_t)rd_u * 256 + j * 256 + lane * 4));
       }
-      rd_u = -1;
+      if (rd_ok && !(MVSN_RD_ABLATE & 2)) {   // uniform
+#pragma unroll
+        for (int j = 0; j < RN; ++j)
+          __builtin_nontemporal_store(o[j], reinterpret_cast<floatx4 *>(rd.out + (size_t)rd_u * 256 + j * 256 + lane * 4));
+      }
     }
   };
 
@@ -534,11 +571,12 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     wait_landed(total_steps - 1 < NSTAGE - 1 ? total_steps - 1 : NSTAGE - 1);
     xf_apply();        // step 0
     xf_prepare();      // step 1
-    __syncthreads();   // step 0 (and U) visible to everyone
+    wn_barrier();      // step 0 (and U) visible to everyone
     float d0[KS][4][4];
     tr_load(d0);
     tr_finish(d0, v);
     tr_advance();
+    rd_issue(-1, 0);
   }
 
   // ---- a finished tile: output transform, bias, stores, GroupNorm partials
@@ -563,7 +601,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     float y[2][2][8];   // [t][row][group * 4 + slot]
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const float bv = bias ? bias[t * 16 + cl] : 0.0f;
+      const float bv = bias_lds[t * 16 + cl];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float s0[4], s1[4];
@@ -669,13 +707,12 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       const bool has_next = step + 1 < total_steps;   // uniform
       bool waited = false;
       if constexpr (RIDE > 0) {
-        if (rd_u >= 0) {   // uniform.  Everything up to the carried loads has landed once only the previous step's
-          // DMA pieces are outstanding -- which covers step + 1 (issued NSTAGE - 1 >= 2 steps ago) as well.
-          if (pf_did) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PERV) : "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          rd_consume();
-          waited = true;
-        }
+        // Everything up to the carried loads has landed once only the previous step's DMA pieces are outstanding --
+        // which covers step + 1 (issued NSTAGE - 1 >= 2 steps ago) as well.
+        if (pf_did) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PERV) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        rd_consume();
+        waited = true;
         pf_did = false;
       }
       if (has_next) {
@@ -683,7 +720,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         if (!waited) wait_landed(rest < 0 ? 0 : (rest < NSTAGE - 2 ? rest : NSTAGE - 2));   // step + 1 has landed
         xf_apply();        // step + 1
         WN_STAMP();   // landed
-        if (!(MVSN_WN_ABLATE & 8)) __syncthreads();   // ... for everyone; everyone has read the raw tile of `step`
+        if (!(MVSN_WN_ABLATE & 8)) wn_barrier();   // ... for everyone; everyone has read the raw tile of `step`
         WN_STAMP();   // barrier
         xf_prepare();      // step + 2: its scalar loads travel behind this step's multiplies
       }
@@ -751,7 +788,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     if (!(MVSN_WN_ABLATE & 16) || n < 0) finish_tile(n, z, tile_id, y0, x0);
   }
   if constexpr (RIDE > 0) {
-    if (rd_u >= 0) {   // the last step's units
+    if (total_steps > 0) {   // the last step's units
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       rd_consume();
     }
@@ -801,8 +838,9 @@ int wino_pack(const mvsn_conv_desc *d, const float *weight, float *packed, hipSt
 // RIDE units per wave and step of the instantiation a layer runs on (0: that kernel carries nothing)
 static int wino_ride_units(const WinoGeom &g) {
   if (g.vol || g.nchunks != 8) return 0;
-  if (g.dil == 4) return 0;    // 94 KB of raw ring + 64 KB of U: no room for the residual slots
-  return g.dil == 8 ? 1 : 2;   // 8 steps of one k-step / 4 steps of two: 64 units = 64 KB per tile either way
+  // 4 steps of two k-steps / 8 steps of one: 64 units = 64 KB per tile either way.  Dilation 4 carries on the
+  // one-k-step form (its two-k-step ring, 94 KB next to 64 KB of U, leaves no room for the residual slots).
+  return g.dil >= 4 ? 1 : 2;
 }
 
 bool wino_can_carry(const WinoGeom &g, const mvsn_apply_job *job) {
@@ -812,7 +850,7 @@ bool wino_can_carry(const WinoGeom &g, const mvsn_apply_job *job) {
   if (job->r_stats && !(job->residual && job->r_gamma && job->r_beta)) return false;
   if ((((size_t)job->x | (size_t)job->out | (size_t)job->residual) & 15) != 0) return false;
   const long units = (long)job->n * 32 * (job->spatial / 256);
-  const int nsteps = g.dil == 8 ? 8 : 4;
+  const int nsteps = g.dil >= 4 ? 8 : 4;
   return units <= (long)g.n * g.tiles * nsteps * WN_WAVES * r && units < (1L << 30);
 }
 
@@ -842,11 +880,12 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   //   dilation 1: 2 k-steps x 4 stages (94 KB); 2, 4: 2 x 3 (78 / 94 KB); 8: 1 x 3 (74 KB); 4-channel head: 1 x 6
   //   volume form: 2 x 3 raw stages + 3 stages of U (118 KB)
   const bool head = g.nchunks == 1;
-  const int ks = (head || g.dil == 8) ? 1 : 2;
+  const int ks = (head || g.dil == 8 || (job && g.dil == 4)) ? 1 : 2;
   // (a carrying launch waits with one step of DMA in flight, see RideArgs: a fourth stage would never be used)
   const int nstage = head ? 6 : ((g.dil == 1 && g.nchunks <= 8 && !job) ? 4 : 3);
   size_t lds = ((size_t)nstage * ks * 4 * wn_rcst(g.dil) +
                 (g.vol ? (size_t)nstage * ks : (size_t)g.nchunks) * WN_UFLOATS) * sizeof(float);
+  lds += 32 * sizeof(float);                                      // bias
   if (job) lds += (size_t)WN_WAVES * wino_ride_units(g) * 1024;   // the carried job's residual slots
 #ifdef MVSN_WN_STAMPS
   lds += 1024;   // stamp area
@@ -876,6 +915,7 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   if (job) {   // the same kernels with the carried job's loads / stores in their steps
     if (g.dil == 1) { if (xf) WN_CASE(1, 2, 3, 1, false, 2); else WN_CASE(0, 2, 3, 1, false, 2); }
     else if (g.dil == 2) { if (xf) WN_CASE(1, 2, 3, 2, false, 2); else WN_CASE(0, 2, 3, 2, false, 2); }
+    else if (g.dil == 4) { if (xf) WN_CASE(1, 1, 3, 4, false, 1); else WN_CASE(0, 1, 3, 4, false, 1); }
     else { if (xf) WN_CASE(1, 1, 3, 8, false, 1); else WN_CASE(0, 1, 3, 8, false, 1); }
   } else
   if (g.vol) { if (xf) WN_CASE(1, 2, 3, 1, true); else WN_CASE(0, 2, 3, 1, true); }

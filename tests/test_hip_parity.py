@@ -1108,7 +1108,7 @@ def _gn_stats(n, seed):
     (3, False, False, 3, 2, 48, 64, 1),      # dilation 8 (one k-step per step), job smaller than the capacity
     (0, True, True, 2, 1, 32, 64, 1),        # carrier applies the previous layer's LReLU(GN(.)) on load
     (4, False, False, 2, 2, 40, 72, 1),      # partial tiles (40 x 72 pixels = 5.6 units of 512: 2880 % 512 != 0 -> own launch)
-    (2, False, False, 2, 2, 32, 64, 0),      # dilation 4: no room in LDS, the job runs as its own launch
+    (2, False, False, 2, 2, 32, 64, 1),      # dilation 4: carried by the one-k-step form of the layer
     (0, False, False, 1, 2, 32, 64, 0),      # job larger than the carrying layer
     (5, False, False, 5, 5, 16, 32, 1),      # 512-pixel planes: one unit pair per plane
 ])
