@@ -346,7 +346,7 @@ def main():
             # dom["flops"] counts the layer in its direct form (2 * cin * taps * cout per output).  The Winograd
             # kernels execute 16 multiplies per 2x2 outputs and tap plane instead of 36 (x 4/9): the roofline is
             # priced on the flops the matrix pipe actually executes, the direct-form figure is reported beside it.
-            wino = name.endswith(" wino]")
+            wino = " wino" in name
             direct_tfl = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12
             tfl = direct_tfl * (4.0 / 9.0 if wino else 1.0)
             traffic = None
@@ -361,6 +361,11 @@ def main():
                                 "unit": "TFLOP/s", "frac": tfl / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                                 "launches_per_step": dom["launches"], "avg_launch_ms": per_launch_ms,
                                 "share_of_step": dom["ms"] / total_ms}
+            if "+pass" in name:
+                line["roofline"]["carried_pass"] = ("each of these launches also executes the in-place LeakyReLU(GroupNorm(.)) "
+                                                    "pass of the other batch slice's previous layer (mvsn_conv_forward_carry): "
+                                                    "its loads / stores are part of the launch time and of `traffic`, "
+                                                    "`achieved` counts the convolution's flops only")
             if wino:
                 line["roofline"]["form"] = ("Winograd F(2x2,3x3) per depth tap: 12 multiplies per output and "
                                             "(cin, cout) pair instead of 27; achieved = executed MFMA flops")

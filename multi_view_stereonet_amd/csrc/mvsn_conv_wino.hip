@@ -240,7 +240,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   int pf_goff[PER];
   int pf_n = 0, pf_z = 0;
   bool pf_live = slot < total;
-  bool pf_did = false;   // RIDE: the previous step issued its DMA pieces
+  int rd_young = 0;   // RIDE: DMA pieces this wave has issued since its carried loads
   auto pf_plan = [&]() {   // DMA plan of the prefetcher's current item
     const int flat = pf_round * G + slot;
     const int n = flat / ptiles;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   };
   auto pf_issue = [&]() {   // issue the DMA of the prefetcher's step and advance it
     if (!pf_live) return;
-    pf_did = true;
+    rd_young += PER;
     bool cok;
     const float *src;
     if constexpr (VOL) {   // step = (depth tap, 8 channels): plane pf_z + kz - 1 of channel c, zeros outside the volume
@@ -300,6 +300,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     if constexpr (VOL) {
       if (uq_left <= 0) return;
       --uq_left;
+      rd_young += 2;
       const float *src = upk + (size_t)uq_chunk * UST + wave * 512 + lane * 4;
       float *dst = U + uq_stage * UST + wave * 512;
       wn_dma16(src, dst);
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   // (vmcnt retires in order; waves 0-3 issue two pieces per step, waves 4-7 one)
   constexpr int PERV = PER + (VOL ? 2 : 0);   // + the step's two U pieces
   static_assert(!VOL || EVEN, "volume form: every wave issues the same number of pieces");
-  static_assert(RIDE == 0 || (!VOL && EVEN), "carried jobs: 2-D layers with an even DMA split");
+  static_assert(RIDE == 0 || EVEN, "carried jobs: layers with an even DMA split");
   auto wait_landed = [&](int younger) {
 #define WN_WAIT_CASE(K)                                                              \
   case K:                                                                            \
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   float rd_sc = 0.f, rd_sh = 0.f, rd_rsc = 0.f, rd_rsh = 0.f;   // wave-uniform
   int rd_u = 0;                                                 // first unit in flight
   bool rd_ok = false;                                           // ... is one of the job's
-  float *rds = U + g.nchunks * WN_UFLOATS + 32 + wave * (RN * 256);
+  float *rds = U + (VOL ? NSTAGE * UST : g.nchunks * WN_UFLOATS) + 32 + wave * (RN * 256);
   auto rd_issue = [&](int flat, int chunk) {   // flat < 0: nothing to fetch (the set-up's and the last step's)
     if constexpr (RIDE > 0) {
       const int u = ((flat * nsteps + chunk) * WN_WAVES + wave) * RN;
@@ -519,6 +520,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       rd_sc = rstd * wn_sload(rd.gamma, c);
       rd_sh = wn_sload(rd.beta, c) - mean * rd_sc;
       const size_t off = (size_t)rd_u * 256 + lane * 4;
+      rd_young = 0;
 #pragma unroll
       for (int j = 0; j < RN; ++j)
         if (!(MVSN_RD_ABLATE & 1))
@@ -709,11 +711,12 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       if constexpr (RIDE > 0) {
         // Everything up to the carried loads has landed once only the previous step's DMA pieces are outstanding --
         // which covers step + 1 (issued NSTAGE - 1 >= 2 steps ago) as well.
-        if (pf_did) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PERV) : "memory");
+        if (rd_young == PERV) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PERV) : "memory");
+        else if (rd_young == PER) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+        else if (VOL && rd_young == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         rd_consume();
         waited = true;
-        pf_did = false;
       }
       if (has_next) {
         const int rest = total_steps - (step + 2);     // steps issued after step + 1 so far
@@ -837,7 +840,8 @@ int wino_pack(const mvsn_conv_desc *d, const float *weight, float *packed, hipSt
 
 // RIDE units per wave and step of the instantiation a layer runs on (0: that kernel carries nothing)
 static int wino_ride_units(const WinoGeom &g) {
-  if (g.vol || g.nchunks != 8) return 0;
+  if (g.vol) return 1;         // 12 steps per (plane, tile): 96 units, of which a job of the layer's own size needs 64
+  if (g.nchunks != 8) return 0;
   // 4 steps of two k-steps / 8 steps of one: 64 units = 64 KB per tile either way.  Dilation 4 carries on the
   // one-k-step form (its two-k-step ring, 94 KB next to 64 KB of U, leaves no room for the residual slots).
   return g.dil >= 4 ? 1 : 2;
@@ -850,8 +854,9 @@ bool wino_can_carry(const WinoGeom &g, const mvsn_apply_job *job) {
   if (job->r_stats && !(job->residual && job->r_gamma && job->r_beta)) return false;
   if ((((size_t)job->x | (size_t)job->out | (size_t)job->residual) & 15) != 0) return false;
   const long units = (long)job->n * 32 * (job->spatial / 256);
-  const int nsteps = g.dil >= 4 ? 8 : 4;
-  return units <= (long)g.n * g.tiles * nsteps * WN_WAVES * r && units < (1L << 30);
+  if (g.vol && job->residual) return false;   // (no residual slots next to the volume form's two rings)
+  const int nsteps = g.vol ? 12 : (g.dil >= 4 ? 8 : 4);
+  return units <= (long)g.n * g.D * g.tiles * nsteps * WN_WAVES * r && units < (1L << 30);
 }
 
 int wino_launch(const WinoGeom &g, const float *in, const float *upk, const float *bias, const float *in_stats,
@@ -886,7 +891,7 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   size_t lds = ((size_t)nstage * ks * 4 * wn_rcst(g.dil) +
                 (g.vol ? (size_t)nstage * ks : (size_t)g.nchunks) * WN_UFLOATS) * sizeof(float);
   lds += 32 * sizeof(float);                                      // bias
-  if (job) lds += (size_t)WN_WAVES * wino_ride_units(g) * 1024;   // the carried job's residual slots
+  if (job && !g.vol) lds += (size_t)WN_WAVES * wino_ride_units(g) * 1024;   // the carried job's residual slots
 #ifdef MVSN_WN_STAMPS
   lds += 1024;   // stamp area
 #endif
@@ -913,7 +918,8 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   grid = dim3((unsigned)(total < cus ? total : cus));   // persistent: one workgroup per CU walks items grid-strided
   const bool xf = in_stats != nullptr;
   if (job) {   // the same kernels with the carried job's loads / stores in their steps
-    if (g.dil == 1) { if (xf) WN_CASE(1, 2, 3, 1, false, 2); else WN_CASE(0, 2, 3, 1, false, 2); }
+    if (g.vol) { if (xf) WN_CASE(1, 2, 3, 1, true, 1); else WN_CASE(0, 2, 3, 1, true, 1); }
+    else if (g.dil == 1) { if (xf) WN_CASE(1, 2, 3, 1, false, 2); else WN_CASE(0, 2, 3, 1, false, 2); }
     else if (g.dil == 2) { if (xf) WN_CASE(1, 2, 3, 2, false, 2); else WN_CASE(0, 2, 3, 2, false, 2); }
     else if (g.dil == 4) { if (xf) WN_CASE(1, 1, 3, 4, false, 1); else WN_CASE(0, 1, 3, 4, false, 1); }
     else { if (xf) WN_CASE(1, 1, 3, 8, false, 1); else WN_CASE(0, 1, 3, 8, false, 1); }

@@ -115,8 +115,11 @@ class EngineOptions:
         # where a slice's activation tensor has at least `carry_min_bytes` bytes (small levels are launch-bound).
         self.carry_passes = True
         self.carry_min_bytes = 32 << 20
+        # ... the regulariser's three in-place passes the same way: measured +0.1-0.2 ms per 38.6 ms step only (a pass
+        # costs the volume kernel about what it costs alone), so the regulariser stays one batch by default
+        self.carry_volume_passes = False
 
-    NAMES = ("carry_passes", "carry_min_bytes", "chain_form", "fold_residual_blocks", "conv_precision", "winograd", "winograd_with_input_transform",
+    NAMES = ("carry_passes", "carry_min_bytes", "carry_volume_passes", "chain_form", "fold_residual_blocks", "conv_precision", "winograd", "winograd_with_input_transform",
              "winograd_volume", "volume_materialise", "trim_tower_ends", "cat_free_heads")
 
 
@@ -158,6 +161,7 @@ class PlaneSweepEngine:
     def __init__(self, net: "MultiViewStereoNet"):
         self.lib = lib = _native.load()
         self.carried_jobs = 0          # normalise/activate/add passes that travelled inside a convolution launch
+        self._carried_before = {}
         # tuning switches live on the module (EngineOptions), so they survive every rebuild of this object
         # (.to(), load_state_dict, in-place parameter updates); `engine.<switch>` reads and writes through
         object.__setattr__(self, "opt", net.options)
@@ -265,13 +269,17 @@ class PlaneSweepEngine:
         if carry is not None:
             assert in_residual is None and not write_staged
             carried = ctypes.c_int(0)
-            self._call("mvsn_conv_forward_carry[" + tag + "]", lib.mvsn_conv_forward_carry, ctypes.byref(d),
+            # (timeline label: whether the pass travels inside the launch is decided by the library from the same
+            # shapes every step, so last step's answer names this one)
+            went = self._carried_before.get(tag, True)
+            self._call("mvsn_conv_forward[" + tag + (" +pass]" if went else "] + pass"), lib.mvsn_conv_forward_carry, ctypes.byref(d),
                        _native.ptr(x), _native.ptr(packed), _native.ptr(c.bias), _native.ptr(in_stats),
                        _native.ptr(in_norm.gamma) if in_norm else None, _native.ptr(in_norm.beta) if in_norm else None,
                        _native.ptr(out), _native.ptr(partials), ctypes.byref(carry.job), ctypes.byref(carried),
                        _native.stream(), flops=2.0 * c.cin * taps * c.cout * out[:, 0].numel(),
                        nbytes=nbytes + carry.nbytes)
             self.carried_jobs += carried.value
+            self._carried_before[tag] = bool(carried.value)
         else:
             self._call("mvsn_conv_forward[" + tag + "]", lib.mvsn_conv_forward, ctypes.byref(d), _native.ptr(x),
                        _native.ptr(packed), _native.ptr(c.bias), _native.ptr(in_stats),
@@ -491,6 +499,12 @@ class PlaneSweepEngine:
         return pyr
 
     def cost_volume_filter(self, cost: torch.Tensor) -> torch.Tensor:
+        n, _, depth, rows, cols = cost.shape
+        to1 = bool(self.lib.mvsn_conv_to1_supported(rows, cols))
+        if (self.carry_passes and self.carry_volume_passes and self.volume_materialise and self.winograd and self.winograd_volume and
+                self.conv_precision == "fp32" and to1 and n >= 2 and (depth * rows * cols) % 256 == 0 and
+                (n // 2) * 128 * depth * rows * cols >= self.carry_min_bytes):
+            return self.cost_volume_filter_sliced(cost)
         x, st = self.conv(self.vf_convs[0], cost, want_stats=True)
         for i in range(1, 4):
             if self.volume_materialise and self.winograd and self.winograd_volume and self.conv_precision == "fp32":
@@ -501,18 +515,42 @@ class PlaneSweepEngine:
             else:
                 x, st = self.conv(self.vf_convs[i], x, in_stats=st, in_norm=self.vf_norms[i - 1], want_stats=True)
         last = self.vf_convs[4]
-        if self.lib.mvsn_conv_to1_supported(x.shape[-2], x.shape[-1]):
-            # the HBM-bound 32 -> 1 pass applies LReLU(GN(.)) of the fourth layer while it loads the raw volume
-            n, _, depth, rows, cols = x.shape
-            out = torch.empty((n, depth, rows, cols), dtype=torch.float32, device=x.device)
-            nrm = self.vf_norms[3]
-            self._call("mvsn_conv_to1_volume_norm", self.lib.mvsn_conv_to1_volume_norm, _native.ptr(x), _native.ptr(st),
-                       _native.ptr(nrm.gamma), _native.ptr(nrm.beta), _native.ptr(last.weight), _native.ptr(last.bias),
-                       n, depth, rows, cols, _native.ptr(out), _native.stream(),
-                       flops=2.0 * 32 * 27 * out.numel(), nbytes=4.0 * (x.numel() + out.numel()))
-            return out
+        if to1:
+            return self.conv_to1_volume_norm(last, x, st, self.vf_norms[3])
         out, _ = self.conv(last, x, in_stats=st, in_norm=self.vf_norms[3])
         return out[:, 0]
+
+    def conv_to1_volume_norm(self, last: _Conv, x, st, nrm: _Norm, out=None):
+        """The HBM-bound 32 -> 1 pass; applies LReLU(GN(.)) of the fourth layer while it loads the raw volume."""
+        n, _, depth, rows, cols = x.shape
+        if out is None:
+            out = torch.empty((n, depth, rows, cols), dtype=torch.float32, device=x.device)
+        self._call("mvsn_conv_to1_volume_norm", self.lib.mvsn_conv_to1_volume_norm, _native.ptr(x), _native.ptr(st),
+                   _native.ptr(nrm.gamma), _native.ptr(nrm.beta), _native.ptr(last.weight), _native.ptr(last.bias),
+                   n, depth, rows, cols, _native.ptr(out), _native.stream(),
+                   flops=2.0 * 32 * 27 * out.numel(), nbytes=4.0 * (x.numel() + out.numel()))
+        return out
+
+    def cost_volume_filter_sliced(self, cost: torch.Tensor) -> torch.Tensor:
+        """The regulariser on two slices of the chains, pipelined like residual_tower_sliced: the in-place
+        LReLU(GN(.)) pass of one slice's layer travels inside the other slice's next convolution launch
+            c0(A) c0(B)+p0(A) c1(A)+p0(B) c1(B)+p1(A) c2(A)+p1(B) c2(B)+p2(A) c3(A)+p2(B) c3(B) tail(A) tail(B)."""
+        n, _, depth, rows, cols = cost.shape
+        h = (n + 1) // 2
+        bounds = ((0, h), (h, n))
+        x = [cost[a:e] for a, e in bounds]
+        job = None
+        stats = [None, None]
+        for i in range(4):
+            r = torch.empty((n, 32, depth, rows, cols), dtype=torch.float32, device=cost.device)
+            for s_, (a, e) in enumerate(bounds):
+                _, stats[s_] = self.conv(self.vf_convs[i], x[s_], want_stats=True, carry=job, out=r[a:e])
+                job = _Job(r[a:e], stats[s_], self.vf_norms[i]) if i < 3 else None
+                x[s_] = r[a:e]
+        out = torch.empty((n, depth, rows, cols), dtype=torch.float32, device=cost.device)
+        for s_, (a, e) in enumerate(bounds):
+            self.conv_to1_volume_norm(self.vf_convs[4], x[s_], stats[s_], self.vf_norms[3], out=out[a:e])
+        return out
 
     def idepth_refiner(self, level: int, guide, prior: torch.Tensor, fx: torch.Tensor) -> torch.Tensor:
         """`guide` is a tensor or a list of channel blocks (image, features): the refiner input

@@ -1167,3 +1167,46 @@ def test_sliced_refiner_tower_is_bit_identical():
             assert torch.equal(got, want), (n, lvl)
     finally:
         net.options.carry_passes, net.options.carry_min_bytes = old
+
+
+@pytest.mark.parametrize("mode1,n,jn,depth,rows,cols,expect", [(False, 2, 2, 8, 16, 32, 1), (True, 2, 2, 5, 16, 32, 1),
+                                                                (False, 3, 2, 4, 12, 24, 0),     # 4*12*24 % 256 != 0
+                                                                (False, 2, 2, 6, 32, 64, 1)])
+def test_conv3d_forward_carry_is_bit_identical(mode1, n, jn, depth, rows, cols, expect):
+    """The volume form (3x3x3 regulariser layer) carrying an in-place LReLU(GN(.)) pass over another volume."""
+    from multi_view_stereonet_amd.multi_view_stereonet import _Job
+    eng = net_for("gta_sfm_150epochs").engine()
+    conv, norm = eng.vf_convs[1], eng.vf_norms[0]
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(n, 32, depth, rows, cols, generator=g).to(DEV)
+    jr = torch.randn(jn, 32, depth, rows, cols, generator=g).to(DEV)
+    st, ist = _gn_stats(jn, 4), _gn_stats(n, 5)
+    kw = dict(in_stats=ist, in_norm=norm) if mode1 else {}
+    want_out, want_st = eng.conv(conv, x, want_stats=True, **kw)
+    want_job = eng.gn_lrelu(jr, st, norm)
+    jr2 = jr.clone()
+    before = eng.carried_jobs
+    got_out, got_st = eng.conv(conv, x, want_stats=True, carry=_Job(jr2, st, norm), **kw)
+    torch.cuda.synchronize()
+    assert eng.carried_jobs - before == expect
+    assert torch.equal(got_out, want_out) and torch.equal(got_st, want_st) and torch.equal(jr2, want_job)
+
+
+def test_sliced_regulariser_is_bit_identical():
+    net = net_for("gta_sfm_150epochs")
+    eng = net.engine()
+    g = torch.Generator().manual_seed(6)
+    old = (net.options.carry_passes, net.options.carry_min_bytes, net.options.carry_volume_passes)
+    try:
+        net.options.carry_volume_passes = True
+        for n, depth in ((4, 8), (3, 16)):
+            cost = torch.rand(n, 32, depth, 16, 32, generator=g).to(DEV)
+            net.options.carry_passes = False
+            want = eng.cost_volume_filter(cost)
+            net.options.carry_passes, net.options.carry_min_bytes = True, 0
+            before = eng.carried_jobs
+            got = eng.cost_volume_filter(cost)
+            torch.cuda.synchronize()
+            assert eng.carried_jobs > before and torch.equal(got, want), (n, depth)
+    finally:
+        net.options.carry_passes, net.options.carry_min_bytes, net.options.carry_volume_passes = old

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""End-to-end forward (512x256, 64 hypotheses, 2 sources, batch 128) against engine options: which refiner levels
+run as two pipelined slices with carried passes (`carry_min_bytes`)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multi_view_stereonet_amd import MultiViewStereoNet, synthetic
+from multi_view_stereonet_amd import multi_view_stereonet_utils as snu
+from multi_view_stereonet_amd.weights import load_weights
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+net = MultiViewStereoNet(); net.load_state_dict(load_weights("gta_sfm_150epochs")); net = net.cuda().eval()
+batch = synthetic.make_batch(256, 512, 2, batch=B, seed=1)
+inp = snu.multi_view_unpack_batch(batch, torch.device("cuda"), 5)
+args = (inp["left_image_pyr"], inp["K_pyr"], inp["T_right_in_left"], inp["right_image_pyr"], 64, True, [True] * 5)
+
+
+def run(it=8):
+    for _ in range(3): net(*args)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(it): net(*args)
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / it
+
+
+cases = [("off", dict(carry_passes=False)), ("0-2 novol", dict(carry_min_bytes=64 << 20, carry_volume_passes=False)),
+         ("0-2 vol", dict(carry_min_bytes=64 << 20, carry_volume_passes=True)),
+         ("vol only", dict(carry_min_bytes=300 << 20, carry_volume_passes=True)),
+         ("0-3 vol", dict(carry_min_bytes=16 << 20, carry_volume_passes=True))]
+for rep in range(2):
+    for name, opts in cases:
+        net.options.carry_passes = True
+        for k, v in opts.items(): setattr(net.options, k, v)
+        ms = run()
+        print(f"{name:8s} {ms:7.3f} ms  {B / ms * 1e3:7.1f} /s", flush=True)
