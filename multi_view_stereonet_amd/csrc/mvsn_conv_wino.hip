@@ -77,29 +77,33 @@ __device__ unsigned long long *g_wn_stamps = nullptr;
 #define WN_STAMP() do { } while (0)
 #endif
 
-// Workgroup barrier that publishes LDS traffic only: __syncthreads() is a release fence and the compiler puts
-// s_waitcnt vmcnt(0) in front of it -- every step would wait for ALL DMA pieces and output stores in flight, and the
-// ring's run-ahead (wait_landed's counts) would never happen.  A wave's own pieces are covered by wait_landed.
-#ifndef MVSN_WN_SYNCTHREADS
-__device__ __forceinline__ void wn_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#else
-__device__ __forceinline__ void wn_barrier() { __syncthreads(); }
-#endif
+// Workgroup barrier that publishes LDS traffic only (LDSONLY): __syncthreads() is a release fence and the compiler puts
+// s_waitcnt vmcnt(0) in front of it -- every step waits for ALL DMA pieces and output stores in flight.  A wave's own
+// pieces are covered by wait_landed.  (With the builtin DMA below the compiler moves that drain behind the barrier
+// instead; measured per instantiation, see conv_wino_kernel.)
+template <bool LDSONLY>
+__device__ __forceinline__ void wn_barrier() {
+  if constexpr (LDSONLY) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else __syncthreads();
+}
 
-// One LDS-DMA piece: lane i's 16 bytes at g go to l + 16 i (l wave-uniform).  Issued as inline assembly on purpose: the
-// compiler orders every LDS read behind a __builtin_amdgcn_global_load_lds it has seen with s_waitcnt vmcnt(0) (it cannot
-// tell the ring stage being filled from the one being read), which drains the whole ring once per step.  The waits that
-// matter are wait_landed's counted ones.  (M0 = LDS address; one wait state between the M0 write and the DMA.)
-#ifndef MVSN_WN_BUILTIN_DMA
+// One LDS-DMA piece: lane i's 16 bytes at g go to l + 16 i (l wave-uniform).  ASM: issued as inline assembly -- the
+// compiler orders every LDS read behind a __builtin_amdgcn_global_load_lds it has seen with s_waitcnt vmcnt(0) (it
+// cannot tell the ring stage being filled from the one being read); in the kernels that carry a pass this drain sits
+// right behind the pass's freshly issued loads and exposes their whole latency every step.  The waits that matter are
+// wait_landed's counted ones.  (M0 = LDS address; one wait state between the M0 write and the DMA.)  The builtin form
+// schedules better where the drain is harmless (measured on MI355X, level-0 layer of 64 images: plain dilation-1
+// layer 0.79 ms builtin / 0.81 asm; the same layer carrying a pass 1.14 / 1.06, with the input transform 1.29 / 1.18;
+// dilation 2, 4, 8 within 1 % either way).
+template <bool ASM>
 __device__ __forceinline__ void wn_dma16(const float *g, const float *l) {
-  const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)WN_LPTR(l));
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory", "m0");
+  if constexpr (ASM) {
+    const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)WN_LPTR(l));
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory", "m0");
+  } else {
+    __builtin_amdgcn_global_load_lds(WN_GPTR(g), WN_LPTR(l), 16, 0, 0);
+  }
 }
-#else
-__device__ __forceinline__ void wn_dma16(const float *g, const float *l) {
-  __builtin_amdgcn_global_load_lds(WN_GPTR(g), WN_LPTR(l), 16, 0, 0);
-}
-#endif
 
 struct WinoDiv {
   unsigned mul, shift;
@@ -182,6 +186,16 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
                                                                   float *__restrict__ out,
                                                                   float *__restrict__ out_partials, RideArgs rd) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef MVSN_WN_FORCE_DMA   // tuning aid: 0 builtin everywhere, 1 inline assembly everywhere
+  constexpr bool ASM_DMA = MVSN_WN_FORCE_DMA;
+#else
+  constexpr bool ASM_DMA = RIDE > 0 && DIL == 1;   // see wn_dma16
+#endif
+#ifdef MVSN_WN_FORCE_BARRIER
+  constexpr bool LDS_BARRIER = MVSN_WN_FORCE_BARRIER;
+#else
+  constexpr bool LDS_BARRIER = !VOL;               // see wn_barrier
+#endif
   constexpr int PA = wn_pa(DIL), XS = wn_xs(DIL), DQ = XS / 4, GROUPS = wn_groups(DIL), PIECES = wn_pieces(DIL);
   constexpr int RCST = wn_rcst(DIL);
   constexpr int STAGE = KS * 4 * RCST;               // ring stage (floats)
@@ -216,7 +230,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   if constexpr (!VOL) {
     const int runs = g.nchunks * (WN_UFLOATS / 256);
     for (int run = wave; run < runs; run += WN_WAVES)
-      wn_dma16(upk + (size_t)run * 256 + lane * 4, U + run * 256);
+      wn_dma16<ASM_DMA>(upk + (size_t)run * 256 + lane * 4, U + run * 256);
   }
 
   // the bias is read from LDS in the tile epilogue: as a global load its s_waitcnt vmcnt(0) would drain the DMA ring
@@ -283,7 +297,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       if (i < dpn) {   // uniform
         const float *p = (cok && pf_goff[i] >= 0) ? src + pf_goff[i] : zero;
         if ((dp0 + i) * 64 + lane < GROUPS)   // lanes past the tile's last 16-byte group stay out of the slot
-          wn_dma16(p, dst + (dp0 + i) * 256);
+          wn_dma16<ASM_DMA>(p, dst + (dp0 + i) * 256);
       }
     }
     pf_stage = pf_stage + 1 == NSTAGE ? 0 : pf_stage + 1;
@@ -303,8 +317,8 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       rd_young += 2;
       const float *src = upk + (size_t)uq_chunk * UST + wave * 512 + lane * 4;
       float *dst = U + uq_stage * UST + wave * 512;
-      wn_dma16(src, dst);
-      wn_dma16(src + 256, dst + 256);
+      wn_dma16<ASM_DMA>(src, dst);
+      wn_dma16<ASM_DMA>(src + 256, dst + 256);
       uq_stage = uq_stage + 1 == NSTAGE ? 0 : uq_stage + 1;
       uq_chunk = uq_chunk + 1 == nsteps ? 0 : uq_chunk + 1;
     }
@@ -527,7 +541,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
           rd_v[j] = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(rd.x + off + j * 256));
       if (rd.res && !(MVSN_RD_ABLATE & 4)) {
 #pragma unroll
-        for (int j = 0; j < RN; ++j) wn_dma16(rd.res + off + j * 256, rds + j * 256);
+        for (int j = 0; j < RN; ++j) wn_dma16<ASM_DMA>(rd.res + off + j * 256, rds + j * 256);
       }
       if (rd.r_stats) {
         const float rm = wn_sload(rd.r_stats, ((size_t)n * 4 + (c >> 3)) * 2 + 0);
@@ -573,7 +587,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     wait_landed(total_steps - 1 < NSTAGE - 1 ? total_steps - 1 : NSTAGE - 1);
     xf_apply();        // step 0
     xf_prepare();      // step 1
-    wn_barrier();      // step 0 (and U) visible to everyone
+    wn_barrier<LDS_BARRIER>();      // step 0 (and U) visible to everyone
     float d0[KS][4][4];
     tr_load(d0);
     tr_finish(d0, v);
@@ -723,7 +737,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         if (!waited) wait_landed(rest < 0 ? 0 : (rest < NSTAGE - 2 ? rest : NSTAGE - 2));   // step + 1 has landed
         xf_apply();        // step + 1
         WN_STAMP();   // landed
-        if (!(MVSN_WN_ABLATE & 8)) wn_barrier();   // ... for everyone; everyone has read the raw tile of `step`
+        if (!(MVSN_WN_ABLATE & 8)) wn_barrier<LDS_BARRIER>();   // ... for everyone; everyone has read the raw tile of `step`
         WN_STAMP();   // barrier
         xf_prepare();      // step + 2: its scalar loads travel behind this step's multiplies
       }
