@@ -824,8 +824,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
   double acc[4][3];
 #pragma unroll
   for (int g = 0; g < 4; ++g) acc[g][0] = acc[g][1] = acc[g][2] = 0.0;
-  for (int t = tid; t < tiles; t += 256) {
-    const floatx4 a = p[(size_t)t * 3], b = p[(size_t)t * 3 + 1], c = p[(size_t)t * 3 + 2];
+  auto add = [&](const floatx4 &a, const floatx4 &b, const floatx4 &c) {
     const float e[12] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3]};
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -834,7 +833,21 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
       acc[g][1] += cnt * mean;
       acc[g][2] += (double)e[g * 3 + 2] + cnt * mean * mean;
     }
+  };
+  // eight records in flight per thread: a level-0 refiner layer leaves 8192 records per sample, and with one record
+  // per iteration the launch was 32 dependent round trips long (25-32 us, 45 launches per forward)
+  constexpr int GF_U = 8;
+  int t = tid;
+  for (; t + (GF_U - 1) * 256 < tiles; t += GF_U * 256) {
+    floatx4 r[GF_U][3];
+#pragma unroll
+    for (int u = 0; u < GF_U; ++u)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) r[u][k] = p[(size_t)(t + u * 256) * 3 + k];
+#pragma unroll
+    for (int u = 0; u < GF_U; ++u) add(r[u][0], r[u][1], r[u][2]);   // (same order as the one-by-one loop)
   }
+  for (; t < tiles; t += 256) add(p[(size_t)t * 3], p[(size_t)t * 3 + 1], p[(size_t)t * 3 + 2]);
   __shared__ double red[4][12];   // per wave
 #pragma unroll
   for (int g = 0; g < 4; ++g)
