@@ -95,6 +95,8 @@ __device__ __forceinline__ void wn_barrier() {
 // schedules better where the drain is harmless (measured on MI355X, level-0 layer of 64 images: plain dilation-1
 // layer 0.79 ms builtin / 0.81 asm; the same layer carrying a pass 1.14 / 1.06, with the input transform 1.29 / 1.18;
 // dilation 2, 4, 8 within 1 % either way).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // (M0 is a reserved register; the compiler keeps nothing in it here)
 template <bool ASM>
 __device__ __forceinline__ void wn_dma16(const float *g, const float *l) {
   if constexpr (ASM) {
@@ -104,6 +106,7 @@ __device__ __forceinline__ void wn_dma16(const float *g, const float *l) {
     __builtin_amdgcn_global_load_lds(WN_GPTR(g), WN_LPTR(l), 16, 0, 0);
   }
 }
+#pragma clang diagnostic pop
 
 struct WinoDiv {
   unsigned mul, shift;
