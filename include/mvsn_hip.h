@@ -78,8 +78,8 @@ int mvsn_homography_warp(const float *image, const float *H, int batch, int chan
  *   left_features (B,32,rows,cols)   refiner_packed: mvsn_feature_refiner_packed_floats() floats
  *   cost_volume (N,32,D,rows,cols)   mask_volume (N,D,rows,cols) u8
  *   feature_volume: optional (N,32,D,rows,cols) masked source features, or NULL
- *   workspace: mvsn_incremental_cost_volume_workspace_bytes() bytes (may be 0 -> NULL allowed)
- *   form: MVSN_CHAIN_AUTO picks per coarse grid (mvsn_incremental_cost_volume_form tells which);
+ *   workspace: mvsn_incremental_cost_volume_workspace_bytes_for() bytes, 16-byte aligned (may be 0 -> NULL allowed)
+ *   form: MVSN_CHAIN_AUTO picks per coarse grid and number of chains (mvsn_incremental_cost_volume_form_for tells which);
  *         MVSN_CHAIN_DIRECT = the three 3x3 convolutions as direct implicit GEMMs (any grid up to 2048 px);
  *         MVSN_CHAIN_WINOGRAD = as Winograd F(2x2,3x3) products (fp32 throughout, 2.25x fewer multiplies; even
  *         rows/cols whose planes + one layer of transformed weights fit LDS, e.g. 16x32), MVSN_E_TOOLARGE otherwise.
@@ -87,6 +87,10 @@ int mvsn_homography_warp(const float *image, const float *H, int batch, int chan
 #define MVSN_CHAIN_AUTO 0
 #define MVSN_CHAIN_DIRECT 1
 #define MVSN_CHAIN_WINOGRAD 2
+#define MVSN_CHAIN_STEPWISE 3 /* one plane per round of full-chip launches (warp, three Winograd convolutions with the
+                                 GroupNorm statistics of the producing launch, the residual pass, the cost slice):
+                                 for coarse grids whose planes do not fit one CU (30x40, 32x64) while fewer chains
+                                 than CUs are in flight -- there the one-workgroup-per-chain forms leave the chip idle */
 size_t mvsn_feature_refiner_packed_floats(void);
 /* Pack the ten FeatureRefiner tensors (state_dict order: conv0.{weight,bias}, bn0.{weight,bias},
  * res0.conv1.{weight,bias}, res0.bn1.{weight,bias}, conv_final.{weight,bias}) into the MFMA
@@ -95,8 +99,13 @@ int mvsn_pack_feature_refiner(const float *conv0_w, const float *conv0_b, const 
                               const float *bn0_b, const float *res0_w, const float *res0_b,
                               const float *res0_bn_w, const float *res0_bn_b, const float *final_w,
                               const float *final_b, float *packed, mvsn_stream_t stream);
-size_t mvsn_incremental_cost_volume_workspace_bytes(int n_chains, int rows, int cols);
-int mvsn_incremental_cost_volume_form(int rows, int cols);   /* what MVSN_CHAIN_AUTO resolves to for this grid */
+size_t mvsn_incremental_cost_volume_workspace_bytes(int n_chains, int rows, int cols);   /* the fused forms only */
+int mvsn_incremental_cost_volume_form(int rows, int cols);   /* the fused form of this grid: WINOGRAD or DIRECT */
+/* what MVSN_CHAIN_AUTO resolves to for this many chains on this grid (WINOGRAD, STEPWISE or DIRECT), and the
+ * workspace `form` (AUTO allowed) needs for num_idepth_samples planes */
+int mvsn_incremental_cost_volume_form_for(int n_chains, int rows, int cols);
+size_t mvsn_incremental_cost_volume_workspace_bytes_for(int n_chains, int num_idepth_samples, int rows, int cols,
+                                                        int form);
 int mvsn_incremental_cost_volume(const float *src_image_lvl4, const float *H_lvl4, const float *H_inc,
                                  const float *plane0_features, const float *left_features,
                                  const float *refiner_packed, int n_chains, int batch,

@@ -16,7 +16,11 @@ constexpr int CH_DIRECT_FLOATS = CH_W0_FLOATS + 2 * CH_W1_FLOATS + CH_SP_FLOATS;
 constexpr int CW_UCHUNK = 2 * 4 * 64 * 4;
 constexpr int CW_U0_FLOATS = 9 * CW_UCHUNK;
 constexpr int CW_U1_FLOATS = 8 * CW_UCHUNK;
-constexpr int CH_PACKED_FLOATS = CH_DIRECT_FLOATS + CW_U0_FLOATS + 2 * CW_U1_FLOATS;
+// stepwise form: the three layers in the convolution kernels' own Winograd layout (mvsn_conv_wino.hip),
+// [chunk of 4 cin][xi][cout tile][lane] = 2048 floats per chunk
+constexpr int CH_STEPS_OFFSET = CH_DIRECT_FLOATS + CW_U0_FLOATS + 2 * CW_U1_FLOATS;
+constexpr int CS_U0_FLOATS = 9 * 2048, CS_U1_FLOATS = 8 * 2048;
+constexpr int CH_PACKED_FLOATS = CH_STEPS_OFFSET + CS_U0_FLOATS + 2 * CS_U1_FLOATS;
 
 struct ChainArgs {
   const float *src;      // (N,3,P)
@@ -36,5 +40,10 @@ struct ChainArgs {
 // Winograd form: does this coarse grid have a plan (even rows / cols, <= 128 patches, LDS fits)?
 bool chain_wino_supported(int rows, int cols);
 int chain_wino_launch(const ChainArgs &a, int n_chains, hipStream_t stream);
+
+// Stepwise form (mvsn_chain_steps.hip): one plane per round of full-chip launches
+bool chain_steps_supported(int rows, int cols);
+size_t chain_steps_workspace_bytes(int n_chains, int D, int rows, int cols);
+int chain_steps_launch(const ChainArgs &a, int n_chains, void *workspace, size_t workspace_bytes, hipStream_t stream);
 
 }  // namespace mvsn

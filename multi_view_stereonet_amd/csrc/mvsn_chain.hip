@@ -22,6 +22,7 @@
 // (L2-resident); the code path is otherwise identical.
 #include "mvsn_chain.h"
 #include "mvsn_common.h"
+#include "mvsn_conv_wino.h"
 
 namespace mvsn {
 
@@ -41,7 +42,7 @@ __global__ void pack_refiner_kernel(const float *c0w, const float *c0b, const fl
                                     const float *c1w, const float *c1b, const float *g1w, const float *g1b,
                                     const float *c2w, const float *c2b, float *out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= PACKED_FLOATS) return;
+  if (i >= CH_STEPS_OFFSET) return;   // (the stepwise form's region is written by wino_pack_2d)
   if (i >= CH_DIRECT_FLOATS) {
     // Winograd form (mvsn_chain_wino.hip): U = G g G^T, [conv][k-step][cout tile][xi quad][lane][4 xi];
     // lane = k*16 + c holds U_xi[cout = t*16 + c][cin = 4*kstep + k] (the A fragment of the MFMA)
@@ -558,10 +559,15 @@ extern "C" int mvsn_pack_feature_refiner(const float *conv0_w, const float *conv
   MVSN_REQUIRE(conv0_w && conv0_b && bn0_w && bn0_b && res0_w && res0_b && res0_bn_w && res0_bn_b && final_w &&
                    final_b && packed,
                MVSN_E_BADARG, "mvsn_pack_feature_refiner: null pointer");
-  hipLaunchKernelGGL(mvsn::pack_refiner_kernel, dim3((mvsn::PACKED_FLOATS + 255) / 256), dim3(256), 0,
+  hipLaunchKernelGGL(mvsn::pack_refiner_kernel, dim3((mvsn::CH_STEPS_OFFSET + 255) / 256), dim3(256), 0,
                      (hipStream_t)stream, conv0_w, conv0_b, bn0_w, bn0_b, res0_w, res0_b, res0_bn_w, res0_bn_b,
                      final_w, final_b, packed);
-  return mvsn::check_launch("mvsn_pack_feature_refiner");
+  if (int rc = mvsn::check_launch("mvsn_pack_feature_refiner")) return rc;
+  // the same three layers in the convolution kernels' Winograd layout (stepwise form)
+  float *u = packed + mvsn::CH_STEPS_OFFSET;
+  if (int rc = mvsn::wino_pack_2d(conv0_w, 35, u, (hipStream_t)stream)) return rc;
+  if (int rc = mvsn::wino_pack_2d(res0_w, 32, u + mvsn::CS_U0_FLOATS, (hipStream_t)stream)) return rc;
+  return mvsn::wino_pack_2d(final_w, 32, u + mvsn::CS_U0_FLOATS + mvsn::CS_U1_FLOATS, (hipStream_t)stream);
 }
 
 extern "C" int mvsn_incremental_cost_volume_form(int rows, int cols) {
@@ -574,6 +580,28 @@ extern "C" size_t mvsn_incremental_cost_volume_workspace_bytes(int n_chains, int
   const int act_floats = (cols + 2) + 36 * CS;
   if (mvsn::chain_lds_bytes(rows * cols, act_floats, true) <= 160 * 1024) return 0;
   return (size_t)n_chains * act_floats * sizeof(float);
+}
+
+// What MVSN_CHAIN_AUTO resolves to for this many chains on this coarse grid.
+static int chain_auto_form(int n_chains, int rows, int cols) {
+  if (mvsn::chain_wino_supported(rows, cols)) return MVSN_CHAIN_WINOGRAD;
+  // no plane-resident plan: one workgroup per chain leaves the chip idle below ~one chain per CU
+  if (mvsn::chain_steps_supported(rows, cols) && n_chains < mvsn::device_cus()) return MVSN_CHAIN_STEPWISE;
+  return MVSN_CHAIN_DIRECT;
+}
+
+extern "C" int mvsn_incremental_cost_volume_form_for(int n_chains, int rows, int cols) {
+  if (n_chains <= 0 || rows <= 0 || cols <= 0) return MVSN_CHAIN_DIRECT;
+  return chain_auto_form(n_chains, rows, cols);
+}
+
+extern "C" size_t mvsn_incremental_cost_volume_workspace_bytes_for(int n_chains, int num_idepth_samples, int rows,
+                                                                   int cols, int form) {
+  if (n_chains <= 0 || rows <= 0 || cols <= 0 || num_idepth_samples <= 0) return 0;
+  if (form == MVSN_CHAIN_AUTO) form = chain_auto_form(n_chains, rows, cols);
+  if (form == MVSN_CHAIN_STEPWISE) return mvsn::chain_steps_workspace_bytes(n_chains, num_idepth_samples, rows, cols);
+  if (form == MVSN_CHAIN_WINOGRAD) return 0;
+  return mvsn_incremental_cost_volume_workspace_bytes(n_chains, rows, cols);
 }
 
 #ifdef MVSN_CHAIN_STAMPS
@@ -596,14 +624,15 @@ extern "C" int mvsn_incremental_cost_volume(const float *src_image_lvl4, const f
                MVSN_E_BADARG, "mvsn_incremental_cost_volume: null pointer");
   MVSN_REQUIRE(n_chains > 0 && batch > 0 && num_idepth_samples >= 1 && rows > 0 && cols > 0, MVSN_E_BADARG,
                "mvsn_incremental_cost_volume: bad sizes");
-  MVSN_REQUIRE(form >= 0 && form <= 2, MVSN_E_BADARG, "mvsn_incremental_cost_volume: form must be 0, 1 or 2");
+  MVSN_REQUIRE(form >= 0 && form <= 3, MVSN_E_BADARG, "mvsn_incremental_cost_volume: form must be 0 .. 3");
+  if (form == MVSN_CHAIN_AUTO) form = chain_auto_form(n_chains, rows, cols);
   MVSN_REQUIRE(form != MVSN_CHAIN_WINOGRAD || chain_wino_supported(rows, cols), MVSN_E_TOOLARGE,
                "mvsn_incremental_cost_volume: no Winograd plan for a %dx%d coarse grid", rows, cols);
   const bool wino = form == MVSN_CHAIN_WINOGRAD || (form == MVSN_CHAIN_AUTO && chain_wino_supported(rows, cols));
   const int P = rows * cols;
   const int tiles = (P + 15) / 16;
   const int TP = (tiles + CH_WAVES - 1) / CH_WAVES;
-  MVSN_REQUIRE(wino || TP <= 8, MVSN_E_TOOLARGE,
+  MVSN_REQUIRE(wino || form == MVSN_CHAIN_STEPWISE || TP <= 8, MVSN_E_TOOLARGE,
                "mvsn_incremental_cost_volume: %dx%d coarse grid (%d px) exceeds the 2048 px plan", rows, cols, P);
   ChainArgs a;
   a.src = src_image_lvl4;
@@ -624,6 +653,10 @@ extern "C" int mvsn_incremental_cost_volume(const float *src_image_lvl4, const f
 #ifdef MVSN_CHAIN_STAMPS   // tuning builds only (tools/chain_phases.py): device pointer to 64 x u64 cycle stamps
   a.dbg = g_chain_stamps;
 #endif
+  if (form == MVSN_CHAIN_STEPWISE) {
+    a.workspace = nullptr;
+    return chain_steps_launch(a, n_chains, workspace, workspace_bytes, (hipStream_t)stream);
+  }
   if (wino) {
     a.workspace = nullptr;
     return chain_wino_launch(a, n_chains, (hipStream_t)stream);

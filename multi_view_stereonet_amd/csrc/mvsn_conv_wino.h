@@ -21,7 +21,10 @@ int wino_pack(const mvsn_conv_desc *d, const float *weight, float *packed, hipSt
 struct WinoBlocks {
   int cb0, cb1;
   const float *in1, *in2;
+  size_t bs0 = 0, cs0 = 0;   // block 0 strided (floats between samples / channels); 0: contiguous
 };
+constexpr int WINO_UFLOATS_PER_CHUNK = 16 * 128;   // packed floats per 4 input channels
+int wino_pack_2d(const float *weight, int cin, float *packed, hipStream_t stream);
 int wino_launch(const WinoGeom &g, const float *in, const float *upk, const float *bias, const float *in_stats,
                 const float *in_gamma, const float *in_beta, float *out, float *out_partials, hipStream_t stream,
                 const WinoBlocks *blocks = nullptr, const mvsn_apply_job *job = nullptr);

@@ -126,6 +126,7 @@ struct WinoArgs {
   // [cb0, cb0 + cb1) from in1, the rest from in2.  One block: cb0 = cin.
   int cb0, cb1;
   const float *in1, *in2;
+  size_t bs0, cs0;   // block 0: floats between samples / between channels (cb0 * plane, plane when contiguous)
   int D;   // planes per sample (volume form; 1 for the 2-D layers)
 };
 
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       const int c = pf_chunk * (KS * 4) + dch;
       cok = c < g.cin;
       const int cc = cok ? c : 0, c1 = cc - g.cb0, c2 = c1 - g.cb1;   // wave-uniform: the block select is scalar work
-      src = c1 < 0 ? in + ((size_t)pf_n * g.cb0 + cc) * plane
+      src = c1 < 0 ? in + (size_t)pf_n * g.bs0 + (size_t)cc * g.cs0
           : c2 < 0 ? g.in1 + ((size_t)pf_n * g.cb1 + c1) * plane
                    : g.in2 + ((size_t)pf_n * (g.cin - g.cb0 - g.cb1) + c2) * plane;
     }
@@ -846,6 +847,14 @@ bool wino_geom(const mvsn_conv_desc *d, WinoGeom *g) {
   return true;
 }
 
+// (cout, cin, 3, 3) -> the [chunk][xi][cout tile][lane] layout above, without a descriptor (the chain's stepwise form)
+int wino_pack_2d(const float *weight, int cin, float *packed, hipStream_t stream) {
+  const int nchunks = (cin + 3) / 4, total = nchunks * WN_UFLOATS;
+  hipLaunchKernelGGL(wino_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, weight, cin, 32, nchunks, 1,
+                     packed);
+  return check_launch("wino_pack_2d");
+}
+
 int wino_pack(const mvsn_conv_desc *d, const float *weight, float *packed, hipStream_t stream) {
   WinoGeom g;
   if (!wino_geom(d, &g)) return MVSN_E_BADARG;
@@ -897,6 +906,8 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   a.cb0 = g.cin, a.cb1 = 0, a.in1 = a.in2 = in;
   a.D = g.D;
   if (blocks) a.cb0 = blocks->cb0, a.cb1 = blocks->cb1, a.in1 = blocks->in1, a.in2 = blocks->in2;
+  a.cs0 = (size_t)g.H * g.W, a.bs0 = (size_t)a.cb0 * a.cs0;
+  if (blocks && blocks->cs0) a.cs0 = blocks->cs0, a.bs0 = blocks->bs0;
   const int cus = device_cus();
   // (k-steps per step, ring depth) by what fits next to the resident U: the raw tile grows with the dilation
   //   dilation 1: 2 k-steps x 4 stages (94 KB); 2, 4: 2 x 3 (78 / 94 KB); 8: 1 x 3 (74 KB); 4-channel head: 1 x 6

@@ -6,23 +6,30 @@
 
 namespace mvsn {
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void homography_warp_kernel(const float *__restrict__ image,
-                                                              const float *__restrict__ H, int C, int n_planes,
-                                                              int rows, int cols, float *__restrict__ volume,
+                                                              const float *__restrict__ H, int h_bstride, int C,
+                                                              int n_planes, int rows, int cols, int cgroups,
+                                                              float *__restrict__ volume,
                                                               uint8_t *__restrict__ mask) {
   const int P = rows * cols;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  // blockIdx.x = pixel block * cgroups + channel group: small launches (one coarse plane of a few chains, the chain's
+  // stepwise form) are latency-bound on the per-thread channel loop, so the channels are dealt to several blocks
+  const int cg = SPLIT ? blockIdx.x % cgroups : 0, pb = SPLIT ? blockIdx.x / cgroups : blockIdx.x;
+  const int p = pb * blockDim.x + threadIdx.x;
   const int plane = blockIdx.y;
   const int b = blockIdx.z;
   if (p >= P) return;
-  const float *Hp = H + ((size_t)b * n_planes + plane) * 9;
+  const int cper = (C + cgroups - 1) / cgroups;
+  const int c_lo = SPLIT ? cg * cper : 0, c_hi = SPLIT ? (c_lo + cper < C ? c_lo + cper : C) : C;
+  const float *Hp = H + (size_t)b * h_bstride + plane * 9;
   float Hl[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) Hl[i] = Hp[i];
   const int y = p / cols, x = p - y * cols;
   WarpCoord c = warp_coord(Hl, (float)x, (float)y, (float)rows, (float)cols);
   Bilinear t = bilinear_taps(c.ix, c.iy, rows, cols);
-  mask[((size_t)b * n_planes + plane) * P + p] = c.outside ? 1 : 0;
+  if (cg == 0) mask[((size_t)b * n_planes + plane) * P + p] = c.outside ? 1 : 0;
   const float keep = c.outside ? 0.0f : 1.0f;
   const float *img = image + (size_t)b * C * P;
   float *out = volume + (((size_t)b * C) * n_planes + plane) * P + p;
@@ -37,7 +44,7 @@ __global__ __launch_bounds__(256) void homography_warp_kernel(const float *__res
     const float wa1 = sh ? 0.0f : t.w10, wb1 = sh ? t.w10 : t.w11;
     const int r0 = t.y0 * cols + xb, r1 = t.y1 * cols + xb;
     typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-    for (int ch = 0; ch < C; ++ch) {
+    for (int ch = c_lo; ch < c_hi; ++ch) {
       const float *ic = img + (size_t)ch * P;
       const f2u a = *reinterpret_cast<const f2u *>(ic + r0), bb = *reinterpret_cast<const f2u *>(ic + r1);
       const float v = a.x * wa0 + a.y * wb0 + bb.x * wa1 + bb.y * wb1;
@@ -46,11 +53,28 @@ __global__ __launch_bounds__(256) void homography_warp_kernel(const float *__res
     return;
   }
   const int o00 = t.y0 * cols + t.x0, o01 = t.y0 * cols + t.x1, o10 = t.y1 * cols + t.x0, o11 = t.y1 * cols + t.x1;
-  for (int ch = 0; ch < C; ++ch) {
+  for (int ch = c_lo; ch < c_hi; ++ch) {
     const float *ic = img + (size_t)ch * P;
     float v = ic[o00] * t.w00 + ic[o01] * t.w01 + ic[o10] * t.w10 + ic[o11] * t.w11;
     out[(size_t)ch * n_planes * P] = keep * v;  // keep*NaN stays NaN, like the reference's multiply
   }
+}
+
+// H for sample b, plane p at H + b * h_bstride + 9 p (the public entry point: h_bstride = 9 * n_planes)
+int warp_launch(const float *image, const float *H, int h_bstride, int batch, int channels, int n_planes, int rows,
+                int cols, float *volume, uint8_t *mask, hipStream_t stream) {
+  const int P = rows * cols;
+  const long threads = (long)((P + 255) / 256) * 256 * n_planes * batch;
+  int cgroups = 1;   // fewer than ~4 threads per lane of the chip: split the channel loop (8 channels per block at most)
+  while (cgroups * 8 < channels && threads * cgroups < 4L * 64 * 4 * device_cus()) cgroups *= 2;
+  dim3 grid((unsigned)((P + 255) / 256) * cgroups, n_planes, batch);
+  if (cgroups > 1)
+    hipLaunchKernelGGL(homography_warp_kernel<true>, grid, dim3(256), 0, stream, image, H, h_bstride, channels, n_planes,
+                       rows, cols, cgroups, volume, mask);
+  else
+    hipLaunchKernelGGL(homography_warp_kernel<false>, grid, dim3(256), 0, stream, image, H, h_bstride, channels,
+                       n_planes, rows, cols, 1, volume, mask);
+  return check_launch("mvsn_homography_warp");
 }
 
 }  // namespace mvsn
@@ -61,9 +85,6 @@ extern "C" int mvsn_homography_warp(const float *image, const float *H, int batc
   MVSN_REQUIRE(batch > 0 && channels > 0 && n_planes > 0 && rows > 0 && cols > 0, MVSN_E_BADARG,
                "mvsn_homography_warp: bad sizes");
   MVSN_REQUIRE(n_planes <= 65535 && batch <= 65535, MVSN_E_TOOLARGE, "mvsn_homography_warp: grid too large");
-  const int P = rows * cols;
-  dim3 grid((P + 255) / 256, n_planes, batch);
-  hipLaunchKernelGGL(mvsn::homography_warp_kernel, grid, dim3(256), 0, (hipStream_t)stream, image, H, channels,
-                     n_planes, rows, cols, volume, mask);
-  return mvsn::check_launch("mvsn_homography_warp");
+  return mvsn::warp_launch(image, H, 9 * n_planes, batch, channels, n_planes, rows, cols, volume, mask,
+                           (hipStream_t)stream);
 }

@@ -108,7 +108,9 @@ class EngineOptions:
         self.trim_tower_ends = True
         self.cat_free_heads = True         # refiner heads read [image, features, idepth] in place (no torch.cat)
         # The fused chain's three 3x3 convolutions: "auto" = Winograd F(2x2,3x3) where the coarse grid has a plan
-        # (16x32 at 512x256 frames), the direct implicit GEMM elsewhere; "direct" / "winograd" force one form.
+        # (16x32 at 512x256 frames); elsewhere one plane per round of full-chip launches ("stepwise") while fewer
+        # chains than CUs are in flight, the fused direct implicit GEMM otherwise; "direct" / "winograd" / "stepwise"
+        # force one form.
         self.chain_form = "auto"
         # Refiner towers on two batch slices, software-pipelined: slice B's convolution (matrix-pipe-bound) carries
         # slice A's normalise/activate/add pass (HBM-bound) inside its own launch (mvsn_conv_forward_carry).  Used
@@ -616,10 +618,13 @@ class PlaneSweepEngine:
         cost = torch.empty((N, 32, D, rows, cols), dtype=torch.float32, device=dev)
         mask = torch.empty((N, D, rows, cols), dtype=torch.bool, device=dev)
         fvol = torch.empty_like(cost) if want_features else None
-        form = {"auto": _native.CHAIN_AUTO, "direct": _native.CHAIN_DIRECT, "winograd": _native.CHAIN_WINOGRAD}[self.chain_form]
+        form = {"auto": _native.CHAIN_AUTO, "direct": _native.CHAIN_DIRECT, "winograd": _native.CHAIN_WINOGRAD,
+                "stepwise": _native.CHAIN_STEPWISE}[self.chain_form]
         if form == _native.CHAIN_WINOGRAD and self.lib.mvsn_incremental_cost_volume_form(rows, cols) != form:
             form = _native.CHAIN_DIRECT        # no Winograd plan for this coarse grid
-        ws_bytes = self.lib.mvsn_incremental_cost_volume_workspace_bytes(N, rows, cols)
+        if form == _native.CHAIN_STEPWISE and cols % 4 != 0:
+            form = _native.CHAIN_DIRECT        # the Winograd convolutions of the stepwise form need cols % 4 == 0
+        ws_bytes = self.lib.mvsn_incremental_cost_volume_workspace_bytes_for(N, D, rows, cols, form)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
         P = rows * cols
         self._call("mvsn_incremental_cost_volume", self.lib.mvsn_incremental_cost_volume,

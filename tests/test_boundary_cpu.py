@@ -52,11 +52,18 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_native.SIGNATURES), (declared ^ set(_native.SIGNATURES))
     typed = _native.load()
     assert typed.mvsn_abi_version() == _native.ABI_VERSION == 2
-    assert typed.mvsn_feature_refiner_packed_floats() == (9 * 9 * 128 + 2 * 9 * 8 * 128 + 7 * 32) + 25 * 2048   # direct + Winograd U
+    # direct form + the chain's Winograd U + the same three layers in the convolution kernels' layout (stepwise form)
+    assert typed.mvsn_feature_refiner_packed_floats() == (9 * 9 * 128 + 2 * 9 * 8 * 128 + 7 * 32) + 25 * 2048 + 25 * 2048
     assert typed.mvsn_incremental_cost_volume_form(16, 32) == _native.CHAIN_WINOGRAD
     assert typed.mvsn_incremental_cost_volume_form(4, 8) == _native.CHAIN_WINOGRAD
     assert typed.mvsn_incremental_cost_volume_form(30, 40) == _native.CHAIN_DIRECT      # planes + U exceed 160 KB
     assert typed.mvsn_incremental_cost_volume_form(5, 6) == _native.CHAIN_DIRECT        # odd rows
+    # the stepwise form: workspace grows with the planes (image volume) and is 0 for the plane-resident Winograd form
+    ws = typed.mvsn_incremental_cost_volume_workspace_bytes_for
+    assert ws(2, 64, 16, 32, _native.CHAIN_WINOGRAD) == 0
+    assert ws(1, 96, 30, 40, _native.CHAIN_STEPWISE) > ws(1, 48, 30, 40, _native.CHAIN_STEPWISE) > 0
+    assert ws(1, 96, 30, 42, _native.CHAIN_STEPWISE) == 0                               # cols % 4 != 0: no such form
+    assert ws(4, 96, 30, 40, _native.CHAIN_DIRECT) == typed.mvsn_incremental_cost_volume_workspace_bytes(4, 30, 40)
 
 
 def test_conv_planning_is_host_side_and_validates():

@@ -614,7 +614,7 @@ def test_upsamplers_golden_units():
                                                    (128, 256, 9, 2, 1, "gta_sfm_150epochs"),     # 8x16: two full tiles
                                                    (480, 640, 12, 1, 1, "demon_45epochs"),
                                                    (512, 1024, 6, 1, 1, "gta_sfm_150epochs")])
-@pytest.mark.parametrize("form", ["direct", "winograd"])
+@pytest.mark.parametrize("form", ["direct", "winograd", "stepwise"])
 def test_incremental_chain_vs_oracle(rows, cols, D, S, B, wname, form):
     """The fused chain (features, cost, mask) against the oracle's step-by-step recurrence, fed
     with the SAME plane-0 features and homographies so only the chain itself is compared.  Both forms of the
@@ -625,6 +625,8 @@ def test_incremental_chain_vs_oracle(rows, cols, D, S, B, wname, form):
     r4, c4 = (rows + 15) // 16, (cols + 15) // 16
     if form == "winograd" and eng.lib.mvsn_incremental_cost_volume_form(r4, c4) != _native.CHAIN_WINOGRAD:
         pytest.skip(f"no Winograd plan for a {r4}x{c4} coarse grid")
+    if form == "stepwise" and c4 % 4 != 0:
+        pytest.skip(f"the stepwise form needs cols % 4 == 0 ({r4}x{c4})")
     net.options.chain_form = form
     try:
         _chain_vs_oracle(w, eng, rows, cols, D, S, B, form)

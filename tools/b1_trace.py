@@ -10,8 +10,10 @@ from multi_view_stereonet_amd.weights import load_weights
 torch.set_grad_enabled(False)
 net = MultiViewStereoNet(); net.load_state_dict(load_weights("gta_sfm_150epochs")); net = net.cuda().eval()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-inp = snu.multi_view_unpack_batch(synthetic.make_batch(256, 512, 2, batch=B, seed=7), torch.device("cuda"), 5)
-run = lambda: net(inp["left_image_pyr"], inp["K_pyr"], inp["T_right_in_left"], inp["right_image_pyr"], 64, True, [True] * 5)
+# optional: rows cols hypotheses sources (default the headline 256 512 64 2; config 4: 480 640 96 1; config 5: 512 1024 128 4)
+R, C, D, S = [int(a) for a in sys.argv[2:6]] if len(sys.argv) > 5 else (256, 512, 64, 2)
+inp = snu.multi_view_unpack_batch(synthetic.make_batch(R, C, S, batch=B, seed=7), torch.device("cuda"), 5)
+run = lambda: net(inp["left_image_pyr"], inp["K_pyr"], inp["T_right_in_left"], inp["right_image_pyr"], D, True, [True] * 5)
 for _ in range(3):
     run()
 torch.cuda.synchronize()
