@@ -482,6 +482,41 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
 #pragma unroll
       for (int j = 0; j < NPT; ++j) fb[buf][j] = bp[lpos[j]];
     };
+    if constexpr (KD == 1 && KW == 5 && STRIDE == 2 && V4) {
+      // 5x5 stride 2 (extractor): a lane's five taps of a kernel row are the columns 2x .. 2x + 4 of one tile row --
+      // three aligned 8-byte reads instead of five 4-byte ones, and (the 16 pixel lanes of a channel are 8 bytes
+      // apart) spread over all 32 banks where the strided 4-byte reads of the four channel groups all fell on the
+      // 16 even ones.  Row ky + 1 is read while row ky's 40 MFMAs are issued.
+      float2 er[2][NPT][3];
+      auto read_row = [&](int ky, int buf) {
+        const float *bp = tile + ky * g.XS;
+#pragma unroll
+        for (int j = 0; j < NPT; ++j)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) er[buf][j][q] = *reinterpret_cast<const float2 *>(bp + lpos[j] + 2 * q);
+      };
+      read_row(0, 0);
+      fw[0][0] = wt[0], fw[0][1] = CT == 2 ? wt[64] : 0.0f;
+#pragma unroll
+      for (int ky = 0; ky < 5; ++ky) {
+        const int rb = ky & 1;
+        if (ky + 1 < 5) read_row(ky + 1, rb ^ 1);
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+          const int tap = ky * 5 + kx, cur = tap & 1;
+          if (tap + 1 < NTAPS) {
+            fw[cur ^ 1][0] = wt[(tap + 1) * 128];
+            fw[cur ^ 1][1] = CT == 2 ? wt[(tap + 1) * 128 + 64] : 0.0f;
+          }
+#pragma unroll
+          for (int j = 0; j < NPT; ++j) {
+            const float a = (kx & 1) ? er[rb][j][kx >> 1].y : er[rb][j][kx >> 1].x;
+            acc[j][0] = mfma16x16x4(a, fw[cur][0], acc[j][0]);
+            if (CT == 2) acc[j][CT - 1] = mfma16x16x4(a, fw[cur][1], acc[j][CT - 1]);
+          }
+        }
+      }
+    } else {
     read_tap(0, 0);
 #pragma unroll
     for (int tap = 0; tap < NTAPS; ++tap) {
@@ -492,6 +527,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_mfma_kernel(ConvGeom g, co
         acc[j][0] = mfma16x16x4(fb[cur][j], fw[cur][0], acc[j][0]);   // D = pixels x couts
         if (CT == 2) acc[j][CT - 1] = mfma16x16x4(fb[cur][j], fw[cur][1], acc[j][CT - 1]);
       }
+    }
     }
     MFMA_PHASE(5);   // MFMAs issued
   }

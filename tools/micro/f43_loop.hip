@@ -103,6 +103,57 @@ __global__ __launch_bounds__(512, 2) void f23(const float *__restrict__ in, floa
   *reinterpret_cast<floatx4 *>(out + (blockIdx.x * 512 + tid) * 4) = sum;
 }
 
+// F(2x2,3x3), two waves per SIMD, the k-step's 32 U fragment values read into registers BEFORE its multiplies
+// (is the production loop's one-coefficient-ahead prefetch what limits the pipe?)
+__global__ __launch_bounds__(512, 2) void f23p(const float *__restrict__ in, float *__restrict__ out, int steps) {
+  extern __shared__ float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < 24576; i += 512) smem[i] = in[i];
+  __syncthreads();
+  floatx4 acc[16][2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i][0] = acc[i][1] = floatx4{0, 0, 0, 0};
+  float v[16], u[2][16][2];
+  {
+    const float *ub = smem + 10240 + lane;
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) u[0][xi][0] = ub[xi * 128], u[0][xi][1] = ub[xi * 128 + 64];
+  }
+  for (int s = 0; s < steps; s += 2) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float d[4][4];
+      const float *w = smem + ((s + half) & 3) * 2560 + (lane >> 4) * 640 + (lane & 15) * 2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float2 a = *reinterpret_cast<const float2 *>(w + i * 40), b = *reinterpret_cast<const float2 *>(w + i * 40 + 2);
+        d[i][0] = a.x, d[i][1] = a.y, d[i][2] = b.x, d[i][3] = b.y;
+      }
+      const float *ub = smem + 10240 + ((half ^ 1) & 1) * 2048 + lane;   // next k-step's U
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi) u[half ^ 1][xi][0] = ub[xi * 128], u[half ^ 1][xi][1] = ub[xi * 128 + 64];
+      float t[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t[0][j] = d[0][j] - d[2][j], t[1][j] = d[1][j] + d[2][j], t[2][j] = d[2][j] - d[1][j], t[3][j] = d[1][j] - d[3][j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i * 4 + 0] = t[i][0] - t[i][2], v[i * 4 + 1] = t[i][1] + t[i][2], v[i * 4 + 2] = t[i][2] - t[i][1], v[i * 4 + 3] = t[i][1] - t[i][3];
+      }
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi) {
+        acc[xi][0] = mfma(v[xi], u[half][xi][0], acc[xi][0]);
+        acc[xi][1] = mfma(v[xi], u[half][xi][1], acc[xi][1]);
+      }
+    }
+  }
+  floatx4 sum = floatx4{0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sum += acc[i][0] + acc[i][1] * 2.f;
+  *reinterpret_cast<floatx4 *>(out + (blockIdx.x * 512 + tid) * 4) = sum;
+}
+
 // F(2x2,3x3), volume form with the three depth taps of a plane sharing ONE input transform: one wave per SIMD, three
 // accumulator sets (384 registers), per 4-channel k-step 48 transform VALU and 96 MFMAs
 __global__ __launch_bounds__(256, 1) void f23x3(const float *__restrict__ in, float *__restrict__ out, int steps) {
@@ -159,24 +210,26 @@ int main() {
   hipFuncSetAttribute((const void *)f43, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
   hipFuncSetAttribute((const void *)f23, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
   hipFuncSetAttribute((const void *)f23x3, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+  hipFuncSetAttribute((const void *)f23p, hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
   const int steps = 20000;
   hipEvent_t a, b;
   hipEventCreate(&a), hipEventCreate(&b);
-  for (int which = 0; which < 3; ++which)
+  for (int which = 0; which < 4; ++which)
     for (int rep = 0; rep < 3; ++rep) {
       hipEventRecord(a);
       if (which == 0) hipLaunchKernelGGL(f43, dim3(256), dim3(256), 98304, 0, in, out, steps);
       else if (which == 1) hipLaunchKernelGGL(f23, dim3(256), dim3(512), 98304, 0, in, out, steps);
-      else hipLaunchKernelGGL(f23x3, dim3(256), dim3(256), 98304, 0, in, out, steps);
+      else if (which == 2) hipLaunchKernelGGL(f23x3, dim3(256), dim3(256), 98304, 0, in, out, steps);
+      else hipLaunchKernelGGL(f23p, dim3(256), dim3(512), 98304, 0, in, out, steps);
       hipEventRecord(b);
       hipEventSynchronize(b);
       float ms;
       hipEventElapsedTime(&ms, a, b);
       // outputs (x 32 couts) per k-step per SIMD: F(4,3) one wave x 16 patches x 16; F(2,3) two waves x 16 patches x 4
       // (third kernel: one wave x 16 patches x 4 outputs x 3 depth taps' worth of multiplies)
-      const double outs = which == 0 ? 256.0 : (which == 1 ? 128.0 : 192.0), mf = which == 0 ? 72.0 : (which == 1 ? 64.0 : 96.0);
+      const double outs = which == 0 ? 256.0 : (which == 2 ? 192.0 : 128.0), mf = which == 0 ? 72.0 : (which == 2 ? 96.0 : 64.0);
       printf("%s: %.3f ms  %.0f ns per k-step  %.2f ns per output (x32 couts x4 cin)  MFMA pipe %.1f %% of 157.3 TFLOP/s\n",
-             which == 0 ? "F(4x4,3x3) 1 wave/SIMD " : (which == 1 ? "F(2x2,3x3) 2 waves/SIMD" : "F(2,3) x3 taps, 1 wave "), ms, ms * 1e6 / steps, ms * 1e6 / steps / outs,
+             which == 0 ? "F(4x4,3x3) 1 wave/SIMD " : (which == 1 ? "F(2x2,3x3) 2 waves/SIMD" : (which == 2 ? "F(2,3) x3 taps, 1 wave " : "F(2,3) 2 waves, U ahead ")), ms, ms * 1e6 / steps, ms * 1e6 / steps / outs,
              100.0 * (mf * 2048.0 * 4 * 256 * steps / (ms * 1e-3)) / 157.3e12);
     }
   return 0;
