@@ -394,7 +394,9 @@ class PlaneSweepEngine:
         other slice's next convolution launch (`carry`): the launch order is
             head(A) head(B) c1(A) c1(B)+p1(A) c2(A)+p1(B) c2(B)+p2(A) ... c6(A)+p5(B) c6(B) tail(A) tail(B)
         with p_k = the pass that turns block k's raw output into its activation.  Same kernels, same arithmetic
-        per sample as the unsliced tower: bit-identical results."""
+        per sample as the unsliced tower: bit-identical results.  Reference: IDepthmapRefiner.forward
+        (multi_view_stereonet.py:448-484), SimpleBasicBlock (:38-48); the samples of a batch are independent there
+        (GroupNorm statistics are per sample), which is what makes the slicing legal."""
         n = blocks_in[0].shape[0]
         h = (n + 1) // 2
         bounds = ((0, h), (h, n))
@@ -534,8 +536,9 @@ class PlaneSweepEngine:
         return out
 
     def cost_volume_filter_sliced(self, cost: torch.Tensor) -> torch.Tensor:
-        """The regulariser on two slices of the chains, pipelined like residual_tower_sliced: the in-place
-        LReLU(GN(.)) pass of one slice's layer travels inside the other slice's next convolution launch
+        """The regulariser (CostVolumeFilter.forward, multi_view_stereonet.py:341-353) on two slices of the chains,
+        pipelined like residual_tower_sliced: the in-place LReLU(GN(.)) pass of one slice's layer travels inside the
+        other slice's next convolution launch
             c0(A) c0(B)+p0(A) c1(A)+p0(B) c1(B)+p1(A) c2(A)+p1(B) c2(B)+p2(A) c3(A)+p2(B) c3(B) tail(A) tail(B)."""
         n, _, depth, rows, cols = cost.shape
         h = (n + 1) // 2
