@@ -882,7 +882,8 @@ bool wino_can_carry(const WinoGeom &g, const mvsn_apply_job *job) {
   const long units = (long)job->n * 32 * (job->spatial / 256);
   if (g.vol && job->residual) return false;   // (no residual slots next to the volume form's two rings)
   const int nsteps = g.vol ? 12 : (g.dil >= 4 ? 8 : 4);
-  return units <= (long)g.n * g.D * g.tiles * nsteps * WN_WAVES * r && units < (1L << 30);
+  const long capacity = (long)g.n * g.D * g.tiles * nsteps * WN_WAVES * r;   // unit indices are 32-bit in the kernel
+  return units <= capacity && capacity < (1L << 31) && units < (1L << 30);
 }
 
 int wino_launch(const WinoGeom &g, const float *in, const float *upk, const float *bias, const float *in_stats,
