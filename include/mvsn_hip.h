@@ -192,6 +192,10 @@ typedef struct mvsn_apply_job {
   const float *residual, *r_stats, *r_gamma, *r_beta;
   float *out;      /* may alias x */
   int n;           /* samples: (n, 32, spatial) */
+  int reverse;     /* 1: the carrying launch walks its tiles, and with them the job, from the end to the beginning
+                      (consecutive launches of a pipelined tower alternate, so that each starts on what the one before
+                      it touched last: a few per cent of the bytes then come from the memory-side cache); results
+                      identical either way */
   long spatial;
 } mvsn_apply_job;
 /* mvsn_conv_forward (no in_residual / out_staged) AND an independent apply job in one call.  The residual blocks

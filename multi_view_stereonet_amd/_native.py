@@ -25,7 +25,7 @@ class ApplyJob(Structure):
     """mvsn_apply_job"""
     _fields_ = [("x", c_void_p), ("stats", c_void_p), ("gamma", c_void_p), ("beta", c_void_p),
                 ("residual", c_void_p), ("r_stats", c_void_p), ("r_gamma", c_void_p), ("r_beta", c_void_p),
-                ("out", c_void_p), ("n", c_int), ("spatial", c_long)]
+                ("out", c_void_p), ("n", c_int), ("reverse", c_int), ("spatial", c_long)]
 
 
 CONV_FP32, CONV_BF16X3, CONV_FP32_WINO, CONV_BF16 = 0, 1, 2, 3

@@ -127,6 +127,7 @@ struct WinoArgs {
   int cb0, cb1;
   const float *in1, *in2;
   size_t bs0, cs0;   // block 0: floats between samples / between channels (cb0 * plane, plane when contiguous)
+  int rev;           // walk the work items from the last to the first (placement only: results are identical)
   int D;   // planes per sample (volume form; 1 for the 2-D layers)
 };
 
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   bool pf_live = slot < total;
   int rd_young = 0;   // RIDE: DMA pieces this wave has issued since its carried loads
   auto pf_plan = [&]() {   // DMA plan of the prefetcher's current item
-    const int flat = pf_round * G + slot;
+    const int flat = g.rev ? total - 1 - (pf_round * G + slot) : pf_round * G + slot;
     const int n = flat / ptiles;
     int tile = flat - n * ptiles;
     if constexpr (VOL) {
@@ -377,8 +378,9 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   bool xf_on = false;
   auto xf_prepare = [&]() {        // parameters of the step the in-LDS side handles next (issued one step early)
     if constexpr (MODE == 1) {
-      const int flat = xf_round * G + slot;
-      xf_on = flat < total;
+      const int lin = xf_round * G + slot;
+      const int flat = g.rev ? total - 1 - lin : lin;
+      xf_on = lin < total;
       if (!xf_on) return;
       const int n = flat / ptiles;
       int tile = flat - n * ptiles, z = 0;
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
 #ifdef MVSN_WN_STAMPS
     dbg_on = round >= 3;   // steady state: skip the first tiles
 #endif
-    const int flat = round * G + slot;
+    const int flat = g.rev ? total - 1 - (round * G + slot) : round * G + slot;
     const int n = flat / ptiles;
     int tile_id = flat - n * ptiles, z = 0;
     if constexpr (VOL) {
@@ -907,6 +909,7 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   a.cb0 = g.cin, a.cb1 = 0, a.in1 = a.in2 = in;
   a.D = g.D;
   if (blocks) a.cb0 = blocks->cb0, a.cb1 = blocks->cb1, a.in1 = blocks->in1, a.in2 = blocks->in2;
+  a.rev = (job && job->reverse == 1) ? 1 : 0;
   a.cs0 = (size_t)g.H * g.W, a.bs0 = (size_t)a.cb0 * a.cs0;
   if (blocks && blocks->cs0) a.cs0 = blocks->cs0, a.bs0 = blocks->bs0;
   const int cus = device_cus();

@@ -56,7 +56,7 @@ for bi, mode1, add2 in ((0, False, False), (1, False, False), (2, False, False),
 
     job = _native.ApplyJob(P(jr), P(stats), P(norm.gamma), P(norm.beta), P(jr0) if add2 else P(jres),
                            P(stats0) if add2 else None, P(norm0.gamma) if add2 else None,
-                           P(norm0.beta) if add2 else None, P(jout2), n, rows * cols)
+                           P(norm0.beta) if add2 else None, P(jout2), n, int(os.environ.get("CARRY_REV", "0")), rows * cols)
     carried = ctypes.c_int(-1)
 
     def run_carry():

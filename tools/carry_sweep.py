@@ -24,13 +24,13 @@ def run(it=8):
     return a.elapsed_time(b) / it
 
 
-cases = [("off", dict(carry_passes=False)), ("0-2 novol", dict(carry_min_bytes=64 << 20, carry_volume_passes=False)),
-         ("0-2 vol", dict(carry_min_bytes=64 << 20, carry_volume_passes=True)),
-         ("vol only", dict(carry_min_bytes=300 << 20, carry_volume_passes=True)),
-         ("0-3 vol", dict(carry_min_bytes=16 << 20, carry_volume_passes=True))]
-for rep in range(2):
+cases = [("off", dict(carry_passes=False)),
+         ("0-2", dict(carry_min_bytes=32 << 20, carry_volume_passes=False, carry_alternate=False)),
+         ("0-2 alternating", dict(carry_min_bytes=32 << 20, carry_volume_passes=False, carry_alternate=True)),
+         ("0-2 + volume", dict(carry_min_bytes=32 << 20, carry_volume_passes=True, carry_alternate=False))]
+for rep in range(int(os.environ.get('REPS', '2'))):
     for name, opts in cases:
         net.options.carry_passes = True
         for k, v in opts.items(): setattr(net.options, k, v)
         ms = run()
-        print(f"{name:8s} {ms:7.3f} ms  {B / ms * 1e3:7.1f} /s", flush=True)
+        print(f"{name:16s} {ms:7.3f} ms  {B / ms * 1e3:7.1f} /s", flush=True)
