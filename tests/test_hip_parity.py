@@ -1212,3 +1212,28 @@ def test_sliced_regulariser_is_bit_identical():
             assert eng.carried_jobs > before and torch.equal(got, want), (n, depth)
     finally:
         net.options.carry_passes, net.options.carry_min_bytes, net.options.carry_volume_passes = old
+
+
+def test_forward_option_variants_agree():
+    """The whole forward on a batch-2 golden case under the engine's scheduling options: slicing / carrying (at every
+    level, with and without alternation, the regulariser too) must not change a bit, the chain forms agree within
+    rounding."""
+    fix = load_golden("g1b_gta_96x80_d8_s2_b2.npz")
+    net = net_for("gta_sfm_150epochs")
+    ref = [t.clone() for t in _forward(net, fix)["left_idepthmap_pyr"]]
+    for opts, exact in ((dict(carry_min_bytes=0), True), (dict(carry_min_bytes=0, carry_alternate=False), True),
+                        (dict(carry_passes=False), True), (dict(carry_min_bytes=0, carry_volume_passes=True), True),
+                        (dict(chain_form="stepwise"), False), (dict(chain_form="direct"), False)):
+        old = {k: getattr(net.options, k) for k in opts}
+        for k, v in opts.items():
+            setattr(net.options, k, v)
+        try:
+            out = _forward(net, fix)["left_idepthmap_pyr"]
+        finally:
+            for k, v in old.items():
+                setattr(net.options, k, v)
+        for a, b in zip(out, ref):
+            if exact:
+                assert torch.equal(a, b), opts
+            else:
+                assert float((a - b).abs().max() / b.abs().max()) < 1e-4, opts
