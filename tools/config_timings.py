@@ -25,7 +25,7 @@ for name, wname, rows, cols, D, S, batches in CONFIGS:
         torch.cuda.reset_peak_memory_stats()
         for _ in range(4): f()          # allocator pools, LDS opt-ins, packed weights
         torch.cuda.synchronize()
-        t0 = time.perf_counter(); n = 5
+        t0 = time.perf_counter(); n = 5 if B > 8 else 25   # (a batch-1 forward is 4-13 ms: five of them are one hiccup away from nonsense)
         for _ in range(n): o = f()
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
         rec = {"config": name, "batch": B, "ms_per_forward": round(dt * 1e3, 2), "depthmaps_per_s": round(B / dt, 1),
