@@ -241,8 +241,11 @@ class PlaneSweepEngine:
         rows, cols = x.shape[-2], x.shape[-1]
         d = c.desc(n, depth, rows, cols)
         packed = c.packed
+        # the bf16 tiers: the 3x3x3 layers always; the 2-D 3x3 layers only when the towers are not sliced (the fp32
+        # Winograd launches that carry the other slice's pass beat bf16 kernels followed by a stand-alone pass:
+        # 15.1 against 17.3 ms per step for the refiner blocks)
         if self.conv_precision in ("bf16x3", "bf16") and c.packed_bx is not None and in_residual is None and \
-                not write_staged:
+                not write_staged and carry is None and (c.dims == 3 or not (self.carry_passes and self.winograd)):
             dbx = c.desc(n, depth, rows, cols,
                          _native.CONV_BF16X3 if self.conv_precision == "bf16x3" else _native.CONV_BF16)
             if lib.mvsn_conv_bf16x3_supported(ctypes.byref(dbx)):
