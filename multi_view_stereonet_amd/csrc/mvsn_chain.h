@@ -46,4 +46,12 @@ bool chain_steps_supported(int rows, int cols);
 size_t chain_steps_workspace_bytes(int n_chains, int D, int rows, int cols);
 int chain_steps_launch(const ChainArgs &a, int n_chains, void *workspace, size_t workspace_bytes, hipStream_t stream);
 
+// Banded form (mvsn_chain_band.hip): one chain on four workgroups, 16x32 coarse grid
+bool chain_band_supported(int rows, int cols);
+int chain_band_groups();
+size_t chain_band_workspace_bytes(int n_chains);
+size_t chain_band_status_offset(int n_chains);
+int chain_band_launch(const ChainArgs &a, int n_chains, void *workspace, size_t workspace_bytes, int flags,
+                      hipStream_t stream);
+
 }  // namespace mvsn

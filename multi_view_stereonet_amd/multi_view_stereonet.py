@@ -109,8 +109,9 @@ class EngineOptions:
         self.cat_free_heads = True         # refiner heads read [image, features, idepth] in place (no torch.cat)
         # The fused chain's three 3x3 convolutions: "auto" = Winograd F(2x2,3x3) where the coarse grid has a plan
         # (16x32 at 512x256 frames); elsewhere one plane per round of full-chip launches ("stepwise") while fewer
-        # chains than CUs are in flight, the fused direct implicit GEMM otherwise; "direct" / "winograd" / "stepwise"
-        # force one form.
+        # chains than CUs are in flight, the fused direct implicit GEMM otherwise; on the 16x32 grid with at most 16
+        # chains (batch 1 .. 8 at two sources) one chain runs on FOUR workgroups ("banded").  "direct" / "winograd" /
+        # "stepwise" / "banded" force one form.
         self.chain_form = "auto"
         # Refiner towers on two batch slices, software-pipelined: slice B's convolution (matrix-pipe-bound) carries
         # slice A's normalise/activate/add pass (HBM-bound) inside its own launch (mvsn_conv_forward_carry).  Used
@@ -166,6 +167,10 @@ class PlaneSweepEngine:
     def __init__(self, net: "MultiViewStereoNet"):
         self.lib = lib = _native.load()
         self.carried_jobs = 0          # normalise/activate/add passes that travelled inside a convolution launch
+        # The banded chain form spins on its sibling workgroups: every workgroup of a launch must be resident, so two
+        # such launches must not share the device (MultiViewStereoNet._forward_lanes clears this for its lanes).
+        self.banded_ok = True
+        self.last_chain_form, self.last_chain_workspace = None, None
         self._carried_before = {}
         # tuning switches live on the module (EngineOptions), so they survive every rebuild of this object
         # (.to(), load_state_dict, in-place parameter updates); `engine.<switch>` reads and writes through
@@ -632,13 +637,18 @@ class PlaneSweepEngine:
         mask = torch.empty((N, D, rows, cols), dtype=torch.bool, device=dev)
         fvol = torch.empty_like(cost) if want_features else None
         form = {"auto": _native.CHAIN_AUTO, "direct": _native.CHAIN_DIRECT, "winograd": _native.CHAIN_WINOGRAD,
-                "stepwise": _native.CHAIN_STEPWISE}[self.chain_form]
+                "stepwise": _native.CHAIN_STEPWISE, "banded": _native.CHAIN_BANDED}[self.chain_form]
+        if form == _native.CHAIN_AUTO:
+            form = self.lib.mvsn_incremental_cost_volume_form_for(N, rows, cols)
+            if form == _native.CHAIN_BANDED and not self.banded_ok:
+                form = self.lib.mvsn_incremental_cost_volume_form(rows, cols)   # lanes on several streams: see forward
         if form == _native.CHAIN_WINOGRAD and self.lib.mvsn_incremental_cost_volume_form(rows, cols) != form:
             form = _native.CHAIN_DIRECT        # no Winograd plan for this coarse grid
         if form == _native.CHAIN_STEPWISE and cols % 4 != 0:
             form = _native.CHAIN_DIRECT        # the Winograd convolutions of the stepwise form need cols % 4 == 0
         ws_bytes = self.lib.mvsn_incremental_cost_volume_workspace_bytes_for(N, D, rows, cols, form)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+        self.last_chain_form, self.last_chain_workspace = form, ws
         P = rows * cols
         self._call("mvsn_incremental_cost_volume", self.lib.mvsn_incremental_cost_volume,
                    _native.ptr(src4), _native.ptr(H4), _native.ptr(Hinc), _native.ptr(plane0), _native.ptr(left_feats),
@@ -647,6 +657,15 @@ class PlaneSweepEngine:
                    flops=N * (D - 1) * 2.0 * 9 * 32 * (35 + 32 + 32) * P,
                    nbytes=N * (4.0 * 67 * P + 128.0 * D * P + D * P))  # Kernel A algorithmic bytes
         return cost, mask, fvol
+
+    def chain_status(self) -> int:
+        """Status word of the last banded chain launch (synchronises): 0 = every inter-workgroup hand-off completed."""
+        if self.last_chain_form != _native.CHAIN_BANDED or self.last_chain_workspace is None:
+            return 0
+        ws = self.last_chain_workspace
+        n = (ws.numel() - 64) // self.lib.mvsn_incremental_cost_volume_status_offset(1)
+        off = self.lib.mvsn_incremental_cost_volume_status_offset(n)
+        return int(ws[off:off + 4].view(torch.int32).item())
 
     def soft_argmin(self, cost: torch.Tensor, samples: torch.Tensor) -> torch.Tensor:
         N, D, rows, cols = cost.shape
@@ -850,11 +869,13 @@ class MultiViewStereoNet(nn.Module):
             lo, hi = bounds[i], bounds[i + 1]
             st = self._lane_streams[i]
             st.wait_stream(main)
+            eng.banded_ok = False       # concurrent lanes: the banded chain needs the device to itself
             with torch.cuda.stream(st):
                 parts.append(eng.forward([x[lo:hi] for x in left_image_pyr], [k[lo:hi] for k in K_pyr],
                                          [t[lo:hi] for t in T_right_in_lefts],
                                          [[x[lo:hi] for x in p] for p in right_image_pyrs], *args, None))
         out = {}
+        eng.banded_ok = True
         for st in self._lane_streams[:lanes]:
             main.wait_stream(st)
         for key in parts[0]:

@@ -614,7 +614,7 @@ def test_upsamplers_golden_units():
                                                    (128, 256, 9, 2, 1, "gta_sfm_150epochs"),     # 8x16: two full tiles
                                                    (480, 640, 12, 1, 1, "demon_45epochs"),
                                                    (512, 1024, 6, 1, 1, "gta_sfm_150epochs")])
-@pytest.mark.parametrize("form", ["direct", "winograd", "stepwise"])
+@pytest.mark.parametrize("form", ["direct", "winograd", "stepwise", "banded"])
 def test_incremental_chain_vs_oracle(rows, cols, D, S, B, wname, form):
     """The fused chain (features, cost, mask) against the oracle's step-by-step recurrence, fed
     with the SAME plane-0 features and homographies so only the chain itself is compared.  Both forms of the
@@ -627,6 +627,8 @@ def test_incremental_chain_vs_oracle(rows, cols, D, S, B, wname, form):
         pytest.skip(f"no Winograd plan for a {r4}x{c4} coarse grid")
     if form == "stepwise" and c4 % 4 != 0:
         pytest.skip(f"the stepwise form needs cols % 4 == 0 ({r4}x{c4})")
+    if form == "banded" and (r4, c4) != (16, 32):
+        pytest.skip(f"the banded form covers the 16x32 coarse grid ({r4}x{c4})")
     net.options.chain_form = form
     try:
         _chain_vs_oracle(w, eng, rows, cols, D, S, B, form)
@@ -659,11 +661,113 @@ def _chain_vs_oracle(w, eng, rows, cols, D, S, B, form):
         cost_ref = (~mask_ref).float()[:, None] * (FL[:, :, None] - fvol_ref).abs()
         cost, mask, fvol = eng.incremental_cost_volume(src4.to(DEV), H.to(DEV), Hinc.to(DEV), F0.to(DEV), FL.to(DEV),
                                                        want_features=True)
+        assert eng.chain_status() == 0, "a banded-chain hand-off timed out"
         assert int((mask.cpu() != mask_ref).sum()) == 0
         for name, a, b in (("features", fvol, fvol_ref), ("cost", cost, cost_ref)):
             mean_rel, max_rel = rel_err(a.cpu(), b)
             print(f"chain[{form}] {r4}x{c4} D={D} source {s} {name}: mean-rel {mean_rel:.3e} max-rel {max_rel:.3e}")
             assert mean_rel < 1e-5 and max_rel < 1e-4, (name, s, mean_rel, max_rel)
+
+
+def _oracle_chain(w, src4, H, Hinc, F0, FL):
+    """The oracle's recurrence (multi_view_stereonet.py:270-300 + the cost build :553,587-592) on explicit
+    homography families."""
+    D = H.shape[1]
+    image_vol, mask_ref = oracle.homography_warp(src4, H)
+    planes = [F0]
+    for d in range(1, D):
+        moved, _ = oracle.homography_warp(planes[-1], Hinc[:, d:d + 1])
+        planes.append(oracle.feature_refiner(w, "right_feature_extractor.refiner", image_vol[:, :, d], moved[:, :, 0]))
+    fvol_ref = torch.stack(planes, 2) * (~mask_ref).float()[:, None]
+    cost_ref = (~mask_ref).float()[:, None] * (FL[:, :, None] - fvol_ref).abs()
+    return fvol_ref, cost_ref, mask_ref
+
+
+def _motion_family(N, D, kind, seed):
+    """Incremental homographies with a prescribed inter-plane motion on the 16x32 grid (H = their running product)."""
+    g = torch.Generator().manual_seed(seed)
+    Hinc = torch.eye(3).repeat(N, D, 1, 1)
+    for n in range(N):
+        for d in range(1, D):
+            if kind == "small":            # within the banded form's gather window (about a pixel per plane, any direction)
+                Hinc[n, d, 0, 2] = float(torch.rand(1, generator=g)) * 2 - 1
+                Hinc[n, d, 1, 2] = float(torch.rand(1, generator=g)) * 2 - 1
+            elif kind == "vertical":       # 3-6 rows per plane: beyond the window, every tap from the hand-off granules
+                Hinc[n, d, 1, 2] = (3 + 3 * float(torch.rand(1, generator=g))) * (1 if d % 2 else -1)
+                Hinc[n, d, 0, 2] = float(torch.rand(1, generator=g)) - 0.5
+            elif kind == "mixed":          # alternates between the two paths, with shear / scale and projective terms
+                big = d % 3 == 0
+                Hinc[n, d, 1, 2] = (5.0 if big else 0.7) * (1 if d % 2 else -1)
+                Hinc[n, d, 0, 1] = 0.05 * (float(torch.rand(1, generator=g)) - 0.5)
+                Hinc[n, d, 1, 1] = 1.0 + 0.1 * (float(torch.rand(1, generator=g)) - 0.5)
+                Hinc[n, d, 2, 0] = 1e-3 * (float(torch.rand(1, generator=g)) - 0.5)
+    H = torch.eye(3).repeat(N, D, 1, 1)
+    for d in range(1, D):
+        H[:, d] = H[:, d - 1] @ Hinc[:, d]
+    return H, Hinc
+
+
+@pytest.mark.parametrize("kind,N,D", [("small", 1, 12), ("vertical", 2, 10), ("mixed", 3, 13), ("small", 8, 6)])
+def test_banded_chain_gather_paths_vs_oracle(kind, N, D):
+    """The banded form's two gather paths (rows fetched into the LDS window / every tap from the granules) against the
+    oracle's recurrence AND against the plane-resident Winograd kernel on the same inputs."""
+    w = load_weights("gta_sfm_150epochs")
+    net = net_for("gta_sfm_150epochs")
+    eng = net.engine()
+    g = torch.Generator().manual_seed(5)
+    H, Hinc = _motion_family(N, D, kind, seed=3)
+    src4 = torch.rand(N, 3, 16, 32, generator=g) * 2 - 1
+    F0 = torch.randn(N, 32, 16, 32, generator=g)
+    FL = torch.randn(N, 32, 16, 32, generator=g)
+    fvol_ref, cost_ref, mask_ref = _oracle_chain(w, src4, H, Hinc, F0, FL)
+    dev = [x.to(DEV) for x in (src4, H, Hinc, F0, FL)]
+    got = {}
+    try:
+        for form in ("banded", "winograd"):
+            net.options.chain_form = form
+            cost, mask, fvol = eng.incremental_cost_volume(*dev, want_features=True)
+            assert eng.chain_status() == 0
+            got[form] = (cost.cpu(), mask.cpu(), fvol.cpu())
+    finally:
+        net.options.chain_form = "auto"
+    for form, (cost, mask, fvol) in got.items():
+        assert int((mask != mask_ref).sum()) == 0, form
+        for name, a, b in (("features", fvol, fvol_ref), ("cost", cost, cost_ref)):
+            mean_rel, max_rel = rel_err(a, b)
+            print(f"chain[{form}] {kind} N={N} D={D} {name}: mean-rel {mean_rel:.3e} max-rel {max_rel:.3e}")
+            assert mean_rel < 1e-5 and max_rel < 1e-4, (form, name, mean_rel, max_rel)
+    assert torch.equal(got["banded"][1], got["winograd"][1])
+
+
+def test_banded_chain_hand_offs_under_uneven_load():
+    """The inter-workgroup hand-offs (tagged granules) must not depend on timing or placement: the same launch
+    repeated while a second stream keeps part of the chip busy with streaming copies of varying size must return
+    bit-identical volumes every time (every word compared), and no wait may time out."""
+    net = net_for("gta_sfm_150epochs")
+    eng = net.engine()
+    N, D = 5, 64
+    g = torch.Generator().manual_seed(9)
+    H, Hinc = _motion_family(N, D, "small", seed=4)
+    dev = [x.to(DEV) for x in (torch.rand(N, 3, 16, 32, generator=g) * 2 - 1, H, Hinc,
+                               torch.randn(N, 32, 16, 32, generator=g), torch.randn(N, 32, 16, 32, generator=g))]
+    net.options.chain_form = "banded"
+    try:
+        cost0, mask0, fvol0 = eng.incremental_cost_volume(*dev, want_features=True)
+        torch.cuda.synchronize()
+        assert eng.chain_status() == 0
+        side = torch.cuda.Stream()
+        big = torch.empty(64 << 20, dtype=torch.float32, device=DEV)
+        for it in range(12):
+            with torch.cuda.stream(side):
+                for k in range(1 + it % 4):
+                    n = (8 + 8 * ((it + k) % 7)) << 20
+                    big[:n].add_(1.0)
+            cost, mask, fvol = eng.incremental_cost_volume(*dev, want_features=True)
+            torch.cuda.synchronize()
+            assert eng.chain_status() == 0
+            assert torch.equal(cost, cost0) and torch.equal(mask, mask0) and torch.equal(fvol, fvol0), it
+    finally:
+        net.options.chain_form = "auto"
 
 
 def _forward(net, fix, smooth=False, **kw):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the fused chain alone (mvsn_incremental_cost_volume) in both forms: ms per launch, us per step,
+"""Time the fused chain alone (mvsn_incremental_cost_volume) in its forms: ms per launch, us per step,
 algorithmic TFLOP/s and GB/s.   python tools/chain_bench.py [N ...]   (N = chains per launch; default 2 and 256)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,7 +19,9 @@ for N in [int(a) for a in sys.argv[1:]] or [2, 256]:
     Hinc = torch.eye(3).repeat(N, D, 1, 1); Hinc[:, 1:, 0, 2] = 12.0 / (D - 1)
     F0 = torch.randn(N, 32, rows, cols, generator=g).cuda(); FL = torch.randn(B, 32, rows, cols, generator=g).cuda()
     H, Hinc = H.cuda(), Hinc.cuda()
-    for form in ("direct", "winograd"):
+    for form in ("direct", "winograd", "banded"):
+        if form == "banded" and N * 4 > 256:
+            continue
         net.options.chain_form = form
         for _ in range(3):
             eng.incremental_cost_volume(src4, H, Hinc, F0, FL)
@@ -34,4 +36,4 @@ for N in [int(a) for a in sys.argv[1:]] or [2, 256]:
         flops = N * (D - 1) * 2.0 * 9 * 32 * 99 * P
         nbytes = N * (4.0 * 67 * P + 128.0 * D * P + D * P)
         print(f"N={N:4d} {form:8s}: {ms:7.3f} ms/launch  {ms * 1e3 / (D - 1):6.1f} us/step  "
-              f"{flops / ms / 1e9:6.1f} direct-form TFLOP/s  {nbytes / ms / 1e6:7.1f} GB/s algorithmic")
+              f"{flops / ms / 1e9:6.1f} direct-form TFLOP/s  {nbytes / ms / 1e6:7.1f} GB/s algorithmic  status {eng.chain_status()}")
