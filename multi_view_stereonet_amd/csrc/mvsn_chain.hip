@@ -585,7 +585,7 @@ extern "C" size_t mvsn_incremental_cost_volume_workspace_bytes(int n_chains, int
 // What MVSN_CHAIN_AUTO resolves to for this many chains on this coarse grid.
 static int chain_auto_form(int n_chains, int rows, int cols) {
   // few chains on the 16x32 grid: four workgroups per chain while they all fit the chip at once
-  if (mvsn::chain_band_supported(rows, cols) && n_chains * mvsn::chain_band_groups() <= mvsn::device_cus() / 4)
+  if (mvsn::chain_band_supported(rows, cols) && n_chains * mvsn::chain_band_groups() <= mvsn::device_cus())
     return MVSN_CHAIN_BANDED;
   if (mvsn::chain_wino_supported(rows, cols)) return MVSN_CHAIN_WINOGRAD;
   // no plane-resident plan: one workgroup per chain leaves the chip idle below ~one chain per CU

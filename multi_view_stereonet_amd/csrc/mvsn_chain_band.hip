@@ -36,6 +36,8 @@
 //
 // LDS (floats):  U 18432 (one layer's transformed weights, LDS-DMA'd per layer exactly as in chain_wino_kernel)
 //                sparams 224 | red 64 (the 4 x 4 waves' GroupNorm records of a hand-off) | range 16 | maskb 128
+//                tab 192 x 8: per pixel of rows lo-1 .. hi+1 the bilinear footprint of its incremental-homography
+//                      gather (4 weights, window offset, row step, y0, x0), computed ONCE per pixel a step ahead
 //                act 36 x 224: layer input planes, 6 rows (band + one halo row either side) x 34, channel stride
 //                      224 = 32 (mod 64) so that the B-fragment reads of neighbouring channels use different banks
 //                win 32 x 376: gather window = feature rows lo-3 .. hi+4 of the previous plane (own band written by
@@ -52,7 +54,8 @@ constexpr int CB_CSA = 224;                                  // channel stride o
 constexpr int CB_W = 3, CB_WSLOTS = CB_BR + 2 * CB_W + 1;    // gather window: rows lo-3 .. hi+4 (11 slots)
 constexpr int CB_CSW = 376;                                  // channel stride of the window (11 * 34 = 374, padded)
 constexpr int CB_RED = 64, CB_RANGE = 16, CB_MASK = CB_BR * CB_COLS;
-constexpr int CB_LDS_FLOATS = CW_U0_FLOATS + CH_SP_FLOATS + CB_RED + CB_RANGE + CB_MASK + 36 * CB_CSA + 32 * CB_CSW;
+constexpr int CB_TAB = (CB_BR + 2) * CB_COLS * 8;            // bilinear footprints of the step's gathers, 8 words per pixel
+constexpr int CB_LDS_FLOATS = CW_U0_FLOATS + CH_SP_FLOATS + CB_RED + CB_RANGE + CB_MASK + CB_TAB + 36 * CB_CSA + 32 * CB_CSW;
 constexpr float CB_GN_EPS = 1e-5f;
 
 // granule workspace of one chain (u64 units)
@@ -66,6 +69,7 @@ typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
 typedef float float2v __attribute__((ext_vector_type(2)));
+typedef int intx4 __attribute__((ext_vector_type(4)));
 #define CB_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 #define CB_GPTR(p) ((const __attribute__((address_space(1))) void *)(p))
 #define CB_LPTR(p) ((__attribute__((address_space(3))) void *)(p))
@@ -147,7 +151,9 @@ __device__ __forceinline__ void band_layer(const float *__restrict__ act, const 
         v[i * 4 + 3] = t[i][1] - t[i][3];
       }
       if (c4 + 1 < NC) fetch(cur ^ 1, c4 + 1);
+#if CB_SCHED == 0
       __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int xq = 0; xq < 2; ++xq)
 #pragma unroll
@@ -155,6 +161,108 @@ __device__ __forceinline__ void band_layer(const float *__restrict__ act, const 
           const floatx4 c0 = c4 == 0 ? floatx4{0.f, 0.f, 0.f, 0.f} : acc[xq * 4 + j];
           acc[xq * 4 + j] = mfma16x16x4(u[cur][xq][j], v[xq * 4 + j], c0);
         }
+#if CB_SCHED == 0
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float s0[4], s1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (half == 0) {
+          s0[j] = acc[j][r] + acc[4 + j][r];
+          s1[j] = acc[4 + j][r];
+        } else {
+          s0[j] = acc[j][r];
+          s1[j] = -acc[j][r] - acc[4 + j][r];
+        }
+      }
+      const float y0 = s0[0] + s0[1] + s0[2], y1 = s0[1] - s0[2] - s0[3];
+      const float y2 = s1[0] + s1[1] + s1[2], y3 = s1[1] - s1[2] - s1[3];
+      if (half == 0) y[r][0] = y0, y[r][1] = y1, y[r][2] = y2, y[r][3] = y3;
+      else y[r][0] += y0, y[r][1] += y1, y[r][2] += y2, y[r][3] += y3;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+#ifndef CB_SCHED
+#define CB_SCHED 0
+#endif
+#if CB_SCHED == 2
+// Variant: one wave per SIMD has nobody to fill the matrix pipe while it transforms, so the NEXT k-step's input
+// transform (16 VALU) and the LDS reads of the k-step after it are interleaved with the current k-step's 8 multiplies
+// (program order MFMA, 2 VALU, 1 DS read, ... pinned with sched_group_barrier).
+template <int NC>
+__device__ __forceinline__ void band_layer_il(const float *__restrict__ act, const float *__restrict__ U, int ct, int wb,
+                                              int lane, float (&y)[4][4]) {
+  const float *wbase = act + (lane >> 4) * CB_CSA + wb;
+  const float *ub = U + ct * 1024 + lane * 4;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    floatx4 acc[8];
+    float d[3][3][4];
+    floatx4 u[2][2];
+    float v[2][8];
+    auto fetch_d = [&](int buf, int c4) {
+      const float *wp = wbase + c4 * 4 * CB_CSA + half * CB_RS;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float2 lo = *reinterpret_cast<const float2 *>(wp + i * CB_RS);
+        const float2 hi = *reinterpret_cast<const float2 *>(wp + i * CB_RS + 2);
+        d[buf][i][0] = lo.x, d[buf][i][1] = lo.y, d[buf][i][2] = hi.x, d[buf][i][3] = hi.y;
+      }
+    };
+    auto fetch_u = [&](int buf, int c4) {
+#pragma unroll
+      for (int xq = 0; xq < 2; ++xq)
+        u[buf][xq] = *reinterpret_cast<const floatx4 *>(ub + (c4 * 8 + half * 2 + xq) * 256);
+    };
+    auto transform = [&](int vb, int db) {
+      float t[2][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (half == 0) {
+          t[0][j] = d[db][0][j] - d[db][2][j];
+          t[1][j] = d[db][1][j] + d[db][2][j];
+        } else {
+          t[0][j] = d[db][1][j] - d[db][0][j];
+          t[1][j] = d[db][0][j] - d[db][2][j];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        v[vb][i * 4 + 0] = t[i][0] - t[i][2];
+        v[vb][i * 4 + 1] = t[i][1] + t[i][2];
+        v[vb][i * 4 + 2] = t[i][2] - t[i][1];
+        v[vb][i * 4 + 3] = t[i][1] - t[i][3];
+      }
+    };
+    fetch_d(0, 0);
+    fetch_u(0, 0);
+    if (NC > 1) fetch_d(1, 1);
+    transform(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c4 = 0; c4 < NC; ++c4) {
+      const int cur = c4 & 1;
+      if (c4 + 1 < NC) transform(cur ^ 1, (c4 + 1) % 3);
+      if (c4 + 2 < NC) fetch_d((c4 + 2) % 3, c4 + 2);
+      if (c4 + 1 < NC) fetch_u(cur ^ 1, c4 + 1);
+#pragma unroll
+      for (int xq = 0; xq < 2; ++xq)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const floatx4 c0 = c4 == 0 ? floatx4{0.f, 0.f, 0.f, 0.f} : acc[xq * 4 + j];
+          acc[xq * 4 + j] = mfma16x16x4(u[cur][xq][j], v[cur][xq * 4 + j], c0);
+        }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
@@ -178,6 +286,8 @@ __device__ __forceinline__ void band_layer(const float *__restrict__ act, const 
     __builtin_amdgcn_sched_barrier(0);
   }
 }
+#define band_layer band_layer_il
+#endif
 
 // sums of two values over the 32 lanes of each half-wave; the totals land in lanes 16..31 / 48..63
 __device__ __forceinline__ void cb_half_wave_sums(float (&s)[2]) {
@@ -224,7 +334,9 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
   float *red = sparams + CH_SP_FLOATS;
   int *range = reinterpret_cast<int *>(red + CB_RED);       // [parity][min y0, max y0 + 1]
   float *maskb = red + CB_RED + CB_RANGE;
-  float *act = maskb + CB_MASK;
+  float *tab = maskb + CB_MASK;
+  int *tabi = reinterpret_cast<int *>(tab);
+  float *act = tab + CB_TAB;
   float *win = act + 36 * CB_CSA;
 
   gu64 *ws = (gu64 *)(reinterpret_cast<u64 *>(a.workspace) + (size_t)n * CB_CHAIN_U64);
@@ -290,17 +402,21 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
     const bool out[4] = {m0.x != 0.0f, m0.y != 0.0f, m1.x != 0.0f, m1.y != 0.0f};
     float *cd = costg + (size_t)d * P;
     float *fd = fvolg ? fvolg + (size_t)d * P : nullptr;
+    // the granules first: the other bands wait for them, everything else of the epilogue travels meanwhile
+    if (d + 1 < D) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float *dst = win + (cbase + r) * CB_CSW + (CB_W + 2 * pt) * RS + px0 + 1;
-      dst[0] = f[r][0], dst[1] = f[r][1], dst[RS] = f[r][2], dst[RS + 1] = f[r][3];
-      gu64 *g = Fg + (size_t)(cbase + r) * P + py0 * cols + px0;
-      if (d + 1 < D) {
+      for (int r = 0; r < 4; ++r) {
+        gu64 *g = Fg + (size_t)(cbase + r) * P + py0 * cols + px0;
         cb_publish(g, d + 1, f[r][0]);
         cb_publish(g + 1, d + 1, f[r][1]);
         cb_publish(g + cols, d + 1, f[r][2]);
         cb_publish(g + cols + 1, d + 1, f[r][3]);
       }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float *dst = win + (cbase + r) * CB_CSW + (CB_W + 2 * pt) * RS + px0 + 1;
+      dst[0] = f[r][0], dst[1] = f[r][1], dst[RS] = f[r][2], dst[RS + 1] = f[r][3];
       float *cdst = cd + (r * D) * P + slice_off;
 #pragma unroll
       for (int a2 = 0; a2 < 2; ++a2) {
@@ -354,69 +470,80 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
 
 #define CB_STAMP(i)                                                                                     \
   do {                                                                                                  \
-    if (a.dbg && blockIdx.x == 0 && tid == 0 && d >= 2 && d <= 5) a.dbg[(d - 2) * 16 + (i)] = __builtin_readcyclecounter(); \
+    if (a.dbg && blockIdx.x == 0 && tid == 0 && d >= 2 && d <= 5) a.dbg[(d - 2) * 32 + (i)] = __builtin_readcyclecounter(); \
   } while (0)
+
+  // Everything of a step that does not depend on the previous plane's features -- the image plane of rows
+  // lo-1 .. hi+1 with the band's mask (A1: global gathers from the 6 KB source image) and where the incremental
+  // homography sends this thread's pixels (A2: own 2x2 patch + one halo pixel; bilinear weights, window offsets,
+  // and the rows of the previous plane the band's gathers touch) -- is computed one step AHEAD, inside the wait of
+  // the previous step's second hand-off (between publishing and the first poll), where the workgroup would idle.
+  float img[3] = {0.f, 0.f, 0.f}, mk = 0.f;
+  auto prepare = [&](int dn) {
+    int ymin = 1 << 20, ymax = -1;
+    if (ivalid) {
+      float Hl[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Hl[i] = Hn[dn * 9 + i];
+      {
+        WarpCoord c = warp_coord(Hl, (float)ixx, (float)iy, (float)rows, (float)cols);
+        Bilinear b = bilinear_taps(c.ix, c.iy, rows, cols);
+        const float keep = c.outside ? 0.0f : 1.0f;
+        mk = c.outside ? 1.0f : 0.0f;
+        const int o00 = b.y0 * cols + b.x0, o01 = b.y0 * cols + b.x1, o10 = b.y1 * cols + b.x0, o11 = b.y1 * cols + b.x1;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          const float *ic = src + (size_t)ch * P;
+          img[ch] = keep * (ic[o00] * b.w00 + ic[o01] * b.w01 + ic[o10] * b.w10 + ic[o11] * b.w11);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Hl[i] = Hin[dn * 9 + i];
+      WarpCoord c = warp_coord(Hl, (float)ixx, (float)iy, (float)rows, (float)cols);
+      Bilinear b = bilinear_taps(c.ix, c.iy, rows, cols);
+      const float keep = c.outside ? 0.0f : 1.0f;
+      floatx4 w4;
+      intx4 i4;
+      w4[0] = keep * b.w00, w4[1] = keep * b.w01, w4[2] = keep * b.w10, w4[3] = keep * b.w11;
+      i4[0] = (b.y0 - wlo) * RS + b.x0 + 1;
+      i4[1] = (b.y1 - b.y0) * RS;   // 0 where the +1 row is clamped (its weight is exactly zero there)
+      i4[2] = b.y0;
+      i4[3] = b.x0;
+      *reinterpret_cast<floatx4 *>(tab + tid0 * 8) = w4;
+      *reinterpret_cast<intx4 *>(tabi + tid0 * 8 + 4) = i4;
+      ymin = b.y0, ymax = b.y1;
+    }
+    cb_wave_minmax(ymin, ymax);
+    if (lane == 0) {
+      atomicMin(&range[(dn & 1) * 2], ymin);
+      atomicMax(&range[(dn & 1) * 2 + 1], ymax);
+    }
+  };
+  if (D > 1) prepare(1);
+  cb_barrier();   // step 1's row range is complete; plane 0 sits in the window
 
   // ---- the recurrence ------------------------------------------------------------------------
   for (int d = 1; d < D; ++d) {
     asm volatile("" : "+v"(tid), "+v"(lane16), "+v"(slice_off));
     const int par = d & 1;
     CB_STAMP(0);
-
-    // A1: image plane d on rows lo-1 .. hi+1 and the band's mask (global gathers; the 6 KB source stays in L1/L2)
-    float img[3] = {0.f, 0.f, 0.f}, mk = 0.f;
-    if (ivalid) {
-      float Hl[9];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) Hl[i] = Hn[d * 9 + i];
-      WarpCoord c = warp_coord(Hl, (float)ixx, (float)iy, (float)rows, (float)cols);
-      Bilinear b = bilinear_taps(c.ix, c.iy, rows, cols);
-      const float keep = c.outside ? 0.0f : 1.0f;
-      mk = c.outside ? 1.0f : 0.0f;
-      const int o00 = b.y0 * cols + b.x0, o01 = b.y0 * cols + b.x1, o10 = b.y1 * cols + b.x0, o11 = b.y1 * cols + b.x1;
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        const float *ic = src + (size_t)ch * P;
-        img[ch] = keep * (ic[o00] * b.w00 + ic[o01] * b.w01 + ic[o10] * b.w10 + ic[o11] * b.w11);
-      }
-    }
-
-    // A2: where the incremental homography sends this thread's pixels (own 2x2 patch + one halo pixel), and which
-    // rows of the previous plane the band's gathers touch
-    float Hl[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) Hl[i] = Hin[d * 9 + i];
-    float tw[5][4];
-    int to[5], tdy[5], ty[5], tx[5];
-    int ymin = 1 << 20, ymax = -1;
-#pragma unroll
-    for (int e = 0; e < 5; ++e) {
-      const float px = e < 4 ? (float)(px0 + (e & 1)) : (float)hx;
-      const float py = e < 4 ? (float)(py0 + (e >> 1)) : (float)hy;
-      WarpCoord c = warp_coord(Hl, px, py, (float)rows, (float)cols);
-      Bilinear b = bilinear_taps(c.ix, c.iy, rows, cols);
-      const float keep = c.outside ? 0.0f : 1.0f;
-      tw[e][0] = keep * b.w00, tw[e][1] = keep * b.w01, tw[e][2] = keep * b.w10, tw[e][3] = keep * b.w11;
-      to[e] = (b.y0 - wlo) * RS + b.x0 + 1;
-      tdy[e] = (b.y1 - b.y0) * RS;   // 0 where the +1 row is clamped (its weight is exactly zero there)
-      ty[e] = b.y0, tx[e] = b.x0;
-      if (e < 4 || hvalid) {
-        ymin = min(ymin, b.y0);
-        ymax = max(ymax, b.y1);
-      }
-    }
-    cb_wave_minmax(ymin, ymax);
-    if (lane == 0) {
-      atomicMin(&range[par * 2], ymin);
-      atomicMax(&range[par * 2 + 1], ymax);
-    }
-    CB_STAMP(1);
-    cb_barrier();   // B1: the range is complete; the previous epilogue's window rows are in place
+    // (the range of this step was completed during the previous step, two barriers ago)
     const int need_lo = range[par * 2], need_hi = range[par * 2 + 1];
-    if (tid == 0) range[(par ^ 1) * 2] = 1 << 20, range[(par ^ 1) * 2 + 1] = -1;
     const bool fast = !(flags & 1) && need_lo >= wlo && need_hi <= wlo + CB_WSLOTS - 1;   // workgroup-uniform
 
     float fp[4][4], hv[8];
+    float tw[5][4];
+    int to[5], tdy[5], ty[5], tx[5];
+    auto footprints = [&]() {   // this thread's five pixels: own 2x2 patch (ext rows 1 + 2pt + a) and one halo pixel
+#pragma unroll
+      for (int e = 0; e < 5; ++e) {
+        const int pix = e < 4 ? (1 + 2 * pt + (e >> 1)) * cols + px0 + (e & 1) : (hs ? CB_BR + 1 : 0) * cols + hx;
+        const floatx4 w4 = *reinterpret_cast<const floatx4 *>(tab + pix * 8);
+        const intx4 i4 = *reinterpret_cast<const intx4 *>(tabi + pix * 8 + 4);
+        tw[e][0] = w4[0], tw[e][1] = w4[1], tw[e][2] = w4[2], tw[e][3] = w4[3];
+        to[e] = i4[0], tdy[e] = i4[1], ty[e] = i4[2], tx[e] = i4[3];
+      }
+    };
     if (fast) {
       // E1 (consume): rows of F_{d-1} the gathers need from the neighbours -> window.  Thread: column tid & 31,
       // channels (tid >> 5) + 8 j.  Up to 7 rows, all loads in flight before the first tag is looked at.
@@ -459,6 +586,7 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
             for (int j = 0; j < 4; ++j) win[(fc + 8 * j) * CB_CSW + slot_of[s] * RS + fx + 1] = v[s][j];
           }
       }
+      footprints();
       CB_STAMP(2);
       cb_barrier();   // B2: window complete
       // A2 gather.  The +1 column tap is read unclamped: where the clamp would act its weight is exactly zero and the
@@ -481,6 +609,7 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
       }
     } else {
       // the gathers reach beyond the window (large inter-plane motion): every tap straight from the granules
+      footprints();
 #pragma unroll
       for (int e = 0; e < 5; ++e) {
         const bool act_e = e < 4 || hvalid;
@@ -508,6 +637,7 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
       }
       cb_barrier();   // (keeps the barrier count of the two paths equal)
     }
+    if (tid == 0) range[par * 2] = 1 << 20, range[par * 2 + 1] = -1;   // (read by everyone before B2; next use: step d+2)
     CB_STAMP(3);
 
     // A3: lay out the refiner input [image(3) | moved features(32)] on rows lo-1 .. hi+1
@@ -543,7 +673,7 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
     // E2 / E3: bias, partial GroupNorm sums (shifted by the previous step's mean, as chain_wino_kernel), publish
     // them with the band's boundary rows; collect the other bands'; normalise + activate own outputs and halo rows
     auto exchange = [&](int layer, const float *bias, const float *gamma, const float *beta, float (&shift)[2],
-                        bool residual) {
+                        bool residual, auto &&meanwhile) {
       float s[2] = {0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -573,19 +703,43 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
           cb_publish(g + r * cols + 1, d, y[r][pt * 2 + 1]);
         }
       }
-      // collect: wave 0 the 64 sum granules (one per lane), every thread its 8 halo granules
-      if (wave == 0) {
-        float v[1];
-        cb_sweep<1>([&](int) { return Sl + lane; }, d, true, v, dead, status);
-        red[lane] = v[0];
-      }
+      CB_STAMP(16 + layer * 4);
+      meanwhile();   // work that needs none of the hand-off, placed where the workgroup would otherwise only wait
+      CB_STAMP(17 + layer * 4);
+      // collect, ONE sweep: every thread its 8 halo granules, wave 0 also the 64 sum granules (one per lane)
       float hr[8];
       {
         // the neighbour's row facing this band: its last row (side 1) for our row lo-1, its first (side 0) for hi+1
         const gu64 *g = Rl + ((size_t)(hnb * 2 + (hs ? 0 : 1)) * 32 + hcg * 8) * cols + hx;
-        cb_sweep<8>([&](int j) { return g + j * cols; }, d, hvalid, hr, dead, status);
+        float sv = 0.f;
+        for (unsigned spins = 0;; ++spins) {
+          bool ok = true;
+          if (wave == 0) {
+            const u64 x = __hip_atomic_load(Sl + lane, CB_RLX_AGENT);
+            sv = __builtin_bit_cast(float, (unsigned)x);
+            ok &= (unsigned)(x >> 32) == (unsigned)d;
+          }
+          if (hvalid) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const u64 x = __hip_atomic_load(g + j * cols, CB_RLX_AGENT);
+              hr[j] = __builtin_bit_cast(float, (unsigned)x);
+              ok &= (unsigned)(x >> 32) == (unsigned)d;
+            }
+          }
+          if (__all(ok) || dead) break;
+          if (spins >= CB_SPIN_LIMIT) {
+            dead = true;
+            __hip_atomic_store(status, 3u + layer, CB_RLX_AGENT);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (wave == 0) red[lane] = sv;
       }
+      CB_STAMP(18 + layer * 4);
       cb_barrier();
+      CB_STAMP(19 + layer * 4);
       // totals in a fixed order (band-major): every workgroup of the chain forms the same statistics bit for bit
       float sc[2], sh2[2];   // [0] own group, [1] halo group: rstd and mean
 #pragma unroll
@@ -633,7 +787,7 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
         }
       }
     };
-    exchange(0, bias0, gn0w, gn0b, shift0, false);
+    exchange(0, bias0, gn0w, gn0b, shift0, false, [] {});
     CB_STAMP(6);
     dma_landed();
     cb_barrier();   // B6
@@ -643,7 +797,9 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
     CB_STAMP(8);
     cb_barrier();   // B7
     dma_u(upk + CW_U0_FLOATS + CW_U1_FLOATS, 8);
-    exchange(1, bias1, gn1w, gn1b, shift1, true);   // x2 = x1 + LReLU(GN(conv1(x1)))
+    exchange(1, bias1, gn1w, gn1b, shift1, true, [&] {   // x2 = x1 + LReLU(GN(conv1(x1)))
+      if (d + 1 < D) prepare(d + 1);
+    });
     CB_STAMP(9);
     dma_landed();
     cb_barrier();   // B10

@@ -109,8 +109,8 @@ class EngineOptions:
         self.cat_free_heads = True         # refiner heads read [image, features, idepth] in place (no torch.cat)
         # The fused chain's three 3x3 convolutions: "auto" = Winograd F(2x2,3x3) where the coarse grid has a plan
         # (16x32 at 512x256 frames); elsewhere one plane per round of full-chip launches ("stepwise") while fewer
-        # chains than CUs are in flight, the fused direct implicit GEMM otherwise; on the 16x32 grid with at most 16
-        # chains (batch 1 .. 8 at two sources) one chain runs on FOUR workgroups ("banded").  "direct" / "winograd" /
+        # chains than CUs are in flight, the fused direct implicit GEMM otherwise; on the 16x32 grid with at most 64
+        # chains (4 workgroups each: all co-resident on the 256 CUs) one chain runs on FOUR workgroups ("banded").  "direct" / "winograd" /
         # "stepwise" / "banded" force one form.
         self.chain_form = "auto"
         # Refiner towers on two batch slices, software-pipelined: slice B's convolution (matrix-pipe-bound) carries

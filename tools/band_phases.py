@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Tuning aid: per-phase cycle counts of the banded chain kernel (block 0, thread 0) for steps 2..5.
+Needs a tuning build: MVSN_HIPCC_FLAGS=-DMVSN_CHAIN_STAMPS python -m multi_view_stereonet_amd.build --force"""
+import os, sys, ctypes, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multi_view_stereonet_amd import MultiViewStereoNet, _native
+from multi_view_stereonet_amd.weights import load_weights
+torch.set_grad_enabled(False)
+dbg = torch.zeros(256, dtype=torch.int64, device="cuda")
+ctypes.CDLL(_native.library_path()).mvsn_debug_set_chain_stamps(ctypes.c_void_p(dbg.data_ptr()))
+net = MultiViewStereoNet(); net.load_state_dict(load_weights("gta_sfm_150epochs")); net = net.cuda().eval()
+eng = net.engine()
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+rows, cols, D = 16, 32, 64
+g = torch.Generator().manual_seed(0)
+src4 = (torch.rand(N, 3, rows, cols, generator=g) * 2 - 1).cuda()
+H = torch.eye(3).repeat(N, D, 1, 1); H[:, :, 0, 2] = torch.linspace(0, 12, D)[None]
+Hinc = torch.eye(3).repeat(N, D, 1, 1); Hinc[:, 1:, 0, 2] = 12.0 / (D - 1)
+F0 = torch.randn(N, 32, rows, cols, generator=g).cuda(); FL = torch.randn(max(1, N // 2), 32, rows, cols, generator=g).cuda()
+net.options.chain_form = "banded"
+for _ in range(3):
+    eng.incremental_cost_volume(src4, H.cuda(), Hinc.cuda(), F0, FL)
+torch.cuda.synchronize()
+t = dbg.cpu()[:128].view(4, 32)
+# stamp -> what ended there
+order = [(0, "step start"), (2, "E1 fetch (poll + LDS writes)"), (3, "B2 + gather"), (4, "A3 layout + U wait + B3"), (5, "conv0"),
+         (16, "B4 + bias/sums/publish"), (17, "(meanwhile)"), (18, "sweep"), (19, "barrier"), (6, "stats + apply"),
+         (7, "U wait + B6"), (8, "conv1"), (20, "B7 + bias/sums/publish"), (21, "prepare(d+1)"), (22, "sweep"),
+         (23, "barrier"), (9, "stats + apply"), (10, "U wait + B10"), (11, "conv2 + left loads"), (12, "B11 + emit")]
+for d in range(4):
+    row = t[d]
+    out, prev = [], int(row[0])
+    for idx, name in order[1:]:
+        v = int(row[idx])
+        out.append(f"{name} {v - prev}")
+        prev = v
+    print("step", d + 2, "total", int(row[12] - row[0]), "|", "; ".join(out))
