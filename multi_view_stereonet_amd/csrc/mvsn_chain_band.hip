@@ -80,6 +80,17 @@ __device__ __forceinline__ void cb_publish(gu64 *g, unsigned tag, float v) {
   __hip_atomic_store(g, ((u64)tag << 32) | (u64)__builtin_bit_cast(unsigned, v), CB_RLX_AGENT);
 }
 
+// Two neighbouring granules (16-byte aligned pair) in ONE write-through store: half the fabric writes of a publish.
+// Each 8-byte half is still a self-contained {value, tag} granule for the reader (8-byte halves of a 16-byte sc1
+// store are observed untorn on gfx950, MI355X_MICROARCH.md section "inter-workgroup visibility"; a torn PAIR is
+// harmless, the reader checks each granule's own tag).
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void cb_publish2(gu64 *g, unsigned tag, float v0, float v1) {
+  uintx4 q;
+  q[0] = __builtin_bit_cast(unsigned, v0), q[1] = tag, q[2] = __builtin_bit_cast(unsigned, v1), q[3] = tag;
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(g), "v"(q) : "memory");
+}
+
 // Re-read this lane's N granules until every tag in the wave matches.  `addr(j)` = granule j of this lane; lanes
 // with !active take no part.  Returns with v[] filled; after a time-out (recorded in *status) it gives up at once.
 template <int N, class Addr>
@@ -407,10 +418,8 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         gu64 *g = Fg + (size_t)(cbase + r) * P + py0 * cols + px0;
-        cb_publish(g, d + 1, f[r][0]);
-        cb_publish(g + 1, d + 1, f[r][1]);
-        cb_publish(g + cols, d + 1, f[r][2]);
-        cb_publish(g + cols + 1, d + 1, f[r][3]);
+        cb_publish2(g, d + 1, f[r][0], f[r][1]);
+        cb_publish2(g + cols, d + 1, f[r][2], f[r][3]);
       }
     }
 #pragma unroll
@@ -690,8 +699,7 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
       gu64 *Sl = Sg + (size_t)layer * (CB_G * CB_WAVES * 4);
       if ((lane & 31) == 16) {
         gu64 *g = Sl + (m * CB_WAVES + wave) * 4 + (lane >> 5) * 2;
-        cb_publish(g, d, s[0]);
-        cb_publish(g + 1, d, s[1]);
+        cb_publish2(g, d, s[0], s[1]);
       }
       // boundary rows: patch row 0 holds the band's first pixel row (e = 0, 1), patch row 1 its last (e = 2, 3)
       gu64 *Rl = Rg + (size_t)layer * (CB_G * 2 * 32 * cols);
@@ -699,8 +707,7 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
         gu64 *g = Rl + ((size_t)(m * 2 + pt) * 32 + cbase) * cols + px0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          cb_publish(g + r * cols, d, y[r][pt * 2]);
-          cb_publish(g + r * cols + 1, d, y[r][pt * 2 + 1]);
+          cb_publish2(g + r * cols, d, y[r][pt * 2], y[r][pt * 2 + 1]);
         }
       }
       CB_STAMP(16 + layer * 4);
