@@ -35,8 +35,49 @@ ROWS, COLS, D, S = 256, 512, 64, 2
 WEIGHTS = "gta_sfm_150epochs"
 GOLDEN = os.path.join(ROOT, "tests", "golden", "g2_gta_512x256_d64_s2.npz")
 GOLDEN_SEED = 7
+# BASELINE.json's configs (config 1 is the CPU plumbing case).  `--config` selects the workload of the timed region;
+# the default line (headline = the configuration the metric is quoted on) also carries the others as `other_configs`.
+# `batch` = reference images per GPU per step; config 3 is stated as batch 8 over 8 GPUs = ONE image per rank.
+# Every config has a reference-generated fixture whose input is image 0 of rank 0 (seed = the fixture's).
+CONFIGS = {
+    "headline": dict(rows=256, cols=512, D=64, S=2, weights="gta_sfm_150epochs", golden="g2_gta_512x256_d64_s2.npz",
+                     batch=128, what="GTA-SfM-shaped 512x256, D=64 hypotheses, 2 source views, cost-volume filter + 5 refiners"),
+    "config2": dict(rows=256, cols=512, D=64, S=1, weights="gta_sfm_150epochs", golden="gc2_gta_512x256_d64_s1.npz",
+                    batch=128, what="BASELINE config 2: GTA-SfM 2-view, 512x256, D=64, 1 source view"),
+    "config3": dict(rows=256, cols=512, D=64, S=5, weights="gta_sfm_150epochs", golden="gc3_gta_512x256_d64_s5.npz",
+                    batch=1, what="BASELINE config 3: GTA-SfM 5-cmp, 512x256, D=64, 5 source views, ONE image per GPU "
+                                  "(batch 8 over 8 GPUs)"),
+    "config4": dict(rows=480, cols=640, D=96, S=1, weights="demon_45epochs", golden="g3_demon_640x480_d96_s1.npz",
+                    batch=32, what="BASELINE config 4: DeMoN 640x480, D=96, 1 source view, demon_45epochs weights"),
+    "config5": dict(rows=512, cols=1024, D=128, S=4, weights="gta_sfm_150epochs", golden="gc5_gta_1024x512_d128_s4.npz",
+                    batch=8, what="BASELINE config 5 geometry: 1024x512, D=128, 4 source views (fp32 throughout; the bf16 "
+                                  "tiers are reported by the headline line)"),
+}
+
+
+def config_inputs(cfg, batch, rank, device):
+    """B independent (image, S sources) sets of a config; image 0 of rank 0 is the golden fixture's input."""
+    import numpy as np
+    fix = np.load(os.path.join(ROOT, "tests", "golden", cfg["golden"]))
+    seed0, smooth = int(fix["meta"][5]), bool(fix["smooth"]) if "smooth" in fix.files else False
+    jitter = float(fix["jitter"]) if "jitter" in fix.files else 0.0
+    parts = [synthetic.make_batch(cfg["rows"], cfg["cols"], cfg["S"], batch=1, seed=seed0 + rank * batch + i,
+                                  smooth=smooth, pose_jitter=jitter) for i in range(batch)]
+    merged = {"left_image": torch.cat([p["left_image"] for p in parts], 0),
+              "right_image": [torch.cat([p["right_image"][s] for p in parts], 0) for s in range(cfg["S"])],
+              "K": torch.cat([p["K"] for p in parts], 0),
+              "T_right_in_left": [torch.cat([p["T_right_in_left"][s] for p in parts], 0) for s in range(cfg["S"])]}
+    return merged, snu.multi_view_unpack_batch(merged, device, 5), torch.from_numpy(fix["idepth_0"])
+
+
+def l1_against(ref0, got0, golden):
+    l1 = float((got0 - ref0).abs().mean())
+    return {"l1": l1, "mean_rel": l1 / float(ref0.abs().mean()),
+            "max_rel": float((got0 - ref0).abs().max() / ref0.abs().max()),
+            "reference": f"tests/golden/{golden} (reference PyTorch-CPU forward)"}
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 dense peak
 PEAK_HBM_GBS = 8000.0
+PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"   # the latest committed FETCH_SIZE / WRITE_SIZE pass (tools/prof_pmc.sh)
 
 
 def make_inputs(batch, first_seed, device):
@@ -50,16 +91,48 @@ def make_inputs(batch, first_seed, device):
     return merged, snu.multi_view_unpack_batch(merged, device, 5)
 
 
-def run_forward(net, inp):
-    return net(inp["left_image_pyr"], inp["K_pyr"], inp["T_right_in_left"], inp["right_image_pyr"], D, True,
+def run_forward(net, inp, d=D):
+    return net(inp["left_image_pyr"], inp["K_pyr"], inp["T_right_in_left"], inp["right_image_pyr"], d, True,
                [True] * 5)
 
 
-def kernel_breakdown(net, inp):
+def other_configs(dev, skip):
+    """BASELINE configs 2-5 at their stated sizes on this GPU: ms per forward at batch 1 and at the config's batch,
+    and the depth error of image 0 against the reference-generated fixture (same contract as the headline)."""
+    res = {}
+    for name, cfg in CONFIGS.items():
+        if name in skip:
+            continue
+        net = MultiViewStereoNet()
+        net.load_state_dict(load_weights(cfg["weights"]), strict=True)
+        net = net.to(dev).eval()
+        entry = {"workload": cfg["what"]}
+        for b in sorted({1, cfg["batch"]}):
+            _, inp, ref0 = config_inputs(cfg, b, 0, dev)
+            for _ in range(3):
+                out = run_forward(net, inp, cfg["D"])
+            torch.cuda.synchronize()
+            reps = 20 if b == 1 else 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                out = run_forward(net, inp, cfg["D"])
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / reps * 1e3
+            entry[f"B={b}"] = {"ms_per_forward": round(ms, 3), "depthmaps_per_s": round(b / ms * 1e3, 1)}
+            if b == 1:
+                entry["l1_vs_ref"] = l1_against(ref0, out["left_idepthmap_pyr"][0][:1].cpu(), cfg["golden"])
+            del inp, out
+        res[name] = entry
+        del net
+        torch.cuda.empty_cache()
+    return res
+
+
+def kernel_breakdown(net, inp, d=D):
     """One instrumented forward: per-kernel launch counts, device time, algorithmic flops/bytes."""
     eng = net.engine()
     eng.timeline = []
-    run_forward(net, inp)
+    run_forward(net, inp, d)
     torch.cuda.synchronize()
     tl, eng.timeline = eng.timeline, None
     agg = {}
@@ -72,17 +145,17 @@ def kernel_breakdown(net, inp):
     return agg
 
 
-def cpu_baseline(budget_s=15.0):
+def cpu_baseline(cfg, budget_s=15.0):
     """The oracle (CPU restatement of the reference forward) on the host cores, B=1, same workload."""
     from oracle import mvsn_oracle as oracle
-    w = load_weights(WEIGHTS)
-    batch = synthetic.make_batch(ROWS, COLS, S, batch=1, seed=GOLDEN_SEED)
-    inp = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
+    w = load_weights(cfg["weights"])
+    _, inp, _ = config_inputs(cfg, 1, 0, torch.device("cpu"))
     cores = os.cpu_count() or 1
 
     def once():
         t0 = time.time()
-        out = oracle.forward(w, inp["left_image_pyr"], inp["K_pyr"], inp["T_right_in_left"], inp["right_image_pyr"], D)
+        out = oracle.forward(w, inp["left_image_pyr"], inp["K_pyr"], inp["T_right_in_left"], inp["right_image_pyr"],
+                             cfg["D"])
         return time.time() - t0, out
 
     # torch's intra-op scaling on this small per-image problem peaks well below the core count; take the
@@ -102,8 +175,8 @@ def cpu_baseline(budget_s=15.0):
         times.append(dt)
     mean = sum(times) / len(times)
     return {"value": 1.0 / mean, "unit": "depthmaps/s", "cores": threads, "kind": "port",
-            "sample": f"{len(times)} forwards of 1 image (512x256, D=64, S=2, fp32, torch CPU, "
-                      f"{threads} threads of {cores} host cpus), mean {mean * 1e3:.1f} ms"}, out
+            "sample": f"{len(times)} forwards of 1 image ({cfg['cols']}x{cfg['rows']}, D={cfg['D']}, S={cfg['S']}, fp32, "
+                      f"torch CPU, {threads} threads of {cores} host cpus), mean {mean * 1e3:.1f} ms"}, out
 
 
 def self_launch(n):
@@ -149,11 +222,21 @@ def timed_steps(step, steps, warmup, world, sync, reduce_device):
     return max(per_rank), per_rank, out
 
 
+def gather_floats(x, world, device):
+    """One float per rank -> list over ranks (identity without a process group)."""
+    if world == 1:
+        return [float(x)]
+    mine = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    torch.distributed.all_gather(every, mine)
+    return [float(e.item()) for e in every]
+
+
 def launcher_selftest(args, rank, world):
     """`--launcher-selftest`: the launch / barrier / max-over-ranks / all-gather plumbing of this file on CPU
     ranks over gloo, with a stand-in step (NO forward, NO GPU).  Its line is labelled as such and is not a
     measurement; tests/test_bench_launcher_cpu.py runs it with --gpus 2."""
-    B = args.batch
+    B = args.batch or 4
 
     def step():
         return torch.full((B, 3), float(rank))
@@ -162,8 +245,13 @@ def launcher_selftest(args, rank, world):
     idx = torch.arange(rank * B, (rank + 1) * B)
     all_rows, all_idx = mdist.gather_metric_rows(rows, idx)
     assert all_rows.shape[0] == B * world and all_idx.tolist() == list(range(B * world))
+    # the per-rank quality fields travel the same way as in a real run (stand-in numbers: rank r reports frac 0.5 + r/10)
+    fracs = gather_floats(0.5 + rank / 10.0, world, torch.device("cpu"))
     if rank == 0:
-        print(json.dumps({"metric": "launcher self-test (no forward, not a measurement)", "value": 0.0,
+        skipped = {"skipped": "launcher self-test: no forward ran"}
+        print(json.dumps({"l1_vs_ref": skipped, "cpu_baseline": skipped, "chain_kernel": skipped,
+                          "roofline": {"frac": min(fracs), "frac_per_rank": fracs, "stand_in": True},
+                          "metric": "launcher self-test (no forward, not a measurement)", "value": 0.0,
                           "unit": "none", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "world_size": torch.distributed.get_world_size() if world > 1 else 1,
                           "backend": torch.distributed.get_backend() if world > 1 else "none",
@@ -257,13 +345,42 @@ def host_feed_rates(net, B, dev, steps=8):
                     "normalisation) and the forward; NOT the headline value (inputs resident in HBM)"}
 
 
+def evaluate_rate(net, B, dev, resident_value, steps=6):
+    """The evaluation loop at throughput grade (never `value`): metrics.evaluate over `steps` batches of B images that
+    live in pinned host memory with a ground-truth depth map each -- Prefetcher (copies of batch k+1 under batch k),
+    device-side unpack, forward, mvsn_depth_metrics (nine doubles per image stay on the device), one synchronisation
+    and one gather at the end.  Reported beside the resident-input rate it should approach."""
+    from multi_view_stereonet_amd import metrics
+    host, _ = make_inputs(B, GOLDEN_SEED, torch.device("cpu"))
+    pin = lambda t: t.pin_memory()   # noqa: E731
+    g = torch.Generator().manual_seed(5)
+    depth = pin(2.0 + 6.0 * torch.rand(B, 1, ROWS, COLS, generator=g))
+    batch = {"left_image": pin(host["left_image"]), "right_image": [pin(r) for r in host["right_image"]],
+             "K": pin(host["K"]), "T_right_in_left": [pin(t) for t in host["T_right_in_left"]],
+             "left_depthmap_true": depth, "right_depthmap_true": [depth] * S}
+    params = {"num_idepth_samples": D, "cost_volume_filter": True, "refiners": [True] * 5}
+    metrics.evaluate(net, [batch] * 2, params, "gta_sfm", dev)          # warm-up (allocator pools, pinned staging)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    avg = metrics.evaluate(net, [batch] * steps, params, "gta_sfm", dev)
+    torch.cuda.synchronize()
+    rate = B * steps / (time.perf_counter() - t0)
+    return {"depthmaps_per_s": round(rate, 1), "fraction_of_resident_rate": round(rate / resident_value, 4),
+            "batches": steps, "images_per_batch": B, "num_samples": avg["num_samples"], "abs_rel": avg.get("abs_rel"),
+            "note": "host batches in pinned memory incl. a ground-truth depth map per image; H2D copies overlapped "
+                    "(Prefetcher), metrics on the device (mvsn_depth_metrics), one sync + one gather at the end"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("MVSN_BENCH_BATCH", "128")),
-                    help="reference images per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("MVSN_BENCH_BATCH", "0")),
+                    help="reference images per GPU per step (default: the config's own, 128 for the headline)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="headline",
+                    help="which BASELINE.json configuration the timed region runs (default: the one the metric is "
+                         "quoted on); config3 = 5 source views, one image per GPU")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("MVSN_BENCH_LANES", "1")),
                     help="batch slices run on separate HIP streams (images are independent)")
     ap.add_argument("--fold", action="store_true", help="fold residual blocks into the next conv's tile load")
@@ -291,21 +408,24 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
+    cfg = CONFIGS[args.config]
+    headline = args.config == "headline"
     net = MultiViewStereoNet()
-    net.load_state_dict(load_weights(WEIGHTS), strict=True)
+    net.load_state_dict(load_weights(cfg["weights"]), strict=True)
     net = net.to(dev).eval()
     net.stream_lanes = args.lanes
     net.options.fold_residual_blocks = args.fold
     net.options.conv_precision = args.precision
-    B = args.batch
-    _, inp = make_inputs(B, GOLDEN_SEED + rank * B, dev)
+    B = args.batch if args.batch > 0 else cfg["batch"]
+    Dn, Sn = cfg["D"], cfg["S"]
+    _, inp, ref0 = config_inputs(cfg, B, rank, dev)
+    step = lambda: run_forward(net, inp, Dn)   # noqa: E731
 
     # set-up, outside the warm-up / timed protocol and reported as "setup_forwards": the first forward packs the
     # weights, opts the kernels into their LDS sizes and grows the allocator pools (one-time work per process)
-    run_forward(net, inp)
+    step()
     torch.cuda.synchronize()
-    elapsed, per_rank, out = timed_steps(lambda: run_forward(net, inp), args.steps, args.warmup, world,
-                                         torch.cuda.synchronize, dev)
+    elapsed, per_rank, out = timed_steps(step, args.steps, args.warmup, world, torch.cuda.synchronize, dev)
 
     # per-image metric rows, all-gathered (the path's only exchange step)
     idepth = out["left_idepthmap_pyr"][0]
@@ -314,6 +434,22 @@ def main():
     idx = torch.arange(rank * B, (rank + 1) * B, device=dev)
     all_rows, all_idx = mdist.gather_metric_rows(rows, idx)
     assert all_rows.shape[0] == B * world and bool(torch.isfinite(all_rows).all())
+
+    # ---- quality fields, on EVERY rank (its own device), reduced to rank 0: the line of an N-GPU run carries the
+    # same parity / roofline / chain-kernel / CPU-baseline fields as the 1-GPU line (roofline: min over ranks)
+    agg = kernel_breakdown(net, inp, Dn)
+    total_ms = sum(e["ms"] for e in agg.values())
+    name, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+    per_launch_ms = dom["ms"] / dom["launches"]
+    # dom["flops"] counts the layer in its direct form (2 * cin * taps * cout per output).  The Winograd
+    # kernels execute 16 multiplies per 2x2 outputs and tap plane instead of 36 (x 4/9): the roofline is
+    # priced on the flops the matrix pipe actually executes, the direct-form figure is reported beside it.
+    wino = " wino" in name
+    direct_tfl = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12
+    tfl = direct_tfl * (4.0 / 9.0 if wino else 1.0)
+    fracs = gather_floats(tfl / PEAK_FP32_MFMA_TFLOPS, world, dev)
+    ch = agg.get("mvsn_incremental_cost_volume")
+    chain_ms = gather_floats(ch["ms"] / ch["launches"] if ch else 0.0, world, dev)
 
     if rank == 0:
         line = {"metric": "depthmaps/sec at 512x256, 64 hypotheses, 2 src views; L1 vs ref",
@@ -324,148 +460,144 @@ def main():
                 "world_size": torch.distributed.get_world_size() if world > 1 else 1,
                 "backend": torch.distributed.get_backend() if world > 1 else "none",
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-                "data": "synthetic (seeded uniform frames, pretrained gta_sfm_150epochs weights)",
-                "config": {"workload": "GTA-SfM-shaped 512x256, D=64 hypotheses, 2 source views, "
-                                       "cost-volume filter + 5 refiners", "images_per_gpu_per_step": B,
+                "data": f"synthetic (seeded frames, pretrained {cfg['weights']} weights)",
+                "config": {"workload": cfg["what"], "name": args.config, "images_per_gpu_per_step": B,
                            "global_batch": B * world, "parallelism": f"dp{world} (independent images, "
                                                                       "all-gather of metric rows)"},
                 "mean_idepth": float(mdist.average_rows(all_rows)[0])}
-        if world == 1:
-            import numpy as np
-            gold = np.load(GOLDEN)
-            ref0 = torch.from_numpy(gold["idepth_0"])
-            got0 = idepth[:1].cpu()
-            l1 = float((got0 - ref0).abs().mean())
-            line["l1_vs_ref"] = {"l1": l1, "mean_rel": l1 / float(ref0.abs().mean()),
-                                 "max_rel": float((got0 - ref0).abs().max() / ref0.abs().max()),
-                                 "reference": "tests/golden/g2_gta_512x256_d64_s2.npz (reference PyTorch-CPU forward)"}
-            agg = kernel_breakdown(net, inp)
-            total_ms = sum(e["ms"] for e in agg.values())
-            name, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
-            per_launch_ms = dom["ms"] / dom["launches"]
-            # dom["flops"] counts the layer in its direct form (2 * cin * taps * cout per output).  The Winograd
-            # kernels execute 16 multiplies per 2x2 outputs and tap plane instead of 36 (x 4/9): the roofline is
-            # priced on the flops the matrix pipe actually executes, the direct-form figure is reported beside it.
-            wino = " wino" in name
-            direct_tfl = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12
-            tfl = direct_tfl * (4.0 / 9.0 if wino else 1.0)
-            traffic = None
-            try:   # HBM bytes per launch from the committed PMC passes (profiles/), scaled to this batch
-                with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-                    t = json.load(f).get(name)
-                if t:
-                    traffic = (t["fetch_bytes_per_chain"] + t["write_bytes_per_chain"]) * B * S
+        if not headline:
+            line["metric"] = (f"depthmaps/sec at {cfg['cols']}x{cfg['rows']}, {Dn} hypotheses, {Sn} src views; L1 vs ref "
+                              f"(--config {args.config}: NOT the headline configuration)")
+        got0 = idepth[:1].cpu()
+        line["l1_vs_ref"] = l1_against(ref0, got0, cfg["golden"])
+        traffic, traffic_source = None, None
+        try:   # HBM bytes per launch from the committed PMC passes (profiles/), scaled to this batch
+            with open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)) as f:
+                pmc = json.load(f)
+            t = pmc.get(name)
+            if t:
+                traffic = (t["fetch_bytes_per_chain"] + t["write_bytes_per_chain"]) * B * Sn
+                traffic_source = (f"profiles/{PMC_TRAFFIC_FILE}: FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc pass "
+                                  f"of this kernel ({pmc.get('_round', 'an earlier round')}), per chain, scaled to this "
+                                  "batch -- a pointer to that pass, NOT a counter read during this run")
+        except OSError:
+            pass
+        line["roofline"] = {"kernel": name, "bound": "mfma", "achieved": tfl, "peak": PEAK_FP32_MFMA_TFLOPS,
+                            "unit": "TFLOP/s", "frac": min(fracs), "frac_per_rank": fracs, "traffic": traffic,
+                            "traffic_source": traffic_source,
+                            "launches_per_step": dom["launches"], "avg_launch_ms": per_launch_ms,
+                            "share_of_step": dom["ms"] / total_ms}
+        if "+pass" in name:
+            line["roofline"]["carried_pass"] = ("each of these launches also executes the in-place LeakyReLU(GroupNorm(.)) "
+                                                "pass of the other batch slice's previous layer (mvsn_conv_forward_carry): "
+                                                "its loads / stores are part of the launch time and of `traffic`, "
+                                                "`achieved` counts the convolution's flops only")
+        if wino:
+            line["roofline"]["form"] = ("Winograd F(2x2,3x3) per depth tap: 12 multiplies per output and "
+                                        "(cin, cout) pair instead of 27; achieved = executed MFMA flops")
+            line["roofline"]["direct_form_equivalent_TFLOPs"] = direct_tfl
+        if ch:
+            eng = net.engine()
+            sec = max(chain_ms) * 1e-3 * ch["launches"]          # slowest rank
+            form = {1: "direct", 2: "winograd", 3: "stepwise", 4: "banded"}.get(eng.last_chain_form, "?")
+            wino_chain = form in ("winograd", "banded", "stepwise")
+            direct_tfl_c = ch["flops"] / sec / 1e12
+            exec_tfl = direct_tfl_c * (4.0 / 9.0 if wino_chain else 1.0)
+            line["chain_kernel"] = {"kernel": "mvsn_incremental_cost_volume (warp + refine + cost volume, fused)",
+                                    "form": form + (": Winograd F(2x2,3x3) for the three 3x3 convolutions of a step (16 "
+                                                    "multiplies per 2x2 outputs instead of 36)" if wino_chain else ""),
+                                    "avg_launch_ms": max(chain_ms), "avg_launch_ms_per_rank": chain_ms,
+                                    "chains_per_launch": B * Sn,
+                                    "algorithmic_GBps": ch["bytes"] / sec / 1e9,
+                                    "frac_of_hbm_peak": ch["bytes"] / sec / 1e9 / PEAK_HBM_GBS,
+                                    "direct_form_TFLOPs": direct_tfl_c,
+                                    "direct_form_frac_of_fp32_mfma_peak": direct_tfl_c / PEAK_FP32_MFMA_TFLOPS,
+                                    "executed_TFLOPs": exec_tfl,
+                                    "executed_frac_of_fp32_mfma_peak": exec_tfl / PEAK_FP32_MFMA_TFLOPS,
+                                    "share_of_step": ch["ms"] / total_ms}
+            try:
+                with open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)) as f:
+                    t = json.load(f).get("mvsn_incremental_cost_volume")
+                if t and form == "winograd":
+                    line["chain_kernel"]["hbm_traffic_bytes_per_chain"] = {
+                        "fetched": t["fetch_bytes_per_chain"], "written": t["write_bytes_per_chain"],
+                        "algorithmic": t["algorithmic_bytes_per_chain"],
+                        "ratio": (t["fetch_bytes_per_chain"] + t["write_bytes_per_chain"]) /
+                        t["algorithmic_bytes_per_chain"], "source": f"profiles/{PMC_TRAFFIC_FILE} (separate PMC pass)"}
             except OSError:
                 pass
-            line["roofline"] = {"kernel": name, "bound": "mfma", "achieved": tfl, "peak": PEAK_FP32_MFMA_TFLOPS,
-                                "unit": "TFLOP/s", "frac": tfl / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                                "launches_per_step": dom["launches"], "avg_launch_ms": per_launch_ms,
-                                "share_of_step": dom["ms"] / total_ms}
-            if "+pass" in name:
-                line["roofline"]["carried_pass"] = ("each of these launches also executes the in-place LeakyReLU(GroupNorm(.)) "
-                                                    "pass of the other batch slice's previous layer (mvsn_conv_forward_carry): "
-                                                    "its loads / stores are part of the launch time and of `traffic`, "
-                                                    "`achieved` counts the convolution's flops only")
-            if wino:
-                line["roofline"]["form"] = ("Winograd F(2x2,3x3) per depth tap: 12 multiplies per output and "
-                                            "(cin, cout) pair instead of 27; achieved = executed MFMA flops")
-                line["roofline"]["direct_form_equivalent_TFLOPs"] = direct_tfl
-            ch = agg.get("mvsn_incremental_cost_volume")
-            if ch:
-                sec = ch["ms"] * 1e-3
-                r4, c4 = (ROWS + 15) // 16, (COLS + 15) // 16
-                wino_chain = net.engine().lib.mvsn_incremental_cost_volume_form(r4, c4) == 2 and \
-                    net.options.chain_form != "direct"
-                direct_tfl = ch["flops"] / sec / 1e12
-                exec_tfl = direct_tfl * (4.0 / 9.0 if wino_chain else 1.0)
-                line["chain_kernel"] = {"kernel": "mvsn_incremental_cost_volume (warp + refine + cost volume, fused)",
-                                        "form": "Winograd F(2x2,3x3) for the three 3x3 convolutions of a step: 16 "
-                                                "multiplies per 2x2 outputs instead of 36" if wino_chain else "direct",
-                                        "avg_launch_ms": ch["ms"] / ch["launches"],
-                                        "algorithmic_GBps": ch["bytes"] / sec / 1e9,
-                                        "frac_of_hbm_peak": ch["bytes"] / sec / 1e9 / PEAK_HBM_GBS,
-                                        "direct_form_TFLOPs": direct_tfl,
-                                        "direct_form_frac_of_fp32_mfma_peak": direct_tfl / PEAK_FP32_MFMA_TFLOPS,
-                                        "executed_TFLOPs": exec_tfl,
-                                        "executed_frac_of_fp32_mfma_peak": exec_tfl / PEAK_FP32_MFMA_TFLOPS,
-                                        "share_of_step": ch["ms"] / total_ms}
+        line["kernel_ms_per_step"] = {k: round(v["ms"], 3) for k, v in
+                                      sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]}
+        line["launches_per_forward"] = int(sum(v["launches"] for v in agg.values()))
+        if world == 1 and args.sustain > 0:
+            windows, t_end = [], time.perf_counter() + args.sustain
+            while time.perf_counter() < t_end:
+                n_steps, t1 = 0, time.perf_counter()
+                while time.perf_counter() - t1 < 2.0:
+                    step()
+                    n_steps += 1
+                    if n_steps % 8 == 0:
+                        torch.cuda.synchronize()
+                torch.cuda.synchronize()
+                windows.append(B * n_steps / (time.perf_counter() - t1))
+            line["sustained"] = {"seconds": args.sustain, "window_s": 2.0,
+                                 "depthmaps_per_s_per_window": [round(w, 1) for w in windows],
+                                 "first": round(windows[0], 1), "last": round(windows[-1], 1),
+                                 "min": round(min(windows), 1), "droop_last_vs_first": 1.0 - windows[-1] / windows[0],
+                                 "timed_region_value": line["value"]}
+        if world == 1 and headline and not args.no_tiers:
+            # side legs: a failure in one of them must not cost the headline line
+            for key, leg in (("pcie_inclusive", lambda: host_feed_rates(net, B, dev)),
+                             ("evaluate_rate", lambda: evaluate_rate(net, B, dev, line["value"])),
+                             ("batch_latency", lambda: batch_latency(net)),
+                             ("other_configs", lambda: other_configs(dev, skip=("headline",)))):
                 try:
-                    with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-                        t = json.load(f).get("mvsn_incremental_cost_volume")
-                    if t:
-                        line["chain_kernel"]["hbm_traffic_bytes_per_chain"] = {
-                            "fetched": t["fetch_bytes_per_chain"], "written": t["write_bytes_per_chain"],
-                            "algorithmic": t["algorithmic_bytes_per_chain"],
-                            "ratio": (t["fetch_bytes_per_chain"] + t["write_bytes_per_chain"]) /
-                            t["algorithmic_bytes_per_chain"]}
-                except OSError:
-                    pass
-            line["kernel_ms_per_step"] = {k: round(v["ms"], 3) for k, v in
-                                          sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]}
-            if args.sustain > 0:
-                windows, t_end = [], time.perf_counter() + args.sustain
-                while time.perf_counter() < t_end:
-                    n_steps, t1 = 0, time.perf_counter()
-                    while time.perf_counter() - t1 < 2.0:
-                        run_forward(net, inp)
-                        n_steps += 1
-                        if n_steps % 8 == 0:
-                            torch.cuda.synchronize()
-                    torch.cuda.synchronize()
-                    windows.append(B * n_steps / (time.perf_counter() - t1))
-                line["sustained"] = {"seconds": args.sustain, "window_s": 2.0,
-                                     "depthmaps_per_s_per_window": [round(w, 1) for w in windows],
-                                     "first": round(windows[0], 1), "last": round(windows[-1], 1),
-                                     "min": round(min(windows), 1), "droop_last_vs_first": 1.0 - windows[-1] / windows[0],
-                                     "timed_region_value": line["value"]}
-            if not args.no_tiers:
-                # side legs: a failure in one of them must not cost the headline line
-                for key, leg in (("pcie_inclusive", lambda: host_feed_rates(net, B, dev)),
-                                 ("batch_latency", lambda: batch_latency(net))):
-                    try:
-                        line[key] = leg()
-                    except Exception as exc:   # noqa: BLE001
-                        line[key] = {"error": f"{type(exc).__name__}: {exc}"}
-            if args.precision == "fp32" and not args.no_tiers:
-                # the two bf16-matrix-core tiers on the same resident inputs, reported beside the fp32 headline, never
-                # as it: the 3 x bf16 split (fp32-equivalent arithmetic) and plain bf16 operands
-                # (BASELINE config 5's speed tier -- outside the 1e-3 parity contract, its error is reported)
-                eng = net.engine()
-                for tier, key, dtype in (
-                        ("bf16x3", "bf16x3_split_tier",
-                         "3 x bf16 split (hi+lo operands, fp32 accumulate) on the 32->32 3x3 layers, f32 elsewhere"),
-                        ("bf16", "bf16_operand_tier",
-                         "bf16 operands, fp32 accumulate on the 32->32 3x3 layers (regulariser + refiner blocks), f32 "
-                         "elsewhere; NOT within the 1e-3 parity contract")):
-                    eng.conv_precision = tier
-                    for _ in range(max(1, args.warmup)):
-                        out_t = run_forward(net, inp)
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    for _ in range(args.steps):
-                        out_t = run_forward(net, inp)
-                    torch.cuda.synchronize()
-                    dt = time.perf_counter() - t1
-                    got_t = out_t["left_idepthmap_pyr"][0][:1].cpu()
-                    l1_t = float((got_t - ref0).abs().mean())
-                    agg_t = kernel_breakdown(net, inp)
-                    name_t, dom_t = max(agg_t.items(), key=lambda kv: kv[1]["ms"])
-                    line[key] = {
-                        "value": B * args.steps / dt, "unit": "depthmaps/s", "ms_per_step": dt / args.steps * 1e3,
-                        "dtype": dtype,
-                        "l1_vs_ref": {"l1": l1_t, "mean_rel": l1_t / float(ref0.abs().mean()),
-                                      "max_rel": float((got_t - ref0).abs().max() / ref0.abs().max())},
-                        "dominant_kernel": name_t, "dominant_kernel_ms": round(dom_t["ms"], 3),
-                        "kernel_ms_per_step": {k: round(v["ms"], 3) for k, v in
-                                               sorted(agg_t.items(), key=lambda kv: -kv[1]["ms"])[:6]}}
-                eng.conv_precision = "fp32"
-            if not args.no_cpu_baseline:
-                cb, ref_out = cpu_baseline()
-                line["cpu_baseline"] = cb
-                o0 = ref_out["left_idepthmap_pyr"][0]
-                line["l1_vs_oracle"] = float((got0 - o0).abs().mean())
+                    line[key] = leg()
+                except Exception as exc:   # noqa: BLE001
+                    line[key] = {"error": f"{type(exc).__name__}: {exc}"}
+        if world == 1 and headline and args.precision == "fp32" and not args.no_tiers:
+            # the two bf16-matrix-core tiers on the same resident inputs, reported beside the fp32 headline, never
+            # as it: the 3 x bf16 split (fp32-equivalent arithmetic) and plain bf16 operands
+            # (BASELINE config 5's speed tier -- outside the 1e-3 parity contract, its error is reported)
+            eng = net.engine()
+            for tier, key, dtype in (
+                    ("bf16x3", "bf16x3_split_tier",
+                     "3 x bf16 split (hi+lo operands, fp32 accumulate) on the 32->32 3x3 layers, f32 elsewhere"),
+                    ("bf16", "bf16_operand_tier",
+                     "bf16 operands, fp32 accumulate on the 32->32 3x3 layers (regulariser + refiner blocks), f32 "
+                     "elsewhere; NOT within the 1e-3 parity contract")):
+                eng.conv_precision = tier
+                for _ in range(max(1, args.warmup)):
+                    out_t = step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    out_t = step()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                got_t = out_t["left_idepthmap_pyr"][0][:1].cpu()
+                l1_t = float((got_t - ref0).abs().mean())
+                agg_t = kernel_breakdown(net, inp, Dn)
+                name_t, dom_t = max(agg_t.items(), key=lambda kv: kv[1]["ms"])
+                line[key] = {
+                    "value": B * args.steps / dt, "unit": "depthmaps/s", "ms_per_step": dt / args.steps * 1e3,
+                    "dtype": dtype,
+                    "l1_vs_ref": {"l1": l1_t, "mean_rel": l1_t / float(ref0.abs().mean()),
+                                  "max_rel": float((got_t - ref0).abs().max() / ref0.abs().max())},
+                    "dominant_kernel": name_t, "dominant_kernel_ms": round(dom_t["ms"], 3),
+                    "kernel_ms_per_step": {k: round(v["ms"], 3) for k, v in
+                                           sorted(agg_t.items(), key=lambda kv: -kv[1]["ms"])[:6]}}
+            eng.conv_precision = "fp32"
+        if not args.no_cpu_baseline:
+            # rank 0's host cores, once per job whatever N is (a bounded sample: shorter beside a multi-GPU run,
+            # where the other ranks wait in the final barrier meanwhile)
+            cb, ref_out = cpu_baseline(cfg, budget_s=15.0 if world == 1 else 6.0)
+            line["cpu_baseline"] = cb
+            o0 = ref_out["left_idepthmap_pyr"][0]
+            line["l1_vs_oracle"] = float((got0 - o0).abs().mean())
         print(json.dumps(line))
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

@@ -358,6 +358,20 @@ int mvsn_occlusion_mask(const float *idepth_in_other, const float *other_sampled
 int mvsn_masked_l1(const float *a, const float *b, const uint8_t *skip_a, const uint8_t *skip_b, long n, int accumulate,
                    float *loss, mvsn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Depth metrics of a batch on the device: replaces the per-image host loop of test.py:210-235 + get_depth_prediction_metrics
+ * (test.py:41-71).  Per image: depth_est = idepth_est / baseline, inverted where positive (:210-214); selected pixels =
+ * truth in (min_depth, max_depth) AND estimate in (min_depth, max_depth) (:221,:232); per-pixel values in fp32 as numpy
+ * forms them, sums in double in a fixed order.
+ *   idepth_est, depth_true (B, pixels) fp32 (depth_true in metric units)   baseline (B)
+ *   partials: B * mvsn_depth_metrics_blocks(pixels) * 9 doubles of scratch
+ *   rows (B, 9) doubles: {n_truth, n_selected, abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3}; NaN metrics when nothing is
+ *   selected (numpy's mean of an empty selection); the caller drops images with n_truth == 0 (:223-225).
+ * ------------------------------------------------------------------------------------------- */
+int mvsn_depth_metrics_blocks(long pixels);
+int mvsn_depth_metrics(const float *idepth_est, const float *depth_true, const float *baseline, int batch, long pixels,
+                       float min_depth, float max_depth, double *partials, double *rows, mvsn_stream_t stream);
+
 /* Device self-test of the MFMA fragment mapping the conv kernels rely on (A = 16x4, B = 4x16
  * fp32, asymmetric operands); returns 0 when the on-device result matches the scalar product. */
 int mvsn_selftest_mfma(mvsn_stream_t stream);

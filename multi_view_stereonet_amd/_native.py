@@ -77,6 +77,8 @@ SIGNATURES = {
     "mvsn_idepth_reproject": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p] * 6 + [c_void_p]),
     "mvsn_occlusion_mask": (c_int, [c_void_p] * 4 + [c_int] * 2 + [c_void_p, c_void_p]),
     "mvsn_masked_l1": (c_int, [c_void_p] * 4 + [c_long, c_int, c_void_p, c_void_p]),
+    "mvsn_depth_metrics_blocks": (c_int, [c_long]),
+    "mvsn_depth_metrics": (c_int, [c_void_p] * 3 + [c_int, c_long, ctypes.c_float, ctypes.c_float, c_void_p, c_void_p, c_void_p]),
     "mvsn_selftest_mfma": (c_int, [c_void_p]),
 }
 

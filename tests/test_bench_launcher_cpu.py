@@ -26,6 +26,40 @@ def test_plain_command_self_launches_two_ranks():
     assert line["steps"] == 3 and line["warmup"] == 1
     assert len(line["per_rank_ms_per_step"]) == 2
     assert line["rows_gathered"] == 8 and line["rank_sum"] == 4.0       # 4 rows of rank 0 (0.0) + 4 of rank 1 (1.0)
+    # the line of an N > 1 run carries the parity / roofline / chain-kernel / CPU-baseline fields too (stand-ins here),
+    # the roofline fraction reduced as the minimum over the ranks' own measurements
+    for key in ("l1_vs_ref", "roofline", "chain_kernel", "cpu_baseline"):
+        assert key in line, key
+    assert line["roofline"]["frac_per_rank"] == [0.5, 0.6] and line["roofline"]["frac"] == 0.5
+
+
+def test_real_line_builds_quality_fields_for_every_world_size():
+    """The measuring path itself (not the self-test): the quality fields are assembled outside any `world == 1`
+    guard, and --config offers every BASELINE configuration with its own reference fixture."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+
+    def guarded_by_world1(node, target, under=False):
+        for child in ast.iter_child_nodes(node):
+            here = under
+            if isinstance(child, ast.If) and "world == 1" in ast.unparse(child.test):
+                here = True
+            if isinstance(child, ast.Assign) and any(target in ast.unparse(t) for t in child.targets) and here:
+                return True
+            if guarded_by_world1(child, target, here):
+                return True
+        return False
+
+    for key in ('line["l1_vs_ref"]', 'line["roofline"]', 'line["chain_kernel"]', 'line["cpu_baseline"]'):
+        assert key in src and not guarded_by_world1(main, key), key
+    sys.path.insert(0, ROOT)
+    import bench
+    assert set(bench.CONFIGS) == {"headline", "config2", "config3", "config4", "config5"}
+    assert bench.CONFIGS["config3"]["S"] == 5 and bench.CONFIGS["config3"]["batch"] == 1
+    for cfg in bench.CONFIGS.values():
+        assert os.path.exists(os.path.join(ROOT, "tests", "golden", cfg["golden"]))
 
 
 def test_single_rank_needs_no_launcher():

@@ -1060,6 +1060,90 @@ def test_evaluate_cli_on_miniature_dataset(tmp_path):
     txt = (out_dir / "avg_depth_metrics.txt").read_text().split("\n")
     vals = dict(zip(txt[0].split(), (float(v) for v in txt[1].split())))
     assert set(["abs_rel", "rmse", "a1", "runtime_ms"]) <= set(vals) and all(np.isfinite(list(vals.values())))
+    # the actual numbers: the same two samples through the dataset reader, the blocking unpack, one forward each and
+    # the reference's host-side metric arithmetic (numpy, image by image) must give the averages the CLI wrote
+    from multi_view_stereonet_amd import datasets, metrics
+    params = {"size": [128, 256], "num_idepth_samples": 8, "cost_volume_filter": True, "refiners": [True] * 5}
+    data = datasets.GTASfMMultiViewStereoDataset(str(root), str(split), transform=datasets.get_testing_transforms(params),
+                                                 load_groundtruth_depthmaps=True, shuffle_on_read=False)
+    net = net_for("gta_sfm_150epochs")
+    rows = []
+    for batch in torch.utils.data.DataLoader(data, batch_size=1, shuffle=False):
+        inputs = snu.multi_view_unpack_batch(batch, torch.device(DEV), 5)
+        out = snu.multi_view_forward(net, inputs, params)
+        est = metrics.idepth_to_depth(out["left_idepthmap_pyr"][0], inputs["baseline"])[0, 0].cpu().numpy()
+        rows.append(metrics.image_metric_row(batch["left_depthmap_true"][0, 0].numpy(), est, *metrics.depth_range("gta_sfm")))
+    want = metrics.compute_avg_metrics(rows)
+    assert want["num_samples"] == 2
+    for k in metrics.METRIC_KEYS:
+        assert abs(vals[k] - want[k]) <= 1e-6 * max(1.0, abs(want[k])), (k, vals[k], want[k])
+    assert 0.0 < vals["abs_rel"] < 10.0 and vals["rmse"] > 0.0      # random frames against a constant 5 m truth
+
+
+def test_depth_metrics_on_device_match_the_host_arithmetic():
+    """mvsn_depth_metrics (idepth -> depth, range masks, seven means per image; test.py:41-71, 210-235) against the
+    numpy functions pinned to the reference (g7): every metric to 1e-6 relative, counts exact; an image without valid
+    truth, one without a selected pixel, negative / zero idepths and the DeMoN range included."""
+    from multi_view_stereonet_amd import metrics
+    fix = load_golden("g7_depth_metrics.npz")
+    g = torch.Generator().manual_seed(3)
+    for (lo, hi), shape in (((0.0, 1e3), (5, 1, 96, 160)), ((0.5, 10.0), (3, 1, 37, 53)), ((0.0, 1e3), (2, 1, 256, 512))):
+        B = shape[0]
+        truth = torch.rand(shape, generator=g) * 12.0
+        truth[truth < 1.0] = 0.0                                  # holes in the ground truth
+        idepth = 1.0 / (truth.clamp_min(0.3) * (0.7 + 0.6 * torch.rand(shape, generator=g)))
+        idepth[:, :, ::7, ::5] = 0.0                              # non-positive estimates stay as they are
+        idepth[:, :, 1::9, 2::4] = -0.25
+        if B >= 3:
+            truth[1] = 0.0                                        # no valid truth at all -> n_truth = 0 (skipped)
+            idepth[2] = -1.0                                      # truth but no valid estimate -> NaN metrics
+        baseline = 0.5 + torch.rand(B, generator=g)
+        got = metrics.depth_metric_rows(idepth.to(DEV), truth.to(DEV), baseline.to(DEV), lo, hi).cpu()
+        want = metrics.depth_metric_rows(idepth, truth, baseline, lo, hi)
+        assert torch.equal(got[:, :2], want[:, :2]), (got[:, :2], want[:, :2])
+        assert torch.equal(torch.isnan(got), torch.isnan(want))
+        ok = ~torch.isnan(want)
+        rel = ((got[ok] - want[ok]).abs() / want[ok].abs().clamp_min(1e-12)).max()
+        assert float(rel) < 1e-6, float(rel)
+    # the reference's own numbers (fixture of test.py's function): already-masked positive depths, baseline 1
+    t = torch.from_numpy(fix["depth_true"]).reshape(1, 1, 1, -1).float()
+    e = torch.from_numpy(fix["depth_est"]).reshape(1, 1, 1, -1).float()
+    row = metrics.depth_metric_rows((1.0 / e).to(DEV), t.to(DEV), torch.ones(1, device=DEV), 0.0, 1e9).cpu()[0]
+    for i, k in enumerate(metrics.METRIC_KEYS):
+        assert abs(float(row[2 + i]) - float(fix[k])) <= 2e-6 * max(1.0, abs(float(fix[k]))), k
+
+
+def test_evaluate_with_prefetcher_matches_blocking_loop():
+    """metrics.evaluate on a GPU (Prefetcher + device metric rows + deferred checks, no per-image host copy) gives the
+    averages of the reference-style loop: blocking unpack, synchronised forward, numpy metrics image by image."""
+    from multi_view_stereonet_amd import metrics
+    net = net_for("gta_sfm_150epochs")
+    params = {"num_idepth_samples": 8, "cost_volume_filter": True, "refiners": [True] * 5}
+    batches = []
+    for i in range(5):
+        b = synthetic.make_batch(64, 128, 2, batch=2 if i % 2 else 1, seed=40 + i, smooth=True)
+        n = b["left_image"].shape[0]
+        depth = 2.0 + 6.0 * torch.rand(n, 1, 64, 128, generator=torch.Generator().manual_seed(i))
+        if i == 2:
+            depth[0] = 0.0                      # an image without ground truth: skipped by both loops
+        b["left_depthmap_true"] = depth
+        b["right_depthmap_true"] = [depth.clone(), depth.clone()]
+        batches.append(b)
+    got = metrics.evaluate(net, batches, params, "gta_sfm", torch.device(DEV))
+    rows = []
+    for b in batches:
+        inputs = snu.multi_view_unpack_batch(b, torch.device(DEV), 5)
+        out = snu.multi_view_forward(net, inputs, params)
+        est = metrics.idepth_to_depth(out["left_idepthmap_pyr"][0], inputs["baseline"]).cpu().numpy()
+        for k in range(est.shape[0]):
+            r = metrics.image_metric_row(b["left_depthmap_true"][k, 0].numpy(), est[k, 0], 0.0, 1e3)
+            if r is not None:
+                rows.append(r)
+    want = metrics.compute_avg_metrics(rows)
+    assert got["num_samples"] == want["num_samples"] == 6
+    for k in metrics.METRIC_KEYS:
+        assert abs(got[k] - want[k]) <= 1e-6 * max(1.0, abs(want[k])), (k, got[k], want[k])
+    assert got["runtime_ms"] > 0.0 and got["batch_runtime_ms"] >= got["runtime_ms"]
 
 
 def test_two_view_bidirectional_golden():

@@ -105,3 +105,17 @@ def test_evaluate_dataset_level_shards_cover_every_image_once():
         parts.append((out, len(mine)))
     merged = sum(o["abs_rel"] * k for o, k in parts) / n
     assert abs(merged - full["abs_rel"]) < 1e-9 and full["num_samples"] == n
+
+
+def test_depth_metric_rows_host_form_and_prefetcher_pass_through():
+    """depth_metric_rows on CPU tensors = the numpy functions per image (counts, NaN for an empty selection); the
+    Prefetcher on a CPU device hands the batches over unchanged, in order."""
+    from multi_view_stereonet_amd import multi_view_stereonet_utils as snu
+    truth = torch.tensor([[[[2.0, 4.0, 0.0, 2000.0]]], [[[0.0, 0.0, 0.0, 0.0]]]])
+    idepth = torch.tensor([[[[0.25, 0.125, 0.5, 0.5]]], [[[0.5, 0.5, 0.5, 0.5]]]])     # at baseline 0.5: depth 2, 4, 1, 1
+    rows = metrics.depth_metric_rows(idepth, truth, torch.tensor([0.5, 0.5]), 0.0, 1e3)
+    assert rows.shape == (2, 9) and rows[0, 0] == 2 and rows[0, 1] == 2 and rows[1, 0] == 0 and rows[1, 1] == 0
+    assert float(rows[0, 2]) == 0.0 and float(rows[0, 6]) == 1.0 and bool(torch.isnan(rows[1, 2:]).all())
+    items = [{"left_image": torch.zeros(1, 3, 4, 4), "tag": i, "right_image": [torch.ones(1, 3, 4, 4)]} for i in range(4)]
+    got = list(snu.Prefetcher(iter(items), torch.device("cpu")))
+    assert [g["tag"] for g in got] == [0, 1, 2, 3] and got[0]["right_image"][0].sum() == 48
