@@ -345,7 +345,7 @@ def host_feed_rates(net, B, dev, steps=8):
                     "normalisation) and the forward; NOT the headline value (inputs resident in HBM)"}
 
 
-def evaluate_rate(net, B, dev, resident_value, steps=6):
+def evaluate_rate(net, B, dev, resident_value, steps=12):
     """The evaluation loop at throughput grade (never `value`): metrics.evaluate over `steps` batches of B images that
     live in pinned host memory with a ground-truth depth map each -- Prefetcher (copies of batch k+1 under batch k),
     device-side unpack, forward, mvsn_depth_metrics (nine doubles per image stay on the device), one synchronisation

@@ -16,7 +16,19 @@ import torch
 from . import _native
 
 
+def _as_flag_bytes(mask: torch.Tensor) -> torch.Tensor:
+    """A mask of any dtype as the dense 0/1 bytes the kernels read (the reference calls .float() on its masks and so
+    accepts any dtype, losses.py:129-135; a float / int32 / int64 tensor handed over as raw bytes would be misread)."""
+    if mask.dtype not in (torch.bool, torch.uint8):
+        mask = mask != 0
+    elif mask.dtype == torch.uint8:
+        mask = mask != 0            # any non-zero byte counts as set, as .float() > 0 would
+    return mask.contiguous()
+
+
 def _reproject(K, T_other_in_this, idepth, other_idepth, other_mask=None, want_partials=False, want_uv=False):
+    if not idepth.is_cuda:
+        raise RuntimeError("the consistency ops run in libmvsn_hip.so on HIP devices only; got a CPU tensor")
     lib = _native.load()
     B, _, rows, cols = idepth.shape
     dev = idepth.device
@@ -26,7 +38,7 @@ def _reproject(K, T_other_in_this, idepth, other_idepth, other_mask=None, want_p
     id_prime, sampled = torch.empty((B, 1, rows, cols), **f), torch.empty((B, 1, rows, cols), **f)
     invalid = torch.empty((B, 1, rows, cols), dtype=torch.bool, device=dev)
     mask_sampled = torch.empty((B, 1, rows, cols), dtype=torch.bool, device=dev) if other_mask is not None else None
-    om = other_mask.contiguous() if other_mask is not None else None
+    om = _as_flag_bytes(other_mask) if other_mask is not None else None
     uv = torch.empty((B, rows, cols, 2), **f) if want_uv else None
     partials = torch.empty((B, lib.mvsn_idepth_reproject_blocks(rows * cols)), **f) if want_partials else None
     _native.check(lib.mvsn_idepth_reproject(_native.ptr(K), _native.ptr(T), _native.ptr(idepth), _native.ptr(other_idepth),
@@ -72,7 +84,7 @@ def left_right_idepthmap_consistency_losses(T_right_in_left, T_left_in_right, K_
             first = loss is None
             if first:
                 loss = torch.empty((1,), dtype=torch.float32, device=a.device)
-            a_occ = a_occ.contiguous()
+            a_occ = _as_flag_bytes(a_occ)
             _native.check(lib.mvsn_masked_l1(_native.ptr(projected), _native.ptr(sampled), _native.ptr(a_occ),
                                              _native.ptr(occ_sampled), projected.numel(), 0 if first else 1,
                                              _native.ptr(loss), _native.stream()), "mvsn_masked_l1")

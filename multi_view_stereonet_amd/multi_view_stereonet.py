@@ -167,6 +167,7 @@ class PlaneSweepEngine:
     def __init__(self, net: "MultiViewStereoNet"):
         self.lib = lib = _native.load()
         self.carried_jobs = 0          # normalise/activate/add passes that travelled inside a convolution launch
+        self.bf16_layers = 0           # convolution launches that ran on the bf16 / bf16x3 kernels
         # The banded chain form spins on its sibling workgroups: every workgroup of a launch must be resident, so two
         # such launches must not share the device (MultiViewStereoNet._forward_lanes clears this for its lanes).
         self.banded_ok = True
@@ -222,7 +223,7 @@ class PlaneSweepEngine:
 
     def conv(self, c: _Conv, x: torch.Tensor, in_stats=None, in_norm: Optional[_Norm] = None, want_stats=False,
              in_residual: Optional[torch.Tensor] = None, write_staged: bool = False, carry: Optional["_Job"] = None,
-             out: Optional[torch.Tensor] = None):
+             out: Optional[torch.Tensor] = None, prefer_fp32_wino: bool = False):
         """x (N,C,[D,]H,W) -> (out, stats or None[, staged]).
 
         `in_stats`/`in_norm` fold LReLU(GN(x)) into the tile load; `in_residual` adds the residual
@@ -246,16 +247,19 @@ class PlaneSweepEngine:
         rows, cols = x.shape[-2], x.shape[-1]
         d = c.desc(n, depth, rows, cols)
         packed = c.packed
-        # the bf16 tiers: the 3x3x3 layers always; the 2-D 3x3 layers only when the towers are not sliced (the fp32
-        # Winograd launches that carry the other slice's pass beat bf16 kernels followed by a stand-alone pass:
-        # 15.1 against 17.3 ms per step for the refiner blocks)
+        # the bf16 tiers: every 32 -> 32 3x3 / 3x3x3 layer that has the kernels -- except where the caller is a SLICED
+        # tower (`prefer_fp32_wino`, set by residual_tower_sliced only): there the fp32 Winograd launches that carry
+        # the other slice's pass beat bf16 kernels followed by a stand-alone pass (15.1 against 17.3 ms per step for
+        # the refiner blocks).  Unsliced towers (small batches, small levels, odd shapes) and the extractor keep the
+        # bf16 kernels; `bf16_layers` counts the launches that ran on them.
         if self.conv_precision in ("bf16x3", "bf16") and c.packed_bx is not None and in_residual is None and \
-                not write_staged and carry is None and (c.dims == 3 or not (self.carry_passes and self.winograd)):
+                not write_staged and carry is None and not prefer_fp32_wino:
             dbx = c.desc(n, depth, rows, cols,
                          _native.CONV_BF16X3 if self.conv_precision == "bf16x3" else _native.CONV_BF16)
             if lib.mvsn_conv_bf16x3_supported(ctypes.byref(dbx)):
                 d, packed = dbx, c.packed_bx
-        elif self.winograd and c.packed_wino is not None and in_residual is None and not write_staged and \
+                self.bf16_layers += 1
+        if d.precision == _native.CONV_FP32 and self.winograd and c.packed_wino is not None and in_residual is None and not write_staged and \
                 (in_stats is None or self.winograd_with_input_transform) and \
                 (c.dims == 2 or self.winograd_volume):
             dwn = c.desc(n, depth, rows, cols, _native.CONV_FP32_WINO)
@@ -429,9 +433,9 @@ class PlaneSweepEngine:
                 flip ^= 1
                 if i == 0:
                     _, st = self.conv(conv, r0[a:e], in_stats=st0[s_], in_norm=bn0, want_stats=True, carry=job,
-                                      out=r[a:e])
+                                      out=r[a:e], prefer_fp32_wino=True)
                 else:
-                    _, st = self.conv(conv, x[s_], want_stats=True, carry=job, out=r[a:e])
+                    _, st = self.conv(conv, x[s_], want_stats=True, carry=job, out=r[a:e], prefer_fp32_wino=True)
                 if i == last:
                     job = None
                     tails.append((r[a:e], st, norm, x[s_]))
@@ -819,6 +823,14 @@ class MultiViewStereoNet(nn.Module):
         self._invalidate()
         return out
 
+    def register_parameter(self, name, param):
+        super().register_parameter(name, param)
+        self.__dict__.pop("_plist", None)
+
+    def refresh(self):
+        """Drop the packed weight copies now (after replacing Parameter objects by hand)."""
+        self._invalidate()
+
     def engine(self) -> PlaneSweepEngine:
         # The packed copies go stale when a parameter is rebound (.to(), load_state_dict: both invalidate above) or
         # updated in place (bumps its version counter).  Walking the module tree for 202 (data_ptr, version) pairs on
@@ -828,6 +840,18 @@ class MultiViewStereoNet(nn.Module):
         if plist is None:
             plist = self.__dict__["_plist"] = list(self.parameters())
         key = (sum(p._version for p in plist), tuple(p.data_ptr() for p in plist))
+        # A Parameter OBJECT that was replaced on a submodule (module.weight = nn.Parameter(...), pruning /
+        # parametrize utilities) changes neither a version nor -- necessarily -- an address the cached list knows:
+        # the module tree is re-walked every 16th call (~6 us per call amortised) and the engine rebuilt when the
+        # objects differ.  `net.refresh()` forces it at once.
+        self.__dict__["_plist_age"] = self.__dict__.get("_plist_age", 0) + 1
+        if self.__dict__["_plist_age"] >= 16:
+            self.__dict__["_plist_age"] = 0
+            fresh = list(self.parameters())
+            if len(fresh) != len(plist) or any(a is not b for a, b in zip(fresh, plist)):
+                plist = self.__dict__["_plist"] = fresh
+                key = (sum(p._version for p in plist), tuple(p.data_ptr() for p in plist))
+                self._engine = None
         if self._engine is None or key != self._engine_key:
             self._engine = PlaneSweepEngine(self)
             self._engine_key = key

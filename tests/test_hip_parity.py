@@ -89,8 +89,18 @@ def test_homography_warp(B, C, n, rows, cols):
     H[..., 2, :2] *= 0.02
     vol, mask = eng.homography_warp(img.to(DEV), H.to(DEV))
     vref, mref = oracle.homography_warp(img, H)
-    mism = int((mask.cpu() != mref).sum())
-    assert mism <= max(1, mref.numel() // 20000), f"{mism} mask voxels differ"
+    # mask voxels may only differ where the normalised coordinate sits within a few fp32 ulps of the |n| > 1
+    # predicate (the oracle forms H @ grid as a matmul, the kernel as the reference's scalar expression): every
+    # mismatching voxel is located, its coordinate recomputed in float64, and its distance to the predicate asserted
+    diff = (mask.cpu() != mref).nonzero()
+    print(f"homography_warp {B}x{C}x{n}x{rows}x{cols}: {diff.shape[0]} of {mref.numel()} mask voxels differ")
+    for b, d, yy, xx in diff.tolist():
+        u = H[b, d].double() @ torch.tensor([float(xx), float(yy), 1.0], dtype=torch.float64)
+        nx = ((u[0] / u[2] + 0.5) * 2.0) / cols - 1.0
+        ny = ((u[1] / u[2] + 0.5) * 2.0) / rows - 1.0
+        edge = min(abs(abs(float(nx)) - 1.0), abs(abs(float(ny)) - 1.0))
+        assert edge < 16 * 2.0 ** -23, f"mask voxel {(b, d, yy, xx)} differs {edge:.3e} away from the predicate"
+    assert diff.shape[0] <= max(1, mref.numel() // 20000)
     agree = (mask.cpu() == mref)[:, None].expand_as(vref)
     # white-noise frames: one ulp of a ~cols-sized coordinate times a gradient of up to 2/px
     close(vol.cpu()[agree], vref[agree], rtol=1e-4, atol=cols * 2.0 ** -23 * 8)
@@ -739,6 +749,72 @@ def test_banded_chain_gather_paths_vs_oracle(kind, N, D):
     assert torch.equal(got["banded"][1], got["winograd"][1])
 
 
+@pytest.mark.parametrize("form", ["winograd", "banded"])
+@pytest.mark.parametrize("case,D", [("long", 128), ("long", 256), ("steps", 48), ("offset", 24)])
+def test_chain_groupnorm_single_pass_stays_accurate(case, D, form):
+    """The Winograd chain forms take GroupNorm's variance in ONE shifted pass, var = E[(x-c)^2] - E[x-c]^2 with c = the
+    previous plane's mean (mvsn_chain_wino.hip wino_groupnorm_lrelu, mvsn_chain_band.hip exchange): exact enough while
+    |mean - c| stays within a few deviations, cancelling if it did not.  Driven here where the shortcut is weakest:
+    D = 128 / 256 planes on 16x32 (error accumulation over a long recurrence), a source whose planes jump between a
+    half that is +40 and one that is -40 from plane to plane (the largest plane-to-plane change of the statistics an
+    input can cause), and plane-0 features with a common offset of 300 (the first step runs with c = 0).  Measured:
+    max |err| <= 8e-6 of the features' spread in every case -- the zero padding of the 3x3 convolution bounds
+    |mean| / sigma of its output by the plane's border fraction (~0.2-1.0 on 16x32 whatever offset the input carries),
+    so the one-pass form never leaves its accurate range on this network; the assertions pin that."""
+    w = load_weights("gta_sfm_150epochs")
+    net = net_for("gta_sfm_150epochs")
+    eng = net.engine()
+    N = 2
+    g = torch.Generator().manual_seed(D)
+    src4 = torch.rand(N, 3, 16, 32, generator=g) * 2 - 1
+    F0 = torch.randn(N, 32, 16, 32, generator=g)
+    FL = torch.randn(N, 32, 16, 32, generator=g)
+    if case == "long":
+        H, Hinc = _motion_family(N, D, "small", seed=D)
+        # keep the sweep inside the image: small zero-mean steps
+        Hinc[:, 1:, 0, 2] *= 0.15
+        Hinc[:, 1:, 1, 2] *= 0.1
+        H = torch.eye(3).repeat(N, D, 1, 1)
+        for d in range(1, D):
+            H[:, d] = H[:, d - 1] @ Hinc[:, d]
+    else:
+        # image planes alternate between the two halves of a source that is +40 on the left and -40 on the right
+        src4[:, :, :, :16] += 40.0
+        src4[:, :, :, 16:] -= 40.0
+        H = torch.eye(3).repeat(N, D, 1, 1)
+        for d in range(D):
+            H[:, d, 0, 0] = 0.45                                   # the plane shows half of the source ...
+            H[:, d, 0, 2] = 0.5 if d % 2 == 0 else 16.5           # ... the bright half on even planes, the dark on odd
+        Hinc = torch.eye(3).repeat(N, D, 1, 1)
+        Hinc[:, 1:, 0, 2] = 0.3
+        if case == "offset":
+            F0 = F0 * 0.05 + 300.0
+    fvol_ref, cost_ref, mask_ref = _oracle_chain(w, src4, H, Hinc, F0, FL)
+    dev = [x.to(DEV) for x in (src4, H, Hinc, F0, FL)]
+    net.options.chain_form = form
+    try:
+        cost, mask, fvol = eng.incremental_cost_volume(*dev, want_features=True)
+        assert eng.chain_status() == 0
+    finally:
+        net.options.chain_form = "auto"
+    assert int((mask.cpu() != mask_ref).sum()) == 0
+    assert bool(torch.isfinite(fvol).all())
+    mean_rel, max_rel = rel_err(fvol.cpu(), fvol_ref)
+    # per plane as well: a drift would grow along the recurrence
+    per_plane = [(fvol.cpu()[:, :, d] - fvol_ref[:, :, d]).abs().mean() / fvol_ref[:, :, d].abs().mean().clamp_min(1e-6)
+                 for d in (1, D // 2, D - 1)]
+    # against the features' spread, not their size: with the common offset the values are ~300 and a wrong variance
+    # would only move them by a fraction of their deviation
+    valid = (~mask_ref)[:, None].expand_as(fvol_ref)
+    spread = float(fvol_ref[valid].std())
+    vs_spread = float((fvol.cpu() - fvol_ref).abs().max()) / spread
+    print(f"chain[{form}] GN stress {case} D={D}: features mean-rel {mean_rel:.3e} max-rel {max_rel:.3e}; "
+          f"planes 1 / D/2 / D-1: {[f'{float(v):.2e}' for v in per_plane]}; max |err| / spread {vs_spread:.2e} "
+          f"(spread {spread:.3g})")
+    assert mean_rel < 2e-5 and max_rel < 2e-4, (case, D, form, mean_rel, max_rel)
+    assert vs_spread < 1e-3, (case, D, form, vs_spread)
+
+
 def test_banded_chain_hand_offs_under_uneven_load():
     """The inter-workgroup hand-offs (tagged granules) must not depend on timing or placement: the same launch
     repeated while a second stream keeps part of the chip busy with streaming copies of varying size must return
@@ -1332,6 +1408,49 @@ def test_conv_forward_carry_is_bit_identical(block, mode1, add2, n, jn, rows, co
     assert eng.carried_jobs - before == expect
     assert torch.equal(got_out, want_out) and torch.equal(got_st, want_st)
     assert torch.equal(jr2, want_job)
+
+
+@pytest.mark.parametrize("mode1,add2,n,jn,rows,cols,reverse", [
+    (False, False, 2, 2, 32, 64, 0), (False, False, 2, 2, 32, 64, 1),      # both walk directions
+    (True, True, 2, 2, 32, 64, 0), (True, True, 3, 3, 32, 64, 1),          # input transform + two-raw-tensor pass
+    (False, False, 5, 5, 16, 32, 0),                                        # one tile per image, 5 images on 256 CUs
+    (False, False, 3, 2, 48, 96, 1),                                        # ragged tile counts: 3 x 3 tiles, job smaller
+    (False, True, 7, 7, 64, 32, 0),                                         # one tile column, odd batch
+    (False, False, 1, 1, 256, 512, 1),                                      # a level-0 plane: 128 tiles of one image
+    (False, False, 9, 4, 80, 160, 0),                                       # 5 x 5 tiles x 9 images: > 256 work items
+])
+def test_carried_dilation1_launches_stress_bit_identical(mode1, add2, n, jn, rows, cols, reverse):
+    """The dilation-1 carrying launches issue their LDS-DMA as inline assembly (invisible to the compiler's waitcnt pass:
+    the ring and the carried loads are guarded by hand-counted s_waitcnt vmcnt(N), mvsn_conv_wino.hip wn_dma16 /
+    wait_landed).  A wrong count shows up as a stale LDS read, i.e. as a rare wrong word -- so: 1000 launches per shape
+    (nine shapes: both walk directions, ragged tile counts, more work items than CUs, both pass forms, the input
+    transform), every output word and every word of the carried pass compared with the two-call reference each time."""
+    eng = net_for("gta_sfm_150epochs").engine()
+    conv, norm = eng.refiners[0]["res"][0]          # dilation 1
+    norm0 = eng.refiners[0]["bn0"]
+    g = torch.Generator().manual_seed(rows * 7 + cols + n)
+    x = torch.randn(n, 32, rows, cols, generator=g).to(DEV)
+    jr = torch.randn(jn, 32, rows, cols, generator=g).to(DEV)
+    jres = torch.randn(jn, 32, rows, cols, generator=g).to(DEV)
+    st, st0, ist = _gn_stats(jn, 1), _gn_stats(jn, 2), _gn_stats(n, 3)
+    kw = dict(in_stats=ist if mode1 else None, in_norm=norm0 if mode1 else None, want_stats=True)
+    want_out, want_st = eng.conv(conv, x, **kw)
+    want_job = eng.gn_lrelu_add2(jr, st, norm, jres, st0, norm0) if add2 else eng.gn_lrelu(jr, st, norm, residual=jres)
+    from multi_view_stereonet_amd.multi_view_stereonet import _Job
+    jr2 = torch.empty_like(jr)
+    out = torch.empty_like(want_out)
+    before = eng.carried_jobs
+    bad = 0
+    iters = 1000
+    for it in range(iters):
+        jr2.copy_(jr)
+        job = _Job(jr2, st, norm, jres, st0 if add2 else None, norm0 if add2 else None)
+        job.job.reverse = reverse if it % 3 else 1 - reverse       # mostly one direction, every third launch the other
+        _, got_st = eng.conv(conv, x, carry=job, out=out, **kw)
+        ok = torch.equal(out, want_out) & torch.equal(got_st, want_st) & torch.equal(jr2, want_job)   # (syncs)
+        bad += 0 if ok else 1
+    assert eng.carried_jobs - before == iters, "the pass did not travel inside the launch: nothing was stressed"
+    assert bad == 0, f"{bad} of {iters} launches differed from the two-call reference"
 
 
 def test_sliced_refiner_tower_is_bit_identical():
