@@ -290,6 +290,10 @@ int mvsn_refiner_epilogue(const float *prior, const float *fx, const float *delt
  * ------------------------------------------------------------------------------------------- */
 int mvsn_upsample_bilinear(const float *in, int n, int channels, int rows_in, int cols_in, int rows_out,
                            int cols_out, float *out, mvsn_stream_t stream);
+/* upsample_bilinear of a one-channel idepth map plus its per-sample scaled copy out * fx[n] (the refiner's input
+ * channel idepth * fx, multi_view_stereonet.py:607-611) in one pass */
+int mvsn_upsample_prior(const float *in, const float *fx, int n, int rows_in, int cols_in, int rows_out, int cols_out,
+                        float *out, float *out_scaled, mvsn_stream_t stream);
 int mvsn_upsample_mask(const uint8_t *in, int n, int channels, int rows_in, int cols_in, int rows_out,
                        int cols_out, uint8_t *out, mvsn_stream_t stream);
 
@@ -357,6 +361,38 @@ int mvsn_occlusion_mask(const float *idepth_in_other, const float *other_sampled
                         const float *absdiff_partials, int batch, int pixels, uint8_t *mask, mvsn_stream_t stream);
 int mvsn_masked_l1(const float *a, const float *b, const uint8_t *skip_a, const uint8_t *skip_b, long n, int accumulate,
                    float *loss, mvsn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Plane-resident residual tower on the 16 x 32 coarse grid: ONE persistent workgroup per sample keeps the 32-channel
+ * activation planes in LDS and runs  [head conv + GroupNorm + LeakyReLU] -> n_blocks x (x + LReLU(GN(conv3x3_dilated(x))))
+ * -> tail  in a single launch.  Replaces, at level 4 of 512 x 256 frames,
+ *   - IDepthmapRefiner.forward (multi_view_stereonet.py:468-484) with the gain trick of :607-611
+ *     (head over [image 3 | features 32 | prior * fx], dilations 1,2,4,8,1,1, tail_mode 1: relu(prior*fx + conv_final)/fx),
+ *   - the residual stack + conv_final of FeatureNetwork.forward (:121-129; no head, tail_mode 0),
+ * i.e. the 15-21 launches of mvsn_conv_forward / mvsn_groupnorm_* the launch-per-layer form needs there.
+ *   in[b] (n_b, channels[b], 16, 32): up to three channel blocks, sample n reads block b at n % sample_mod[b]
+ *   block_scale (optional): block `scale_block` is multiplied by block_scale[n % scale_mod] while it is loaded
+ *   weights: the layers' Winograd-transformed weights (mvsn_conv_pack_weights, MVSN_CONV_FP32_WINO) re-ordered per
+ *            k-step as [cout tile][xi row][lane][xi column], layer after layer: head (9 k-steps), blocks (8 each),
+ *            and for tail_mode 0 the final 32 -> 32 layer
+ *   params:  [bias 32 | gamma 32 | beta 32] per layer (head, blocks), then tail_mode 0: bias 32;
+ *            tail_mode 1: the 32 -> 1 layer's weight (32 x 9) and bias (1)
+ *   out: tail_mode 0 (n, 32, 16, 32); tail_mode 1 (n, 1, 16, 32) with prior (n, 16, 32), fx[n % fx_mod]
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float *in[3];
+  int channels[3], sample_mod[3];
+  const float *block_scale;
+  int scale_mod, scale_block;
+  int head_chunks, n_blocks;
+  int dilation[6];
+  const float *weights, *params;
+  int tail_mode;
+  const float *prior, *fx;
+  int fx_mod;
+  float *out;
+} mvsn_tower_desc;
+int mvsn_tower_16x32(const mvsn_tower_desc *desc, int n_samples, mvsn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Depth metrics of a batch on the device: replaces the per-image host loop of test.py:210-235 + get_depth_prediction_metrics

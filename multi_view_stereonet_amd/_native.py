@@ -28,6 +28,14 @@ class ApplyJob(Structure):
                 ("out", c_void_p), ("n", c_int), ("reverse", c_int), ("spatial", c_long)]
 
 
+class TowerDesc(Structure):
+    """mvsn_tower_desc"""
+    _fields_ = [("inp", c_void_p * 3), ("channels", c_int * 3), ("sample_mod", c_int * 3), ("block_scale", c_void_p),
+                ("scale_mod", c_int), ("scale_block", c_int), ("head_chunks", c_int), ("n_blocks", c_int),
+                ("dilation", c_int * 6), ("weights", c_void_p), ("params", c_void_p), ("tail_mode", c_int),
+                ("prior", c_void_p), ("fx", c_void_p), ("fx_mod", c_int), ("out", c_void_p)]
+
+
 CONV_FP32, CONV_BF16X3, CONV_FP32_WINO, CONV_BF16 = 0, 1, 2, 3
 CHAIN_AUTO, CHAIN_DIRECT, CHAIN_WINOGRAD, CHAIN_STEPWISE, CHAIN_BANDED = 0, 1, 2, 3, 4
 ABI_VERSION = 2
@@ -67,6 +75,7 @@ SIGNATURES = {
     "mvsn_idepth_scale": (c_int, [c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p]),
     "mvsn_refiner_epilogue": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p]),
     "mvsn_upsample_bilinear": (c_int, [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
+    "mvsn_upsample_prior": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p] * 3),
     "mvsn_upsample_mask": (c_int, [c_void_p] + [c_int] * 6 + [c_void_p, c_void_p]),
     "mvsn_image_pyramid_supported": (c_int, [c_int] * 3),
     "mvsn_image_pyramid": (c_int, [c_void_p] + [c_int] * 5 + [POINTER(c_void_p), c_void_p]),
@@ -77,6 +86,7 @@ SIGNATURES = {
     "mvsn_idepth_reproject": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_void_p] * 6 + [c_void_p]),
     "mvsn_occlusion_mask": (c_int, [c_void_p] * 4 + [c_int] * 2 + [c_void_p, c_void_p]),
     "mvsn_masked_l1": (c_int, [c_void_p] * 4 + [c_long, c_int, c_void_p, c_void_p]),
+    "mvsn_tower_16x32": (c_int, [POINTER(TowerDesc), c_int, c_void_p]),
     "mvsn_depth_metrics_blocks": (c_int, [c_long]),
     "mvsn_depth_metrics": (c_int, [c_void_p] * 3 + [c_int, c_long, ctypes.c_float, ctypes.c_float, c_void_p, c_void_p, c_void_p]),
     "mvsn_selftest_mfma": (c_int, [c_void_p]),

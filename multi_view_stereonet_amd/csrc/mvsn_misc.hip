@@ -15,10 +15,30 @@ __global__ __launch_bounds__(256) void soft_argmin_kernel(const float *__restric
   if (p >= P) return;
   const float *c = cost + (size_t)n * D * P + p;
   const float *s = samples + (size_t)n * D;
+  // (sixteen independent loads in flight per round: at batch 1 the kernel is one latency chain per pixel)
   float m = -INFINITY;
-  for (int d = 0; d < D; ++d) m = fmaxf(m, -c[(size_t)d * P]);
+  int d0 = 0;
+  for (; d0 + 16 <= D; d0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = c[(size_t)(d0 + j) * P];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) m = fmaxf(m, -v[j]);
+  }
+  for (int d = d0; d < D; ++d) m = fmaxf(m, -c[(size_t)d * P]);
   float den = 0.0f, num = 0.0f;
-  for (int d = 0; d < D; ++d) {
+  for (d0 = 0; d0 + 16 <= D; d0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = c[(size_t)(d0 + j) * P];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const float e = expf(-v[j] - m);
+      den += e;
+      num += e * s[d0 + j];
+    }
+  }
+  for (int d = d0; d < D; ++d) {
     float e = expf(-c[(size_t)d * P] - m);
     den += e;
     num += e * s[d];
@@ -92,6 +112,25 @@ __global__ __launch_bounds__(256) void upsample_kernel(const TIn *__restrict__ i
     out[(plane * hout + y) * wout + x] = (TOut)(v > 0.5f ? 1 : 0);
   else
     out[(plane * hout + y) * wout + x] = (TOut)v;
+}
+
+// The coarse-to-fine step's prior: the upsampled idepth map AND its fx-scaled copy (the refiner's input channel,
+// multi_view_stereonet.py:607-611) from one pass -- the scaling no longer costs a launch per level.
+__global__ __launch_bounds__(256) void upsample_gain_kernel(const float *__restrict__ in, const float *__restrict__ gain,
+                                                            int hin, int win, int hout, int wout,
+                                                            float *__restrict__ out, float *__restrict__ out_scaled) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  const size_t plane = blockIdx.z;
+  if (x >= wout) return;
+  ResizeTap ty = resize_tap(y, hin, hout);
+  ResizeTap tx = resize_tap(x, win, wout);
+  const float *ip = in + plane * hin * win;
+  float v00 = ip[ty.i0 * win + tx.i0], v01 = ip[ty.i0 * win + tx.i1];
+  float v10 = ip[ty.i1 * win + tx.i0], v11 = ip[ty.i1 * win + tx.i1];
+  float v = ty.l0 * (tx.l0 * v00 + tx.l1 * v01) + ty.l1 * (tx.l0 * v10 + tx.l1 * v11);
+  out[(plane * hout + y) * wout + x] = v;
+  out_scaled[(plane * hout + y) * wout + x] = v * gain[plane];
 }
 
 // Mask variant: each thread produces 16 consecutive output columns of one row and stores them as
@@ -259,6 +298,18 @@ extern "C" int mvsn_upsample_bilinear(const float *in, int n, int channels, int 
   hipLaunchKernelGGL((mvsn::upsample_kernel<float, float, false>), grid, dim3(256), 0, (hipStream_t)stream, in,
                      rows_in, cols_in, rows_out, cols_out, out);
   return mvsn::check_launch("mvsn_upsample_bilinear");
+}
+
+extern "C" int mvsn_upsample_prior(const float *in, const float *fx, int n, int rows_in, int cols_in, int rows_out,
+                                   int cols_out, float *out, float *out_scaled, mvsn_stream_t stream) {
+  MVSN_REQUIRE(in && fx && out && out_scaled, MVSN_E_BADARG, "mvsn_upsample_prior: null pointer");
+  MVSN_REQUIRE(n > 0 && rows_in > 0 && cols_in > 0 && rows_out > 0 && cols_out > 0, MVSN_E_BADARG,
+               "mvsn_upsample_prior: bad sizes");
+  MVSN_REQUIRE(n <= 65535 && rows_out <= 65535, MVSN_E_TOOLARGE, "mvsn_upsample_prior: grid");
+  dim3 grid((cols_out + 255) / 256, rows_out, n);
+  hipLaunchKernelGGL(mvsn::upsample_gain_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, fx, rows_in, cols_in,
+                     rows_out, cols_out, out, out_scaled);
+  return mvsn::check_launch("mvsn_upsample_prior");
 }
 
 extern "C" int mvsn_upsample_mask(const uint8_t *in, int n, int channels, int rows_in, int cols_in, int rows_out,
@@ -605,6 +656,9 @@ static int conv_to1_volume(const float *in, const float *weight, const float *bi
   const int nty = (rows + T3_TY - 1) / T3_TY, ntx = (cols + T3_TX - 1) / T3_TX;
   int nslab = 1;
   while (nslab < 8 && (long)n * nty * ntx * nslab < 1024 && depth / (nslab * 2) >= 8) nslab *= 2;
+  // a handful of chains on a small grid (batch 1: 2 x 1 tile): a plane is ~7 us of dependent load -> multiply -> LDS
+  // round trips, so thinner slabs (down to one output plane, its two halo planes re-read) while workgroups < CUs
+  while (nslab < depth && (long)n * nty * ntx * nslab * 2 <= device_cus()) nslab *= 2;
   const int zslab = (depth + nslab - 1) / nslab;
   const int nz = (depth + zslab - 1) / zslab;
   MVSN_REQUIRE(n <= 65535 && nz <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_to1: grid");

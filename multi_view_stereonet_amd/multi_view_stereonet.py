@@ -124,8 +124,11 @@ class EngineOptions:
         # ... the regulariser's three in-place passes the same way: measured +0.1-0.2 ms per 38.6 ms step only (a pass
         # costs the volume kernel about what it costs alone), so the regulariser stays one batch by default
         self.carry_volume_passes = False
+        # Plane-resident towers on the 16x32 coarse grid (mvsn_tower_16x32): the level-4 refiner and the extractor's
+        # residual stack as ONE launch each, one persistent workgroup per sample (15-21 launches otherwise)
+        self.towers = True
 
-    NAMES = ("carry_passes", "carry_min_bytes", "carry_volume_passes", "carry_alternate", "chain_form", "fold_residual_blocks", "conv_precision", "winograd", "winograd_with_input_transform",
+    NAMES = ("towers", "carry_passes", "carry_min_bytes", "carry_volume_passes", "carry_alternate", "chain_form", "fold_residual_blocks", "conv_precision", "winograd", "winograd_with_input_transform",
              "winograd_volume", "volume_materialise", "trim_tower_ends", "cat_free_heads")
 
 
@@ -209,6 +212,89 @@ class PlaneSweepEngine:
                                dilation=REFINER_DILATIONS[i]), _Norm(getattr(m, f"res{i}").bn1)) for i in range(6)],
                 "final": _Conv(lib, m.conv_final.weight, m.conv_final.bias),
             })
+
+        self._tower_packs = {}
+
+    # ---- plane-resident towers (16x32) -----------------------------------------------------------
+    @staticmethod
+    def _tower_weights(convs):
+        """Winograd-transformed weights of the layers in the tower kernel's order: per k-step
+        [cout tile][xi row][lane][xi column] (mvsn_conv_pack_weights gives [xi][cout tile][lane])."""
+        parts = [c.packed_wino.view(-1, 4, 4, 2, 64).permute(0, 3, 1, 4, 2).contiguous().view(-1) for c in convs]
+        return torch.cat(parts).contiguous()
+
+    def _tower_pack(self, which: str):
+        if which in self._tower_packs:
+            return self._tower_packs[which]
+        pack = None
+        if which == "refiner4":
+            p = self.refiners[4]
+            convs = [p["conv0"]] + [c for c, _ in p["res"]]
+            norms = [p["bn0"]] + [n for _, n in p["res"]]
+            fin = p["final"]
+            if all(c.packed_wino is not None for c in convs) and fin.cout == 1 and fin.cin == 32 and p["conv0"].cin == 36:
+                dev = fin.weight.device
+                zeros = torch.zeros(32, dtype=torch.float32, device=dev)
+                params = []
+                for c, nm in zip(convs, norms):
+                    params += [c.bias if c.bias is not None else zeros, nm.gamma, nm.beta]
+                params += [fin.weight.reshape(-1), fin.bias if fin.bias is not None else zeros[:1]]
+                pack = (self._tower_weights(convs), torch.cat([t.reshape(-1) for t in params]).contiguous(),
+                        [c.dilation for c, _ in p["res"]])
+        else:
+            convs = [c for c, _ in self.fe_res]
+            fin = self.fe_final
+            if all(c.packed_wino is not None for c in convs + [fin]):
+                dev = fin.packed_wino.device
+                zeros = torch.zeros(32, dtype=torch.float32, device=dev)
+                params = []
+                for c, nm in self.fe_res:
+                    params += [c.bias if c.bias is not None else zeros, nm.gamma, nm.beta]
+                params += [fin.bias if fin.bias is not None else zeros]
+                pack = (self._tower_weights(convs + [fin]), torch.cat([t.reshape(-1) for t in params]).contiguous(),
+                        [c.dilation for c, _ in self.fe_res])
+        self._tower_packs[which] = pack
+        return pack
+
+    def tower_extractor_tail(self, x: torch.Tensor) -> Optional[torch.Tensor]:
+        """The six residual blocks + conv_final of FeatureNetwork.forward (:121-129) on (n, 32, 16, 32) as one launch."""
+        pack = self._tower_pack("extractor")
+        if pack is None or tuple(x.shape[1:]) != (32, 16, 32):
+            return None
+        U, params, dils = pack
+        x = x.contiguous()
+        out = torch.empty_like(x)
+        d = _native.TowerDesc()
+        d.inp[0], d.channels[0], d.sample_mod[0] = x.data_ptr(), 32, x.shape[0]
+        d.head_chunks, d.n_blocks, d.tail_mode = 0, len(dils), 0
+        for i, v in enumerate(dils):
+            d.dilation[i] = v
+        d.weights, d.params, d.out = U.data_ptr(), params.data_ptr(), out.data_ptr()
+        self._call("mvsn_tower_16x32[extractor blocks]", self.lib.mvsn_tower_16x32, ctypes.byref(d), x.shape[0],
+                   _native.stream(), flops=2.0 * 9 * 32 * 32 * 512 * 7 * x.shape[0], nbytes=8.0 * x.numel())
+        return out
+
+    def tower_refiner4(self, image4, feats4, prior, fx) -> Optional[torch.Tensor]:
+        """IDepthmapRefiner.forward at level 4 (:468-484, gain :607-611) for N chains sharing B reference images."""
+        pack = self._tower_pack("refiner4")
+        if pack is None or tuple(prior.shape[1:]) != (1, 16, 32) or tuple(feats4.shape[1:]) != (32, 16, 32):
+            return None
+        U, params, dils = pack
+        image4, feats4, prior, fx = image4.float().contiguous(), feats4.contiguous(), prior.contiguous(), fx.float().contiguous()
+        N, B = prior.shape[0], image4.shape[0]
+        out = torch.empty_like(prior)
+        d = _native.TowerDesc()
+        for b, (t, c, m) in enumerate(((image4, 3, B), (feats4, 32, B), (prior, 1, N))):
+            d.inp[b], d.channels[b], d.sample_mod[b] = t.data_ptr(), c, m
+        d.block_scale, d.scale_mod, d.scale_block = fx.data_ptr(), B, 2
+        d.head_chunks, d.n_blocks, d.tail_mode = 9, len(dils), 1
+        for i, v in enumerate(dils):
+            d.dilation[i] = v
+        d.weights, d.params = U.data_ptr(), params.data_ptr()
+        d.prior, d.fx, d.fx_mod, d.out = prior.data_ptr(), fx.data_ptr(), B, out.data_ptr()
+        self._call("mvsn_tower_16x32[refiner 4]", self.lib.mvsn_tower_16x32, ctypes.byref(d), N, _native.stream(),
+                   flops=2.0 * 9 * 32 * 512 * (36 + 6 * 32 + 1) * N, nbytes=4.0 * (36 + 1) * 512 * N)
+        return out
 
     # ---- primitive wrappers ------------------------------------------------------------------
     def _call(self, kernel: str, fn, *args, flops: float = 0.0, nbytes: float = 0.0):
@@ -515,6 +601,11 @@ class PlaneSweepEngine:
             x, _ = self.conv(self.fe_down[i], x)
             pyr.append(x)
         x, _ = self.conv(self.fe_down[3], x)
+        if self.towers and not self.fold_residual_blocks:
+            feats = self.tower_extractor_tail(x)
+            if feats is not None:
+                pyr.append(feats)
+                return pyr
         if self.fold_residual_blocks:
             pyr.append(self.residual_tower(x, None, self.fe_res, self.fe_final))
         else:
@@ -576,15 +667,18 @@ class PlaneSweepEngine:
             self.conv_to1_volume_norm(self.vf_convs[4], x[s_], stats[s_], self.vf_norms[3], out=out[a:e])
         return out
 
-    def idepth_refiner(self, level: int, guide, prior: torch.Tensor, fx: torch.Tensor) -> torch.Tensor:
+    def idepth_refiner(self, level: int, guide, prior: torch.Tensor, fx: torch.Tensor,
+                       scaled: Optional[torch.Tensor] = None) -> torch.Tensor:
         """`guide` is a tensor or a list of channel blocks (image, features): the refiner input
-        [guide..., prior * fx] is assembled with ONE concatenation."""
+        [guide..., prior * fx] is assembled with ONE concatenation.  `scaled` = prior * fx when the caller already
+        has it (upsample_prior forms it in the upsampling pass)."""
         p = self.refiners[level]
         prior, fx = prior.contiguous(), fx.contiguous()
         n, pixels = prior.shape[0], prior[0].numel()
-        scaled = torch.empty_like(prior)
-        self._call("mvsn_idepth_scale", self.lib.mvsn_idepth_scale, _native.ptr(prior), _native.ptr(fx), n, pixels,
-                   _native.ptr(scaled), _native.stream(), nbytes=8.0 * prior.numel())
+        if scaled is None:
+            scaled = torch.empty_like(prior)
+            self._call("mvsn_idepth_scale", self.lib.mvsn_idepth_scale, _native.ptr(prior), _native.ptr(fx), n, pixels,
+                       _native.ptr(scaled), _native.stream(), nbytes=8.0 * prior.numel())
         x_in = (list(guide) if isinstance(guide, (list, tuple)) else [guide]) + [scaled]
         rows, cols = prior.shape[-2], prior.shape[-1]
         if (self.carry_passes and not self.fold_residual_blocks and self.trim_tower_ends and n >= 2 and
@@ -685,6 +779,17 @@ class PlaneSweepEngine:
                    int(size[1]), _native.ptr(out), _native.stream(), nbytes=4.0 * (x.numel() + out.numel()))
         return out
 
+    def upsample_prior(self, x: torch.Tensor, fx: torch.Tensor, size):
+        """upsample(x) and upsample(x) * fx[n] (the next refiner's prior and its input channel) in one launch."""
+        n, c, h, w = x.shape
+        assert c == 1
+        out = torch.empty((n, 1, int(size[0]), int(size[1])), dtype=torch.float32, device=x.device)
+        scaled = torch.empty_like(out)
+        self._call("mvsn_upsample_prior", self.lib.mvsn_upsample_prior, _native.ptr(x), _native.ptr(fx), n, h, w,
+                   int(size[0]), int(size[1]), _native.ptr(out), _native.ptr(scaled), _native.stream(),
+                   nbytes=4.0 * (x.numel() + 2 * out.numel()))
+        return out, scaled
+
     def upsample_mask(self, m: torch.Tensor, size) -> torch.Tensor:
         n, c, h, w = m.shape
         out = torch.empty((n, c, int(size[0]), int(size[1])), dtype=torch.bool, device=m.device)
@@ -746,9 +851,13 @@ class PlaneSweepEngine:
 
         # 6. level-4 refinement per chain, then fuse the sources
         if do_refiners[4]:
-            guide4 = torch.cat([left_image_pyr[-1].float(), left_feats[-1]], 1).repeat(S, 1, 1, 1)
-            fx4 = K_pyr[-1][:, 0, 0].float().repeat(S)
-            refined = self.idepth_refiner(4, guide4, raw, fx4)
+            refined = None
+            if self.towers and not self.fold_residual_blocks:
+                refined = self.tower_refiner4(left_image_pyr[-1], left_feats[-1], raw, K_pyr[-1][:, 0, 0])
+            if refined is None:
+                guide4 = torch.cat([left_image_pyr[-1].float(), left_feats[-1]], 1).repeat(S, 1, 1, 1)
+                fx4 = K_pyr[-1][:, 0, 0].float().repeat(S)
+                refined = self.idepth_refiner(4, guide4, raw, fx4)
         else:
             refined = None
         raw4, idepth4, mask4 = self.fuse_sources(raw, refined, baseline, mask, S, B, alias=refined is None)
@@ -765,12 +874,16 @@ class PlaneSweepEngine:
         prior[4], idepth[4], masks[4] = raw4, idepth4, mask4
         for lvl in (3, 2, 1, 0):
             size = left_image_pyr[lvl].shape[-2:]
-            prior[lvl] = self.upsample(idepth[lvl + 1], size)
+            if do_refiners[lvl]:
+                fx = K_pyr[lvl][:, 0, 0].float().contiguous()
+                prior[lvl], scaled = self.upsample_prior(idepth[lvl + 1].contiguous(), fx, size)
+            else:
+                prior[lvl] = self.upsample(idepth[lvl + 1], size)
             masks[lvl] = self.upsample_mask(masks[lvl + 1], size)
             if do_refiners[lvl]:
                 img = left_image_pyr[lvl].float()
                 guide = [img] if lvl == 0 else [img, left_feats[lvl]]
-                idepth[lvl] = self.idepth_refiner(lvl, guide, prior[lvl], K_pyr[lvl][:, 0, 0].float())
+                idepth[lvl] = self.idepth_refiner(lvl, guide, prior[lvl], fx, scaled=scaled)
             else:
                 idepth[lvl] = prior[lvl]
         return {"left_idepthmap_pyr": idepth, "left_idepthmap_raw_pyr": prior, "left_idepthmap_mask_pyr": masks}

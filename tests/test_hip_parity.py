@@ -604,6 +604,49 @@ def test_idepth_refiner_golden_units():
         close(out, fix[f"idr{lvl}_out"], rtol=1e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("wname", ["gta_sfm_150epochs", "demon_45epochs", None])
+def test_plane_resident_towers_vs_oracle(wname):
+    """mvsn_tower_16x32 (one persistent workgroup per sample, activations resident in LDS): the extractor's residual
+    stack + conv_final and the level-4 refiner (head over [image | features | prior*fx], dilations 1,2,4,8,1,1, the
+    32 -> 1 tail with the gain epilogue) against the oracle's layer-by-layer form AND against this library's own
+    launch-per-layer path, for chains that share reference images (N = S * B)."""
+    w = load_weights(wname) if wname else default_init_weights(0)
+    net = net_for(wname)
+    eng = net.engine()
+    g = torch.Generator().manual_seed(17)
+    # extractor tail
+    x = torch.randn(5, 32, 16, 32, generator=g)
+    ref = x
+    for i in range(6):
+        ref = oracle._res_block(w, f"left_feature_extractor.res{i}", ref)
+    ref = oracle._conv(w, "left_feature_extractor.conv_final", ref)
+    got = eng.tower_extractor_tail(x.to(DEV))
+    assert got is not None
+    mean_rel, max_rel = rel_err(got.cpu(), ref)
+    print(f"tower[extractor, {wname}]: mean-rel {mean_rel:.3e} max-rel {max_rel:.3e}")
+    assert mean_rel < 2e-5 and max_rel < 2e-4
+    want, _ = eng.residual_tower_unfused(x.to(DEV), None, eng.fe_res, eng.fe_final)
+    mean_rel, max_rel = rel_err(got.cpu(), want.cpu())
+    assert mean_rel < 2e-5 and max_rel < 2e-4
+    # level-4 refiner, S = 3 chains per reference image
+    B, S = 2, 3
+    img = torch.rand(B, 3, 16, 32, generator=g) * 2 - 1
+    feats = torch.randn(B, 32, 16, 32, generator=g)
+    prior = 0.02 + 0.2 * torch.rand(S * B, 1, 16, 32, generator=g)
+    fx = 20.0 + 10.0 * torch.rand(B, generator=g)
+    fxn = fx.repeat(S).view(-1, 1, 1, 1)
+    guide = torch.cat([img, feats], 1).repeat(S, 1, 1, 1)
+    ref = oracle.idepth_refiner(w, "refiner4", guide, prior * fxn) / fxn
+    got = eng.tower_refiner4(img.to(DEV), feats.to(DEV), prior.to(DEV), fx.to(DEV))
+    assert got is not None
+    mean_rel, max_rel = rel_err(got.cpu(), ref)
+    print(f"tower[refiner 4, {wname}]: mean-rel {mean_rel:.3e} max-rel {max_rel:.3e}")
+    assert mean_rel < 2e-5 and max_rel < 2e-4
+    want = eng.idepth_refiner(4, guide.to(DEV), prior.to(DEV), fx.repeat(S).to(DEV))
+    mean_rel, max_rel = rel_err(got.cpu(), want.cpu())
+    assert mean_rel < 2e-5 and max_rel < 2e-4
+
+
 def test_upsamplers_golden_units():
     fix = load_golden("g4_units.npz")
     eng = net_for("gta_sfm_150epochs").engine()

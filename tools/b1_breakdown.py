@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Per-call breakdown of one batch-B forward (device events around every library call, launch gaps included)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from multi_view_stereonet_amd import MultiViewStereoNet
+from multi_view_stereonet_amd.weights import load_weights
+torch.set_grad_enabled(False)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+dev = torch.device("cuda")
+net = MultiViewStereoNet(); net.load_state_dict(load_weights(bench.WEIGHTS)); net = net.to(dev).eval()
+_, inp = bench.make_inputs(B, 7, dev)
+for _ in range(3): bench.run_forward(net, inp)
+agg = bench.kernel_breakdown(net, inp)
+tot = sum(v["ms"] for v in agg.values())
+print(f"B={B}: {sum(v['launches'] for v in agg.values())} calls, {tot:.3f} ms inside calls")
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+    print(f"  {v['ms']*1e3:8.1f} us {v['launches']:3d} x {v['ms']/v['launches']*1e3:7.1f}  {k}")
