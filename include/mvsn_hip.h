@@ -408,6 +408,12 @@ int mvsn_depth_metrics_blocks(long pixels);
 int mvsn_depth_metrics(const float *idepth_est, const float *depth_true, const float *baseline, int batch, long pixels,
                        float min_depth, float max_depth, double *partials, double *rows, mvsn_stream_t stream);
 
+/* Tensor plumbing of the forward as library calls (so that a whole forward is a replayable list of C calls and nothing
+ * else): a device-to-device copy on the stream (the torch.cat / repeat of poses, intrinsics and coarse source images,
+ * multi_view_stereonet.py:553,:587-592) and dst[i] = src[i * stride] (the focal lengths K[:, 0, 0], :607). */
+int mvsn_copy(void *dst, const void *src, size_t nbytes, mvsn_stream_t stream);
+int mvsn_gather_strided(const float *src, int count, long stride, float *dst, mvsn_stream_t stream);
+
 /* Device self-test of the MFMA fragment mapping the conv kernels rely on (A = 16x4, B = 4x16
  * fp32, asymmetric operands); returns 0 when the on-device result matches the scalar product. */
 int mvsn_selftest_mfma(mvsn_stream_t stream);

@@ -89,6 +89,8 @@ SIGNATURES = {
     "mvsn_tower_16x32": (c_int, [POINTER(TowerDesc), c_int, c_void_p]),
     "mvsn_depth_metrics_blocks": (c_int, [c_long]),
     "mvsn_depth_metrics": (c_int, [c_void_p] * 3 + [c_int, c_long, ctypes.c_float, ctypes.c_float, c_void_p, c_void_p, c_void_p]),
+    "mvsn_copy": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mvsn_gather_strided": (c_int, [c_void_p, c_int, c_long, c_void_p, c_void_p]),
     "mvsn_selftest_mfma": (c_int, [c_void_p]),
 }
 

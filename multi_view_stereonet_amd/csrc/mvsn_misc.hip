@@ -261,6 +261,31 @@ extern "C" int mvsn_soft_argmin(const float *cost, const float *idepth_samples, 
   return mvsn::check_launch("mvsn_soft_argmin");
 }
 
+namespace mvsn {
+__global__ void gather_strided_kernel(const float *__restrict__ src, int count, long stride, float *__restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) dst[i] = src[(size_t)i * stride];
+}
+}  // namespace mvsn
+
+extern "C" int mvsn_copy(void *dst, const void *src, size_t nbytes, mvsn_stream_t stream) {
+  MVSN_REQUIRE(dst && src, MVSN_E_BADARG, "mvsn_copy: null pointer");
+  if (nbytes == 0) return 0;
+  hipError_t e = hipMemcpyAsync(dst, src, nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+  if (e != hipSuccess) {
+    mvsn::set_error("mvsn_copy: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+extern "C" int mvsn_gather_strided(const float *src, int count, long stride, float *dst, mvsn_stream_t stream) {
+  MVSN_REQUIRE(src && dst && count > 0 && stride > 0, MVSN_E_BADARG, "mvsn_gather_strided: bad arguments");
+  hipLaunchKernelGGL(mvsn::gather_strided_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, count,
+                     stride, dst);
+  return mvsn::check_launch("mvsn_gather_strided");
+}
+
 extern "C" int mvsn_channel_l2_norm(const float *x, int n, int channels, long pixels, float *out,
                                     mvsn_stream_t stream) {
   MVSN_REQUIRE(x && out, MVSN_E_BADARG, "mvsn_channel_l2_norm: null pointer");

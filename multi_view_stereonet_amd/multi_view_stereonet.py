@@ -127,8 +127,12 @@ class EngineOptions:
         # Plane-resident towers on the 16x32 coarse grid (mvsn_tower_16x32): the level-4 refiner and the extractor's
         # residual stack as ONE launch each, one persistent workgroup per sample (15-21 launches otherwise)
         self.towers = True
+        # Forwards of at most this many chains (S * B) are recorded once per input shape and replayed afterwards
+        # (ForwardPlan: same calls, same arguments, ~2 us of host time per launch instead of ~23); 0 = always eager.
+        self.plan_max_chains = 16
+        self.plan_graph = True     # ... and from the second replay on the call list is launched as one hipGraph
 
-    NAMES = ("towers", "carry_passes", "carry_min_bytes", "carry_volume_passes", "carry_alternate", "chain_form", "fold_residual_blocks", "conv_precision", "winograd", "winograd_with_input_transform",
+    NAMES = ("towers", "plan_max_chains", "plan_graph", "carry_passes", "carry_min_bytes", "carry_volume_passes", "carry_alternate", "chain_form", "fold_residual_blocks", "conv_precision", "winograd", "winograd_with_input_transform",
              "winograd_volume", "volume_materialise", "trim_tower_ends", "cat_free_heads")
 
 
@@ -150,6 +154,34 @@ class _Job:
             eng.gn_lrelu_add2(r, stats, norm, residual, r_stats, r_norm, out=r)
         else:
             eng.gn_lrelu(r, stats, norm, residual=residual, out=r)
+
+
+class ForwardPlan:
+    """One recorded forward: the library calls it consists of (function, arguments without the stream), every
+    intermediate tensor those arguments point into, static copies of the inputs, and the output tensors.
+
+    A forward at small batch is ~110 dependent launches of a few microseconds each; issued from Python one ctypes call
+    at a time the host needs ~23 us per launch (argument checks, allocations, descriptor set-up: 2.6 ms per batch-1
+    forward -- as long as the device takes).  All of that depends on the SHAPES only.  So the first forward of a shape
+    is recorded while it runs, and later ones replay the list: inputs are copied into the plan's static tensors (one
+    multi-tensor copy), each recorded call is re-issued with its recorded arguments on the current stream (~2 us of
+    host time per call), and the outputs are copied into fresh tensors (so results stay valid after the next call,
+    unlike a graph replay's).  Same kernels, same arguments, same order: bit-identical to the eager forward."""
+
+    def __init__(self):
+        self.calls, self.keep = [], []
+        self.replayable = True
+        self.static_inputs: List[torch.Tensor] = []
+        self.outputs: Optional[dict] = None
+        self.graph = None          # hipGraph of the call list (None: not captured yet, False: capture refused)
+        self.uses = 0
+
+    def replay(self):
+        stream = _native.stream()
+        for fn, args, name in self.calls:
+            rc = fn(*args, stream)
+            if rc != 0:
+                _native.check(rc, name)
 
 
 class PlaneSweepEngine:
@@ -175,6 +207,9 @@ class PlaneSweepEngine:
         # such launches must not share the device (MultiViewStereoNet._forward_lanes clears this for its lanes).
         self.banded_ok = True
         self.last_chain_form, self.last_chain_workspace = None, None
+        self.recording: Optional["ForwardPlan"] = None    # the plan a forward is being recorded into
+        self.plans: Dict[tuple, Optional[ForwardPlan]] = {}   # shape key -> plan (None: that shape runs eagerly)
+        self.replays = 0
         self._carried_before = {}
         # tuning switches live on the module (EngineOptions), so they survive every rebuild of this object
         # (.to(), load_state_dict, in-place parameter updates); `engine.<switch>` reads and writes through
@@ -263,7 +298,7 @@ class PlaneSweepEngine:
             return None
         U, params, dils = pack
         x = x.contiguous()
-        out = torch.empty_like(x)
+        out = self.empty(x.shape, x.dtype, x.device)
         d = _native.TowerDesc()
         d.inp[0], d.channels[0], d.sample_mod[0] = x.data_ptr(), 32, x.shape[0]
         d.head_chunks, d.n_blocks, d.tail_mode = 0, len(dils), 0
@@ -280,9 +315,9 @@ class PlaneSweepEngine:
         if pack is None or tuple(prior.shape[1:]) != (1, 16, 32) or tuple(feats4.shape[1:]) != (32, 16, 32):
             return None
         U, params, dils = pack
-        image4, feats4, prior, fx = image4.float().contiguous(), feats4.contiguous(), prior.contiguous(), fx.float().contiguous()
+        image4, feats4, prior, fx = self.f32c(image4), self.f32c(feats4), self.f32c(prior), self.f32c(fx)
         N, B = prior.shape[0], image4.shape[0]
-        out = torch.empty_like(prior)
+        out = self.empty(prior.shape, prior.dtype, prior.device)
         d = _native.TowerDesc()
         for b, (t, c, m) in enumerate(((image4, 3, B), (feats4, 32, B), (prior, 1, N))):
             d.inp[b], d.channels[b], d.sample_mod[b] = t.data_ptr(), c, m
@@ -297,9 +332,56 @@ class PlaneSweepEngine:
         return out
 
     # ---- primitive wrappers ------------------------------------------------------------------
+    def empty(self, shape, dtype=torch.float32, device=None, **_):
+        """Device allocation of the launch sequence.  While a forward is being recorded into a plan (ForwardPlan) the
+        tensor is kept alive by the plan: its address is what the recorded calls hold."""
+        t = torch.empty(tuple(shape) if not isinstance(shape, int) else shape, dtype=dtype, device=device)
+        if self.recording is not None:
+            self.recording.keep.append(t)
+        return t
+
+    def _aten(self):
+        """Marks the forward being recorded as not replayable: an ATen kernel took part in it (a fallback path)."""
+        if self.recording is not None:
+            self.recording.replayable = False
+
+    def f32c(self, t: torch.Tensor) -> torch.Tensor:
+        """t as dense fp32 -- free when it already is (the normal case), an ATen copy otherwise."""
+        if t.dtype == torch.float32 and t.is_contiguous():
+            return t
+        self._aten()
+        return t.float().contiguous()
+
+    def copy_into(self, dst: torch.Tensor, src: torch.Tensor):
+        assert dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and dst.numel() == src.numel()
+        self._call("mvsn_copy", self.lib.mvsn_copy, _native.ptr(dst), _native.ptr(src),
+                   dst.numel() * dst.element_size(), _native.stream(), nbytes=2.0 * dst.numel() * dst.element_size())
+
+    def cat0(self, parts) -> torch.Tensor:
+        """torch.cat(parts, 0) of dense fp32 tensors as device copies into one allocation."""
+        parts = [self.f32c(t) for t in parts]
+        if len(parts) == 1:
+            return parts[0]
+        out = self.empty((sum(t.shape[0] for t in parts),) + tuple(parts[0].shape[1:]), torch.float32, parts[0].device)
+        at = 0
+        for t in parts:
+            self.copy_into(out[at:at + t.shape[0]], t)
+            at += t.shape[0]
+        return out
+
+    def focal(self, K: torch.Tensor) -> torch.Tensor:
+        """K[:, 0, 0] of (B, 4, 4) intrinsics as a dense (B,) tensor."""
+        K = self.f32c(K)
+        out = self.empty((K.shape[0],), torch.float32, K.device)
+        self._call("mvsn_gather_strided", self.lib.mvsn_gather_strided, _native.ptr(K), K.shape[0], K[0].numel(),
+                   _native.ptr(out), _native.stream())
+        return out
+
     def _call(self, kernel: str, fn, *args, flops: float = 0.0, nbytes: float = 0.0):
         if self.timeline is None:
             _native.check(fn(*args), kernel)
+            if self.recording is not None:
+                self.recording.calls.append((fn, args[:-1], kernel))      # (the last argument is always the stream)
             return
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
@@ -327,6 +409,7 @@ class PlaneSweepEngine:
                 if carry is not None:
                     carry.run_alone(self)
                 return res
+            self._aten()
             x = torch.cat(list(x), 1)
         n = x.shape[0]
         depth = x.shape[2] if c.dims == 3 else 1
@@ -354,13 +437,13 @@ class PlaneSweepEngine:
         ro, co = (rows - 1) // c.stride + 1, (cols - 1) // c.stride + 1
         shape = (n, c.cout, depth, ro, co) if c.dims == 3 else (n, c.cout, ro, co)
         if out is None:
-            out = torch.empty(shape, dtype=torch.float32, device=x.device)
+            out = self.empty(shape, dtype=torch.float32, device=x.device)
         assert tuple(out.shape) == shape and out.is_contiguous()
-        staged = torch.empty_like(x) if write_staged else None
+        staged = self.empty(x.shape, x.dtype, x.device) if write_staged else None
         partials = None
         if want_stats:
             tiles = lib.mvsn_conv_num_tiles(ctypes.byref(d))
-            partials = torch.empty((n, tiles, 4, 3), dtype=torch.float32, device=x.device)
+            partials = self.empty((n, tiles, 4, 3), dtype=torch.float32, device=x.device)
         taps = c.kd * c.kh * c.kw
         tag = (f"conv{c.dims}d k{c.kh}" + (f"s{c.stride}" if c.stride > 1 else "") +
                (f"d{c.dilation}" if c.dilation > 1 else "") + f" {c.cin}->{c.cout}" +
@@ -391,7 +474,7 @@ class PlaneSweepEngine:
                        _native.stream(), flops=2.0 * c.cin * taps * c.cout * out[:, 0].numel(), nbytes=nbytes)
         stats = None
         if want_stats:
-            stats = torch.empty((n, 4, 2), dtype=torch.float32, device=x.device)
+            stats = self.empty((n, 4, 2), dtype=torch.float32, device=x.device)
             self._call("mvsn_groupnorm_finalize", lib.mvsn_groupnorm_finalize, _native.ptr(partials), n,
                        partials.shape[1], _native.ptr(stats), _native.stream())
         if write_staged:
@@ -415,11 +498,11 @@ class PlaneSweepEngine:
         if any(b.data_ptr() % 16 for b in blocks):
             return None
         if out is None:
-            out = torch.empty((n, c.cout, rows, cols), dtype=torch.float32, device=x0.device)
+            out = self.empty((n, c.cout, rows, cols), dtype=torch.float32, device=x0.device)
         assert tuple(out.shape) == (n, c.cout, rows, cols) and out.is_contiguous()
         partials = None
         if want_stats:
-            partials = torch.empty((n, lib.mvsn_conv_num_tiles(ctypes.byref(d)), 4, 3), dtype=torch.float32,
+            partials = self.empty((n, lib.mvsn_conv_num_tiles(ctypes.byref(d)), 4, 3), dtype=torch.float32,
                                    device=x0.device)
         ptrs = (ctypes.c_void_p * len(blocks))(*[b.data_ptr() for b in blocks])
         chans = (ctypes.c_int * len(blocks))(*[b.shape[1] for b in blocks])
@@ -430,7 +513,7 @@ class PlaneSweepEngine:
                    nbytes=4.0 * (sum(b.numel() for b in blocks) + out.numel()))
         stats = None
         if want_stats:
-            stats = torch.empty((n, 4, 2), dtype=torch.float32, device=x0.device)
+            stats = self.empty((n, 4, 2), dtype=torch.float32, device=x0.device)
             self._call("mvsn_groupnorm_finalize", lib.mvsn_groupnorm_finalize, _native.ptr(partials), n,
                        partials.shape[1], _native.ptr(stats), _native.stream())
         return out, stats
@@ -446,7 +529,7 @@ class PlaneSweepEngine:
         n = x.shape[0]
         depth = x.shape[2] if c.dims == 3 else 1
         shape = (n, 1, depth, rows, cols) if c.dims == 3 else (n, 1, rows, cols)
-        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        out = self.empty(shape, dtype=torch.float32, device=x.device)
         self._call(f"mvsn_conv_to1[{c.dims}d]", self.lib.mvsn_conv_to1, _native.ptr(x), _native.ptr(c.weight),
                    _native.ptr(c.bias), _native.ptr(prior), _native.ptr(fx), n, depth, rows, cols,
                    3 if c.dims == 3 else 1, _native.ptr(out), _native.stream(),
@@ -504,7 +587,7 @@ class PlaneSweepEngine:
         rows, cols = blocks_in[0].shape[-2], blocks_in[0].shape[-1]
         dev = blocks_in[0].device
         conv0, bn0 = first
-        r0 = torch.empty((n, 32, rows, cols), dtype=torch.float32, device=dev)
+        r0 = self.empty((n, 32, rows, cols), dtype=torch.float32, device=dev)
         st0 = [self.conv(conv0, [b[a:e] for b in blocks_in], want_stats=True, out=r0[a:e])[1] for a, e in bounds]
         x = [None, None]                 # the slice's current block input (materialised by a carried pass)
         job = None
@@ -512,7 +595,7 @@ class PlaneSweepEngine:
         tails = []
         flip = 0
         for i, (conv, norm) in enumerate(blocks):
-            r = torch.empty((n, 32, rows, cols), dtype=torch.float32, device=dev)
+            r = self.empty((n, 32, rows, cols), dtype=torch.float32, device=dev)
             for s_, (a, e) in enumerate(bounds):
                 if job is not None and self.carry_alternate:
                     job.job.reverse = flip      # every other launch walks its tiles (and the job) from the end
@@ -531,14 +614,14 @@ class PlaneSweepEngine:
                 else:
                     job = _Job(r[a:e], st, norm, x[s_])                      # x_k = x_{k-1} + LReLU(GN(r_k))
                     x[s_] = r[a:e]
-        out = torch.empty((n, 1, rows, cols), dtype=torch.float32, device=dev)
+        out = self.empty((n, 1, rows, cols), dtype=torch.float32, device=dev)
         for (a, e), (r_, st, norm, x_) in zip(bounds, tails):
             self.conv_to1_block(final, r_, st, norm, x_, prior[a:e], fx[a:e], out=out[a:e])
         return out
 
     def gn_lrelu_add2(self, r, st, norm: _Norm, r0, st0, norm0: _Norm, out=None):
         n, spatial = r.shape[0], r[0, 0].numel()
-        out = torch.empty_like(r) if out is None else out
+        out = self.empty(r.shape, r.dtype, r.device) if out is None else out
         self._call("mvsn_groupnorm_lrelu_add2", self.lib.mvsn_groupnorm_lrelu_add2, _native.ptr(r), _native.ptr(st),
                    _native.ptr(norm.gamma), _native.ptr(norm.beta), _native.ptr(r0), _native.ptr(st0),
                    _native.ptr(norm0.gamma), _native.ptr(norm0.beta), n, spatial, _native.ptr(out), _native.stream(),
@@ -549,7 +632,7 @@ class PlaneSweepEngine:
         """conv_to1 on x + LReLU(GN(r)) without materialising it."""
         n, rows, cols = r.shape[0], r.shape[-2], r.shape[-1]
         if out is None:
-            out = torch.empty((n, 1, rows, cols), dtype=torch.float32, device=r.device)
+            out = self.empty((n, 1, rows, cols), dtype=torch.float32, device=r.device)
         assert tuple(out.shape) == (n, 1, rows, cols) and out.is_contiguous()
         self._call("mvsn_conv_to1_block", self.lib.mvsn_conv_to1_block, _native.ptr(r), _native.ptr(st),
                    _native.ptr(norm.gamma), _native.ptr(norm.beta), _native.ptr(x), _native.ptr(c.weight),
@@ -587,7 +670,7 @@ class PlaneSweepEngine:
                  out: Optional[torch.Tensor] = None):
         n = r.shape[0]
         spatial = r[0, 0].numel()
-        out = torch.empty_like(r) if out is None else out
+        out = self.empty(r.shape, r.dtype, r.device) if out is None else out
         self._call("mvsn_groupnorm_lrelu_apply", self.lib.mvsn_groupnorm_lrelu_apply, _native.ptr(r),
                    _native.ptr(stats), _native.ptr(norm.gamma), _native.ptr(norm.beta), _native.ptr(residual), n,
                    spatial, _native.ptr(out), _native.stream(),
@@ -638,7 +721,7 @@ class PlaneSweepEngine:
         """The HBM-bound 32 -> 1 pass; applies LReLU(GN(.)) of the fourth layer while it loads the raw volume."""
         n, _, depth, rows, cols = x.shape
         if out is None:
-            out = torch.empty((n, depth, rows, cols), dtype=torch.float32, device=x.device)
+            out = self.empty((n, depth, rows, cols), dtype=torch.float32, device=x.device)
         self._call("mvsn_conv_to1_volume_norm", self.lib.mvsn_conv_to1_volume_norm, _native.ptr(x), _native.ptr(st),
                    _native.ptr(nrm.gamma), _native.ptr(nrm.beta), _native.ptr(last.weight), _native.ptr(last.bias),
                    n, depth, rows, cols, _native.ptr(out), _native.stream(),
@@ -657,12 +740,12 @@ class PlaneSweepEngine:
         job = None
         stats = [None, None]
         for i in range(4):
-            r = torch.empty((n, 32, depth, rows, cols), dtype=torch.float32, device=cost.device)
+            r = self.empty((n, 32, depth, rows, cols), dtype=torch.float32, device=cost.device)
             for s_, (a, e) in enumerate(bounds):
                 _, stats[s_] = self.conv(self.vf_convs[i], x[s_], want_stats=True, carry=job, out=r[a:e])
                 job = _Job(r[a:e], stats[s_], self.vf_norms[i]) if i < 3 else None
                 x[s_] = r[a:e]
-        out = torch.empty((n, depth, rows, cols), dtype=torch.float32, device=cost.device)
+        out = self.empty((n, depth, rows, cols), dtype=torch.float32, device=cost.device)
         for s_, (a, e) in enumerate(bounds):
             self.conv_to1_volume_norm(self.vf_convs[4], x[s_], stats[s_], self.vf_norms[3], out=out[a:e])
         return out
@@ -676,7 +759,7 @@ class PlaneSweepEngine:
         prior, fx = prior.contiguous(), fx.contiguous()
         n, pixels = prior.shape[0], prior[0].numel()
         if scaled is None:
-            scaled = torch.empty_like(prior)
+            scaled = self.empty(prior.shape, prior.dtype, prior.device)
             self._call("mvsn_idepth_scale", self.lib.mvsn_idepth_scale, _native.ptr(prior), _native.ptr(fx), n, pixels,
                        _native.ptr(scaled), _native.stream(), nbytes=8.0 * prior.numel())
         x_in = (list(guide) if isinstance(guide, (list, tuple)) else [guide]) + [scaled]
@@ -696,7 +779,7 @@ class PlaneSweepEngine:
                                                       prior=prior, fx=fx)
         if done:
             return delta            # epilogue relu(prior*fx + delta)/fx already applied in the kernel
-        out = torch.empty_like(prior)
+        out = self.empty(prior.shape, prior.dtype, prior.device)
         self._call("mvsn_refiner_epilogue", self.lib.mvsn_refiner_epilogue, _native.ptr(prior), _native.ptr(fx),
                    _native.ptr(delta.contiguous()), n, pixels, _native.ptr(out), _native.stream(),
                    nbytes=12.0 * prior.numel())
@@ -705,9 +788,9 @@ class PlaneSweepEngine:
     def homography_warp(self, image: torch.Tensor, H: torch.Tensor, out: Optional[torch.Tensor] = None):
         B, C, rows, cols = image.shape
         n = H.shape[1]
-        vol = torch.empty((B, C, n, rows, cols), dtype=torch.float32, device=image.device) if out is None else out
+        vol = self.empty((B, C, n, rows, cols), dtype=torch.float32, device=image.device) if out is None else out
         assert vol.shape == (B, C, n, rows, cols) and vol.is_contiguous()
-        mask = torch.empty((B, n, rows, cols), dtype=torch.bool, device=image.device)
+        mask = self.empty((B, n, rows, cols), dtype=torch.bool, device=image.device)
         self._call("mvsn_homography_warp", self.lib.mvsn_homography_warp, _native.ptr(image), _native.ptr(H), B, C, n,
                    rows, cols, _native.ptr(vol), _native.ptr(mask), _native.stream(),
                    nbytes=4.0 * (image.numel() + vol.numel()) + mask.numel())
@@ -716,11 +799,11 @@ class PlaneSweepEngine:
     def plane_sweep_setup(self, T: torch.Tensor, K0: torch.Tensor, K4: torch.Tensor, rows4: int, cols4: int, D: int):
         N, dev = T.shape[0], T.device
         f = dict(dtype=torch.float32, device=dev)
-        samples = torch.empty((N, D), **f)
-        H4 = torch.empty((N, D, 3, 3), **f)
-        Hinc = torch.empty((N, D, 3, 3), **f)
-        H0 = torch.empty((N, 1, 3, 3), **f)
-        base = torch.empty((N,), **f)
+        samples = self.empty((N, D), **f)
+        H4 = self.empty((N, D, 3, 3), **f)
+        Hinc = self.empty((N, D, 3, 3), **f)
+        H0 = self.empty((N, 1, 3, 3), **f)
+        base = self.empty((N,), **f)
         self._call("mvsn_plane_sweep_setup", self.lib.mvsn_plane_sweep_setup, _native.ptr(T), _native.ptr(K0),
                    _native.ptr(K4), N, rows4, cols4, D, _native.ptr(samples), _native.ptr(H4), _native.ptr(Hinc),
                    _native.ptr(H0), _native.ptr(base), _native.stream())
@@ -731,9 +814,9 @@ class PlaneSweepEngine:
         B = left_feats.shape[0]
         D = H4.shape[1]
         dev = src4.device
-        cost = torch.empty((N, 32, D, rows, cols), dtype=torch.float32, device=dev)
-        mask = torch.empty((N, D, rows, cols), dtype=torch.bool, device=dev)
-        fvol = torch.empty_like(cost) if want_features else None
+        cost = self.empty((N, 32, D, rows, cols), dtype=torch.float32, device=dev)
+        mask = self.empty((N, D, rows, cols), dtype=torch.bool, device=dev)
+        fvol = self.empty(cost.shape, cost.dtype, cost.device) if want_features else None
         form = {"auto": _native.CHAIN_AUTO, "direct": _native.CHAIN_DIRECT, "winograd": _native.CHAIN_WINOGRAD,
                 "stepwise": _native.CHAIN_STEPWISE, "banded": _native.CHAIN_BANDED}[self.chain_form]
         if form == _native.CHAIN_AUTO:
@@ -745,7 +828,7 @@ class PlaneSweepEngine:
         if form == _native.CHAIN_STEPWISE and cols % 4 != 0:
             form = _native.CHAIN_DIRECT        # the Winograd convolutions of the stepwise form need cols % 4 == 0
         ws_bytes = self.lib.mvsn_incremental_cost_volume_workspace_bytes_for(N, D, rows, cols, form)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
+        ws = self.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
         self.last_chain_form, self.last_chain_workspace = form, ws
         P = rows * cols
         self._call("mvsn_incremental_cost_volume", self.lib.mvsn_incremental_cost_volume,
@@ -767,14 +850,14 @@ class PlaneSweepEngine:
 
     def soft_argmin(self, cost: torch.Tensor, samples: torch.Tensor) -> torch.Tensor:
         N, D, rows, cols = cost.shape
-        out = torch.empty((N, 1, rows, cols), dtype=torch.float32, device=cost.device)
+        out = self.empty((N, 1, rows, cols), dtype=torch.float32, device=cost.device)
         self._call("mvsn_soft_argmin", self.lib.mvsn_soft_argmin, _native.ptr(cost.contiguous()), _native.ptr(samples),
                    N, D, rows * cols, _native.ptr(out), _native.stream(), nbytes=4.0 * (cost.numel() + out.numel()))
         return out
 
     def upsample(self, x: torch.Tensor, size) -> torch.Tensor:
         n, c, h, w = x.shape
-        out = torch.empty((n, c, int(size[0]), int(size[1])), dtype=torch.float32, device=x.device)
+        out = self.empty((n, c, int(size[0]), int(size[1])), dtype=torch.float32, device=x.device)
         self._call("mvsn_upsample_bilinear", self.lib.mvsn_upsample_bilinear, _native.ptr(x), n, c, h, w, int(size[0]),
                    int(size[1]), _native.ptr(out), _native.stream(), nbytes=4.0 * (x.numel() + out.numel()))
         return out
@@ -783,8 +866,8 @@ class PlaneSweepEngine:
         """upsample(x) and upsample(x) * fx[n] (the next refiner's prior and its input channel) in one launch."""
         n, c, h, w = x.shape
         assert c == 1
-        out = torch.empty((n, 1, int(size[0]), int(size[1])), dtype=torch.float32, device=x.device)
-        scaled = torch.empty_like(out)
+        out = self.empty((n, 1, int(size[0]), int(size[1])), dtype=torch.float32, device=x.device)
+        scaled = self.empty(out.shape, out.dtype, out.device)
         self._call("mvsn_upsample_prior", self.lib.mvsn_upsample_prior, _native.ptr(x), _native.ptr(fx), n, h, w,
                    int(size[0]), int(size[1]), _native.ptr(out), _native.ptr(scaled), _native.stream(),
                    nbytes=4.0 * (x.numel() + 2 * out.numel()))
@@ -792,7 +875,7 @@ class PlaneSweepEngine:
 
     def upsample_mask(self, m: torch.Tensor, size) -> torch.Tensor:
         n, c, h, w = m.shape
-        out = torch.empty((n, c, int(size[0]), int(size[1])), dtype=torch.bool, device=m.device)
+        out = self.empty((n, c, int(size[0]), int(size[1])), dtype=torch.bool, device=m.device)
         self._call("mvsn_upsample_mask", self.lib.mvsn_upsample_mask, _native.ptr(m), n, c, h, w, int(size[0]),
                    int(size[1]), _native.ptr(out), _native.stream(), nbytes=float(m.numel() + out.numel()))
         return out
@@ -800,9 +883,9 @@ class PlaneSweepEngine:
     def fuse_sources(self, raw, refined, baseline, mask, S, B, alias):
         N, D, rows, cols = mask.shape
         dev = raw.device
-        raw_out = torch.empty((B, 1, rows, cols), dtype=torch.float32, device=dev)
-        ref_out = torch.empty((B, 1, rows, cols), dtype=torch.float32, device=dev)
-        mask_out = torch.empty((B, D, rows, cols), dtype=torch.bool, device=dev)
+        raw_out = self.empty((B, 1, rows, cols), dtype=torch.float32, device=dev)
+        ref_out = self.empty((B, 1, rows, cols), dtype=torch.float32, device=dev)
+        mask_out = self.empty((B, D, rows, cols), dtype=torch.bool, device=dev)
         self._call("mvsn_fuse_sources", self.lib.mvsn_fuse_sources, _native.ptr(raw), _native.ptr(refined),
                    _native.ptr(baseline), _native.ptr(mask), S, B, D, rows * cols, 1 if alias else 0,
                    _native.ptr(raw_out), _native.ptr(ref_out), _native.ptr(mask_out), _native.stream(),
@@ -813,37 +896,37 @@ class PlaneSweepEngine:
     def forward(self, left_image_pyr, K_pyr, T_right_in_lefts, right_image_pyrs, D, do_filter, do_refiners,
                 capture: Optional[dict] = None):
         S = len(T_right_in_lefts)
-        left0 = left_image_pyr[0].contiguous().float()
+        left0 = self.f32c(left_image_pyr[0])
         B = left0.shape[0]
         rows4, cols4 = left_image_pyr[-1].shape[-2:]
 
         # 1. set-up for all N = S*B chains (chain n = s*B + b)
-        T = torch.cat([t.float() for t in T_right_in_lefts], 0).contiguous()
-        K0 = K_pyr[0].float().repeat(S, 1, 1).contiguous()
-        K4 = K_pyr[-1].float().repeat(S, 1, 1).contiguous()
+        T = self.cat0(list(T_right_in_lefts))
+        K0 = self.cat0([K_pyr[0]] * S)
+        K4 = self.cat0([K_pyr[-1]] * S)
         samples, H4, Hinc, H0, baseline = self.plane_sweep_setup(T, K0, K4, rows4, cols4, D)
 
         # 2. full-resolution source images on plane 0, 3. one extractor batch
         #    (each source is warped straight into its slot of the extractor's frame batch)
-        frames = torch.empty(((S + 1) * B,) + tuple(left0.shape[1:]), dtype=torch.float32, device=left0.device)
-        frames[:B].copy_(left0)
+        frames = self.empty(((S + 1) * B,) + tuple(left0.shape[1:]), dtype=torch.float32, device=left0.device)
+        self.copy_into(frames[:B], left0)
         for s_, pyr in enumerate(right_image_pyrs):
-            self.homography_warp(pyr[0].float().contiguous(), H0[s_ * B:(s_ + 1) * B],
+            self.homography_warp(self.f32c(pyr[0]), H0[s_ * B:(s_ + 1) * B],
                                  out=frames[(s_ + 1) * B:(s_ + 2) * B].unsqueeze(2))
         warped0 = frames[B:].unsqueeze(2)
         feats = self.feature_network(frames)
-        left_feats = [f[:B].contiguous() for f in feats]
-        plane0 = feats[-1][B:].contiguous()
+        left_feats = [f[:B] for f in feats]        # (leading slices of dense tensors: dense)
+        plane0 = feats[-1][B:]
 
         # 4. the fused chain
-        src4 = torch.cat([p[-1].float() for p in right_image_pyrs], 0).contiguous()
+        src4 = self.cat0([p[-1] for p in right_image_pyrs])
         cost, mask, fvol = self.incremental_cost_volume(src4, H4, Hinc, plane0, left_feats[-1],
                                                         want_features=capture is not None)
         # 5. regularise + soft-argmin
         if do_filter:
             filtered = self.cost_volume_filter(cost)
         else:
-            filtered = torch.empty((cost.shape[0],) + tuple(cost.shape[2:]), dtype=torch.float32, device=cost.device)
+            filtered = self.empty((cost.shape[0],) + tuple(cost.shape[2:]), dtype=torch.float32, device=cost.device)
             self._call("mvsn_channel_l2_norm", self.lib.mvsn_channel_l2_norm, _native.ptr(cost), cost.shape[0],
                        cost.shape[1], cost[0, 0].numel(), _native.ptr(filtered), _native.stream(),
                        nbytes=4.0 * (cost.numel() + filtered.numel()))
@@ -853,11 +936,13 @@ class PlaneSweepEngine:
         if do_refiners[4]:
             refined = None
             if self.towers and not self.fold_residual_blocks:
-                refined = self.tower_refiner4(left_image_pyr[-1], left_feats[-1], raw, K_pyr[-1][:, 0, 0])
+                refined = self.tower_refiner4(self.f32c(left_image_pyr[-1]), left_feats[-1], raw, self.focal(K_pyr[-1]))
             if refined is None:
-                guide4 = torch.cat([left_image_pyr[-1].float(), left_feats[-1]], 1).repeat(S, 1, 1, 1)
-                fx4 = K_pyr[-1][:, 0, 0].float().repeat(S)
-                refined = self.idepth_refiner(4, guide4, raw, fx4)
+                # per chain: the guide blocks of its reference image (device copies, no concatenated tensor)
+                img4 = self.cat0([left_image_pyr[-1]] * S)
+                feats4 = self.cat0([left_feats[-1]] * S)
+                fx4 = self.cat0([self.focal(K_pyr[-1])] * S)
+                refined = self.idepth_refiner(4, [img4, feats4], raw, fx4)
         else:
             refined = None
         raw4, idepth4, mask4 = self.fuse_sources(raw, refined, baseline, mask, S, B, alias=refined is None)
@@ -875,13 +960,13 @@ class PlaneSweepEngine:
         for lvl in (3, 2, 1, 0):
             size = left_image_pyr[lvl].shape[-2:]
             if do_refiners[lvl]:
-                fx = K_pyr[lvl][:, 0, 0].float().contiguous()
-                prior[lvl], scaled = self.upsample_prior(idepth[lvl + 1].contiguous(), fx, size)
+                fx = self.focal(K_pyr[lvl])
+                prior[lvl], scaled = self.upsample_prior(idepth[lvl + 1], fx, size)
             else:
                 prior[lvl] = self.upsample(idepth[lvl + 1], size)
             masks[lvl] = self.upsample_mask(masks[lvl + 1], size)
             if do_refiners[lvl]:
-                img = left_image_pyr[lvl].float()
+                img = self.f32c(left_image_pyr[lvl])
                 guide = [img] if lvl == 0 else [img, left_feats[lvl]]
                 idepth[lvl] = self.idepth_refiner(lvl, guide, prior[lvl], fx, scaled=scaled)
             else:
@@ -989,8 +1074,71 @@ class MultiViewStereoNet(nn.Module):
             B = left_image_pyr[0].shape[0]
             lanes = min(self.stream_lanes, B) if capture is None else 1
             if lanes <= 1:
+                S = len(T_right_in_lefts)
+                if capture is None and eng.timeline is None and 0 < B * S <= self.options.plan_max_chains:
+                    return self._forward_planned(eng, left_image_pyr, K_pyr, T_right_in_lefts, right_image_pyrs, args)
                 return eng.forward(left_image_pyr, K_pyr, T_right_in_lefts, right_image_pyrs, *args, capture)
             return self._forward_lanes(eng, lanes, left_image_pyr, K_pyr, T_right_in_lefts, right_image_pyrs, args)
+
+    def _forward_planned(self, eng, left_image_pyr, K_pyr, T_right_in_lefts, right_image_pyrs, args):
+        """Small batches: record the forward once per shape, replay it afterwards (ForwardPlan)."""
+        S, L = len(T_right_in_lefts), len(left_image_pyr)
+        flat = list(left_image_pyr) + list(K_pyr) + list(T_right_in_lefts) + [x for p in right_image_pyrs for x in p]
+        opts = tuple(getattr(self.options, k) for k in EngineOptions.NAMES)
+        key = (tuple((tuple(t.shape), t.dtype) for t in flat), S, args[0], args[1], tuple(args[2]), opts, eng.banded_ok)
+        plan = eng.plans.get(key, False)
+
+        def unflatten(ts):
+            rp = ts[2 * L + S:]
+            return ts[:L], ts[L:2 * L], ts[2 * L:2 * L + S], [rp[i * L:(i + 1) * L] for i in range(S)]
+
+        if plan is None:                         # this shape took an ATen fallback somewhere: always eager
+            return eng.forward(left_image_pyr, K_pyr, T_right_in_lefts, right_image_pyrs, *args, None)
+        if plan is False:
+            plan = ForwardPlan()
+            plan.static_inputs = [t.detach().clone(memory_format=torch.contiguous_format) for t in flat]
+            eng.recording = plan
+            try:
+                plan.outputs = eng.forward(*unflatten(plan.static_inputs), *args, None)
+            finally:
+                eng.recording = None
+            if len(eng.plans) >= 8:              # a handful of shapes at most: drop the oldest
+                eng.plans.pop(next(iter(eng.plans)))
+            eng.plans[key] = plan if plan.replayable else None
+        else:
+            torch._foreach_copy_(plan.static_inputs, flat)
+            plan.uses += 1
+            if plan.graph is None and self.options.plan_graph and plan.uses >= 2:
+                # every address in the recorded calls is static: from its second replay on, the call list runs as
+                # ONE hipGraph launch (captured by replaying it under stream capture)
+                try:
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        plan.replay()
+                    plan.graph = g
+                except Exception:                       # capture refused (e.g. a foreign capture in progress): stay on the list
+                    plan.graph = False
+            if plan.graph:
+                plan.graph.replay()
+            else:
+                plan.replay()
+            eng.replays += 1
+        # fresh output tensors (a caller may keep them across forwards)
+        out, news, olds = {}, [], []
+        for k, lst in plan.outputs.items():
+            out[k] = []
+            for t in lst:
+                if t is None:
+                    out[k].append(None)
+                    continue
+                n = torch.empty_like(t)
+                out[k].append(n)
+                news.append(n)
+                olds.append(t)
+        for dt in {t.dtype for t in olds}:
+            torch._foreach_copy_([n for n in news if n.dtype == dt], [o for o in olds if o.dtype == dt])
+        return out
 
     def _forward_lanes(self, eng, lanes, left_image_pyr, K_pyr, T_right_in_lefts, right_image_pyrs, args):
         """Images are independent, so the batch is cut into `lanes` slices that run on their own HIP

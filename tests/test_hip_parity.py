@@ -1354,6 +1354,47 @@ def test_two_view_consistency_ops_golden():
         losses.get_occlusion_mask(Ks[0].cpu(), T.cpu(), L[0].cpu(), None, R[0].cpu(), None)     # no CPU path
 
 
+def test_forward_plan_replay_is_bit_identical():
+    """Small batches run from a recorded plan (ForwardPlan: the library calls of the first forward of a shape, replayed
+    with their recorded arguments).  The replay must equal the eager forward bit for bit on NEW input values, its
+    outputs must survive the next forward, and a different shape must get its own plan."""
+    net = net_for("gta_sfm_150epochs")
+    eng = net.engine()
+    D = 16
+
+    def inputs(seed, rows=64, cols=128, S=2, B=1):
+        return to_dev(snu.multi_view_unpack_batch(synthetic.make_batch(rows, cols, S, batch=B, seed=seed, smooth=True),
+                                                  torch.device("cpu"), 5))
+
+    def run(inp):
+        return net(*inp, D, True, [True] * 5)
+
+    def same(a, b):
+        return all((x is None and y is None) or torch.equal(x, y) for k in a for x, y in zip(a[k], b[k]))
+
+    old = net.options.plan_max_chains
+    try:
+        net.options.plan_max_chains = 0
+        eager = [run(inputs(s)) for s in (1, 2, 3)]
+        eager_other = run(inputs(4, rows=96, cols=160, S=1, B=2))
+        net.options.plan_max_chains = 16
+        before = eng.replays
+        first = run(inputs(1))                 # records
+        second = run(inputs(2))                # replays with new values
+        third = run(inputs(3))
+        assert eng.replays - before == 2
+        assert same(first, eager[0]) and same(second, eager[1]) and same(third, eager[2])
+        assert same(second, eager[1])          # (not clobbered by the third forward)
+        other = run(inputs(4, rows=96, cols=160, S=1, B=2))     # another shape: its own plan
+        other2 = run(inputs(4, rows=96, cols=160, S=1, B=2))
+        assert same(other, eager_other) and same(other2, eager_other)
+        assert same(run(inputs(2)), eager[1])  # and back (by now the call list runs as a hipGraph)
+        assert same(run(inputs(3)), eager[2])
+        assert any(p is not None and p.graph for p in eng.plans.values())
+    finally:
+        net.options.plan_max_chains = old
+
+
 def test_graph_replay_matches_eager():
     """hipGraph capture of the whole forward: replay on new inputs equals the eager launch sequence."""
     from multi_view_stereonet_amd.graphed import GraphedForward

@@ -12,11 +12,19 @@ dev = torch.device("cuda")
 net = MultiViewStereoNet(); net.load_state_dict(load_weights(bench.WEIGHTS)); net = net.to(dev).eval()
 net.stream_lanes = lanes
 _, inp = bench.make_inputs(B, 7, dev)
-for _ in range(2):
-    bench.run_forward(net, inp)
-torch.cuda.synchronize()
-t0 = time.perf_counter(); bench.run_forward(net, inp); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
-print(f"B={B} lanes={lanes}: host enqueue {1e3*(t1-t0):.2f} ms, until idle {1e3*(t2-t0):.2f} ms")
+for mode, cap, gr in (("eager (one ctypes call per launch from Python)", 0, False),
+                      ("recorded plan, call list replayed from Python", 16, False),
+                      ("recorded plan as one hipGraph launch (default at small batch)", 16, True)):
+    net.options.plan_max_chains, net.options.plan_graph = cap, gr
+    for _ in range(3):
+        bench.run_forward(net, inp)
+    torch.cuda.synchronize()
+    hs, ts = [], []
+    for _ in range(10):
+        t0 = time.perf_counter(); bench.run_forward(net, inp); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+        hs.append(t1 - t0); ts.append(t2 - t0)
+    print(f"B={B} lanes={lanes} {mode}: host enqueue {1e3*min(hs):.3f} ms (median {1e3*sorted(hs)[5]:.3f}), until idle {1e3*min(ts):.3f} ms")
+net.options.plan_max_chains = 0
 # hipGraph capture of the whole forward
 g = torch.cuda.CUDAGraph()
 s = torch.cuda.Stream()
