@@ -1,5 +1,7 @@
 // Small HBM-bound kernels either side of the cost-volume regulariser: soft-argmin, bilinear
 // resize of idepth maps and hypothesis masks, multi-source fusion.
+#include <type_traits>
+
 #include "mvsn_common.h"
 
 namespace mvsn {
@@ -411,6 +413,7 @@ namespace mvsn {
 //   B = 4 cins x 16 slots: lane (k, i) loads slots 64g + 4i .. + 3 of channel 4 ks + k with one dwordx4;
 //       register p of that load is the B fragment of "slot tile p" = slots {64g + 4i + p}, so the four
 //       accumulators of a lane are four CONSECUTIVE slots of one tap row -> one 16-byte LDS write.
+__device__ __forceinline__ void t3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 constexpr int T3_TY = 16, T3_TX = 32;
 constexpr int T3_HY = T3_TY + 2, T3_XS = 40;          // haloed rows, row stride in slots
 constexpr int T3_SLOTS = T3_HY * T3_XS;               // 720
@@ -477,53 +480,72 @@ __global__ __launch_bounds__(256, 2) void conv_to1_3d_mfma_kernel(const float *_
   const float b = bias ? bias[0] : 0.0f;
   float *outn = out + (size_t)n * chan + (size_t)(y0 + oy) * W + x0 + ox;
 
-  for (int z = zb - 1; z <= ze; ++z) {
-    if (z >= 0 && z < D) {   // uniform: planes outside the volume contribute nothing
-      // ---- P = taps x slots for plane z
-      floatx4 bfr[2][8];
-      auto load_group = [&](int u, floatx4 (&dst)[8]) {
-        const float *src = inn + (size_t)z * plane + (goff[u] >= 0 ? goff[u] : 0);
+  // The stream over the slab's planes is software-pipelined ACROSS planes, two slot groups ahead: a group's 64
+  // multiplies take ~0.85 us, an HBM round trip under load more than twice that, and with one request burst per plane
+  // (round 2) the kernel sat at 27 % of the HBM rate.  Three groups per plane, three register buffers: group u of every
+  // plane lives in bfr[u]; while group u multiplies, group u + 2 (of this plane or the next) is requested.
+  floatx4 bfr[3][8];
+  auto load_group = [&](int z, int u, floatx4 (&dst)[8]) {
+    const float *src = inn + (size_t)z * plane + (goff[u] >= 0 ? goff[u] : 0);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          dst[ks] = goff[u] >= 0 ? *reinterpret_cast<const floatx4 *>(src + (size_t)ks * 4 * chan) : floatx4{0.f, 0.f, 0.f, 0.f};
-          if constexpr (XF) {   // padding stays zero: it pads the ACTIVATED tensor
-            if (goff[u] >= 0) {
-#pragma unroll
-              for (int p = 0; p < 4; ++p) dst[ks][p] = lrelu02(dst[ks][p] * xsc[ks] + xsh[ks]);
-            }
-          }
-        }
-      };
-      load_group(0, bfr[0]);
-#pragma unroll
-      for (int u = 0; u < GPW; ++u) {
-        if (u + 1 < GPW) load_group(u + 1, bfr[(u + 1) & 1]);
-        floatx4 d[2][4];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int p = 0; p < 4; ++p) d[t][p] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < 8; ++ks)
+      dst[ks] = goff[u] >= 0 ? __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(src + (size_t)ks * 4 * chan))
+                             : floatx4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto activate = [&](int u, floatx4 (&dst)[8]) {
+    if constexpr (XF) {   // padding stays zero: it pads the ACTIVATED tensor
+      if (goff[u] >= 0) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-          for (int p = 0; p < 4; ++p) {
-            d[0][p] = mfma16x16x4(a[0][ks], bfr[u & 1][ks][p], d[0][p]);
-            d[1][p] = mfma16x16x4(a[1][ks], bfr[u & 1][ks][p], d[1][p]);
-          }
-        // lane holds taps 16 t + 4 (lane>>4) + r of slots s0 .. s0 + 3
-        const int s0 = (wave + 4 * u) * 64 + 4 * (lane & 15);
-        if (s0 < T3_SLOTS) {
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int tap = t * 16 + (lane >> 4) * 4 + r;
-              if (tap < 27)
-                *reinterpret_cast<floatx4 *>(P + tap * T3_SLOTS + s0) = floatx4{d[t][0][r], d[t][1][r], d[t][2][r], d[t][3][r]};
-            }
-        }
+          for (int p = 0; p < 4; ++p) dst[ks][p] = lrelu02(dst[ks][p] * xsc[ks] + xsh[ks]);
       }
-      __syncthreads();
+    }
+  };
+  static_assert(GPW == 3, "the plane pipeline below is written for three slot groups per wave");
+  const int zfirst = zb - 1 < 0 ? 0 : zb - 1, zlast = ze < D ? ze : D - 1;   // input planes inside the volume
+  if (zfirst <= zlast) {
+    load_group(zfirst, 0, bfr[0]);
+    load_group(zfirst, 1, bfr[1]);
+  }
+  auto plane_products = [&](int z) {
+#pragma unroll
+    for (int u = 0; u < GPW; ++u) {
+      if (u == 0) load_group(z, 2, bfr[2]);
+      else if (z + 1 <= zlast) load_group(z + 1, u - 1, bfr[u - 1]);   // next plane: in flight across the barriers below
+      activate(u, bfr[u]);
+      floatx4 d[2][4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) d[t][p] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          d[0][p] = mfma16x16x4(a[0][ks], bfr[u][ks][p], d[0][p]);
+          d[1][p] = mfma16x16x4(a[1][ks], bfr[u][ks][p], d[1][p]);
+        }
+      // lane holds taps 16 t + 4 (lane>>4) + r of slots s0 .. s0 + 3
+      const int s0 = (wave + 4 * u) * 64 + 4 * (lane & 15);
+      if (s0 < T3_SLOTS) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int tap = t * 16 + (lane >> 4) * 4 + r;
+            if (tap < 27)
+              *reinterpret_cast<floatx4 *>(P + tap * T3_SLOTS + s0) = floatx4{d[t][0][r], d[t][1][r], d[t][2][r], d[t][3][r]};
+          }
+      }
+    }
+  };
+
+  for (int z = zb - 1; z <= ze; ++z) {
+    if (z >= 0 && z < D) {   // uniform: planes outside the volume contribute nothing
+      // ---- P = taps x slots for plane z
+      plane_products(z);
+      t3_barrier();   // (LDS only: the next plane's first loads stay in flight across it)
       // ---- shift-and-add: input plane z feeds output planes z + 1 (dz = 0), z (dz = 1), z - 1 (dz = 2)
 #pragma unroll
       for (int dz = 0; dz < 3; ++dz)
@@ -544,7 +566,7 @@ __global__ __launch_bounds__(256, 2) void conv_to1_3d_mfma_kernel(const float *_
     acc[0][0] = acc[1][0], acc[0][1] = acc[1][1];
     acc[1][0] = acc[2][0], acc[1][1] = acc[2][1];
     acc[2][0] = 0.f, acc[2][1] = 0.f;
-    __syncthreads();   // everyone is done reading P before the next plane overwrites it
+    t3_barrier();   // everyone is done reading P before the next plane overwrites it
   }
 }
 
