@@ -55,6 +55,13 @@ int mvsn_plane_sweep_setup(const float *T_right_in_left, const float *K_lvl0, co
                            int n_chains, int rows4, int cols4, int num_idepth_samples,
                            float *idepth_samples, float *H_lvl4, float *H_inc, float *H_lvl0_plane0,
                            float *baseline, mvsn_stream_t stream);
+/* The same with the poses and intrinsics as the forward holds them: one (batch, 4, 4) pose tensor per source view
+ * (host array of n_sources <= 8 device pointers) and the batch's intrinsics shared by its sources; chain n = s * batch + b.
+ * Saves the torch.cat / repeat of :553,:587-592 in front of the launch. */
+int mvsn_plane_sweep_setup_sources(const float *const *T_right_in_lefts, int n_sources, const float *K_lvl0,
+                                   const float *K_lvl4, int batch, int rows4, int cols4, int num_idepth_samples,
+                                   float *idepth_samples, float *H_lvl4, float *H_inc, float *H_lvl0_plane0,
+                                   float *baseline, mvsn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Homography warp with bilinear, clamp-to-edge sampling and out-of-image zeroing.
@@ -412,6 +419,9 @@ int mvsn_depth_metrics(const float *idepth_est, const float *depth_true, const f
  * else): a device-to-device copy on the stream (the torch.cat / repeat of poses, intrinsics and coarse source images,
  * multi_view_stereonet.py:553,:587-592) and dst[i] = src[i * stride] (the focal lengths K[:, 0, 0], :607). */
 int mvsn_copy(void *dst, const void *src, size_t nbytes, mvsn_stream_t stream);
+/* fx[l * batch + b] = K_pyr[l][b][0][0] for every pyramid level in one launch (K_pyr: host array of `levels` <= 8 device
+ * pointers to (batch, 4, 4) intrinsics) */
+int mvsn_gather_focal(const float *const *K_pyr, int levels, int batch, float *fx, mvsn_stream_t stream);
 int mvsn_gather_strided(const float *src, int count, long stride, float *dst, mvsn_stream_t stream);
 
 /* Device self-test of the MFMA fragment mapping the conv kernels rely on (A = 16x4, B = 4x16

@@ -46,6 +46,8 @@ SIGNATURES = {
     "mvsn_abi_version": (c_int, []),
     "mvsn_last_error": (c_char_p, []),
     "mvsn_plane_sweep_setup": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 5 + [c_void_p]),
+    "mvsn_plane_sweep_setup_sources": (c_int, [POINTER(c_void_p), c_int, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p] * 5 + [c_void_p]),
+    "mvsn_gather_focal": (c_int, [POINTER(c_void_p), c_int, c_int, c_void_p, c_void_p]),
     "mvsn_homography_warp": (c_int, [c_void_p] * 2 + [c_int] * 5 + [c_void_p] * 2 + [c_void_p]),
     "mvsn_feature_refiner_packed_floats": (c_size_t, []),
     "mvsn_pack_feature_refiner": (c_int, [c_void_p] * 11 + [c_void_p]),

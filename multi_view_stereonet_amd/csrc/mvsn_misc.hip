@@ -270,6 +270,29 @@ __global__ void gather_strided_kernel(const float *__restrict__ src, int count, 
 }
 }  // namespace mvsn
 
+namespace mvsn {
+struct FocalSrc {
+  const float *K[8];
+};
+__global__ void gather_focal_kernel(FocalSrc src, int levels, int batch, float *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < levels * batch) out[i] = src.K[i / batch][(size_t)(i % batch) * 16];
+}
+}  // namespace mvsn
+
+extern "C" int mvsn_gather_focal(const float *const *K_pyr, int levels, int batch, float *fx, mvsn_stream_t stream) {
+  MVSN_REQUIRE(K_pyr && fx && levels >= 1 && levels <= 8 && batch > 0, MVSN_E_BADARG, "mvsn_gather_focal: bad arguments");
+  mvsn::FocalSrc src = {};
+  for (int l = 0; l < levels; ++l) {
+    MVSN_REQUIRE(K_pyr[l], MVSN_E_BADARG, "mvsn_gather_focal: null pointer");
+    src.K[l] = K_pyr[l];
+  }
+  const int total = levels * batch;
+  hipLaunchKernelGGL(mvsn::gather_focal_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, levels,
+                     batch, fx);
+  return mvsn::check_launch("mvsn_gather_focal");
+}
+
 extern "C" int mvsn_copy(void *dst, const void *src, size_t nbytes, mvsn_stream_t stream) {
   MVSN_REQUIRE(dst && src, MVSN_E_BADARG, "mvsn_copy: null pointer");
   if (nbytes == 0) return 0;

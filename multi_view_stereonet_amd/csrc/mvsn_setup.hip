@@ -41,15 +41,24 @@ __device__ inline void plane_homography(const double *K3, const double *K3inv, c
 
 constexpr int SETUP_THREADS = 256;
 
+// Where a chain's pose and intrinsics live: per chain (T (N,4,4), K (N,4,4)) or, `per_source`, as the forward holds
+// them -- one (B,4,4) pose tensor per source view and the B reference images' intrinsics shared by their S chains
+// (chain n = s * B + b): no cat / repeat in front of the launch.
+struct SetupSrc {
+  const float *T[8];
+  int B, per_source;
+};
+
 __global__ __launch_bounds__(SETUP_THREADS) void plane_sweep_setup_kernel(
-    const float *__restrict__ T_in, const float *__restrict__ K0_in, const float *__restrict__ K4_in, int rows4,
+    SetupSrc src, const float *__restrict__ K0_in, const float *__restrict__ K4_in, int rows4,
     int cols4, int D, float *__restrict__ samples_out, float *__restrict__ H4_out, float *__restrict__ Hinc_out,
     float *__restrict__ H0_out, float *__restrict__ baseline_out) {
   const int n = blockIdx.x;
   const int tid = threadIdx.x;
-  const float *T = T_in + (size_t)n * 16;
-  const float *K0 = K0_in + (size_t)n * 16;
-  const float *K4 = K4_in + (size_t)n * 16;
+  const int kb = src.per_source ? n % src.B : n;
+  const float *T = src.per_source ? src.T[n / src.B] + (size_t)kb * 16 : src.T[0] + (size_t)n * 16;
+  const float *K0 = K0_in + (size_t)kb * 16;
+  const float *K4 = K4_in + (size_t)kb * 16;
 
   __shared__ double s_sum[SETUP_THREADS];
   __shared__ int s_cnt[SETUP_THREADS];
@@ -165,8 +174,30 @@ extern "C" int mvsn_plane_sweep_setup(const float *T_right_in_left, const float 
                MVSN_E_BADARG, "mvsn_plane_sweep_setup: null pointer");
   MVSN_REQUIRE(n_chains > 0 && rows4 > 0 && cols4 > 0 && num_idepth_samples >= 2, MVSN_E_BADARG,
                "mvsn_plane_sweep_setup: bad sizes (chains %d, %dx%d, D %d)", n_chains, rows4, cols4, num_idepth_samples);
+  mvsn::SetupSrc src = {};
+  src.T[0] = T_right_in_left;
   hipLaunchKernelGGL(mvsn::plane_sweep_setup_kernel, dim3(n_chains), dim3(mvsn::SETUP_THREADS), 0,
-                     (hipStream_t)stream, T_right_in_left, K_lvl0, K_lvl4, rows4, cols4, num_idepth_samples,
+                     (hipStream_t)stream, src, K_lvl0, K_lvl4, rows4, cols4, num_idepth_samples,
                      idepth_samples, H_lvl4, H_inc, H_lvl0_plane0, baseline);
   return mvsn::check_launch("mvsn_plane_sweep_setup");
+}
+
+extern "C" int mvsn_plane_sweep_setup_sources(const float *const *T_right_in_lefts, int n_sources, const float *K_lvl0,
+                                              const float *K_lvl4, int batch, int rows4, int cols4,
+                                              int num_idepth_samples, float *idepth_samples, float *H_lvl4, float *H_inc,
+                                              float *H_lvl0_plane0, float *baseline, mvsn_stream_t stream) {
+  MVSN_REQUIRE(T_right_in_lefts && K_lvl0 && K_lvl4 && idepth_samples && H_lvl4 && H_inc && H_lvl0_plane0 && baseline,
+               MVSN_E_BADARG, "mvsn_plane_sweep_setup_sources: null pointer");
+  MVSN_REQUIRE(n_sources >= 1 && n_sources <= 8 && batch > 0 && rows4 > 0 && cols4 > 0 && num_idepth_samples >= 2,
+               MVSN_E_BADARG, "mvsn_plane_sweep_setup_sources: bad sizes (sources %d of at most 8, batch %d)", n_sources, batch);
+  mvsn::SetupSrc src = {};
+  for (int s = 0; s < n_sources; ++s) {
+    MVSN_REQUIRE(T_right_in_lefts[s], MVSN_E_BADARG, "mvsn_plane_sweep_setup_sources: null pose pointer");
+    src.T[s] = T_right_in_lefts[s];
+  }
+  src.B = batch, src.per_source = 1;
+  hipLaunchKernelGGL(mvsn::plane_sweep_setup_kernel, dim3(n_sources * batch), dim3(mvsn::SETUP_THREADS), 0,
+                     (hipStream_t)stream, src, K_lvl0, K_lvl4, rows4, cols4, num_idepth_samples, idepth_samples, H_lvl4,
+                     H_inc, H_lvl0_plane0, baseline);
+  return mvsn::check_launch("mvsn_plane_sweep_setup_sources");
 }

@@ -506,6 +506,7 @@ class PlaneSweepEngine:
                                    device=x0.device)
         ptrs = (ctypes.c_void_p * len(blocks))(*[b.data_ptr() for b in blocks])
         chans = (ctypes.c_int * len(blocks))(*[b.shape[1] for b in blocks])
+        self._keep(blocks)
         self._call(f"mvsn_conv_forward_blocks[conv2d k3 {c.cin}->{c.cout} wino]", lib.mvsn_conv_forward_blocks,
                    ctypes.byref(d), ptrs, chans, len(blocks), _native.ptr(c.packed_wino), _native.ptr(c.bias),
                    _native.ptr(out), _native.ptr(partials), _native.stream(),
@@ -809,6 +810,44 @@ class PlaneSweepEngine:
                    _native.ptr(H0), _native.ptr(base), _native.stream())
         return samples, H4, Hinc, H0, base
 
+    def plane_sweep_setup_sources(self, Ts, K0: torch.Tensor, K4: torch.Tensor, rows4: int, cols4: int, D: int):
+        """plane_sweep_setup for chains n = s * B + b straight from the per-source pose tensors and the batch's
+        intrinsics (no cat / repeat)."""
+        S = len(Ts)
+        if S > 8:
+            return self.plane_sweep_setup(self.cat0(list(Ts)), self.cat0([K0] * S), self.cat0([K4] * S), rows4, cols4, D)
+        Ts = [self.f32c(t) for t in Ts]
+        K0, K4 = self.f32c(K0), self.f32c(K4)
+        B, dev = K0.shape[0], K0.device
+        N = S * B
+        f = dict(dtype=torch.float32, device=dev)
+        samples, H4, Hinc = self.empty((N, D), **f), self.empty((N, D, 3, 3), **f), self.empty((N, D, 3, 3), **f)
+        H0, base = self.empty((N, 1, 3, 3), **f), self.empty((N,), **f)
+        ptrs = (ctypes.c_void_p * S)(*[_native.ptr(t) for t in Ts])
+        self._keep(Ts)
+        self._call("mvsn_plane_sweep_setup", self.lib.mvsn_plane_sweep_setup_sources, ptrs, S, _native.ptr(K0),
+                   _native.ptr(K4), B, rows4, cols4, D, _native.ptr(samples), _native.ptr(H4), _native.ptr(Hinc),
+                   _native.ptr(H0), _native.ptr(base), _native.stream())
+        return samples, H4, Hinc, H0, base
+
+    def focal_pyramid(self, K_pyr) -> torch.Tensor:
+        """(levels, B) focal lengths K_pyr[l][:, 0, 0]."""
+        Ks = [self.f32c(k) for k in K_pyr]
+        L, B = len(Ks), Ks[0].shape[0]
+        out = self.empty((L, B), torch.float32, Ks[0].device)
+        if L > 8:
+            for l in range(L):
+                self.copy_into(out[l], self.focal(Ks[l]))
+            return out
+        ptrs = (ctypes.c_void_p * L)(*[_native.ptr(k) for k in Ks])
+        self._keep(Ks)
+        self._call("mvsn_gather_focal", self.lib.mvsn_gather_focal, ptrs, L, B, _native.ptr(out), _native.stream())
+        return out
+
+    def _keep(self, tensors):
+        if self.recording is not None:
+            self.recording.keep.extend(tensors)
+
     def incremental_cost_volume(self, src4, H4, Hinc, plane0, left_feats, want_features=False):
         N, _, rows, cols = src4.shape
         B = left_feats.shape[0]
@@ -901,10 +940,9 @@ class PlaneSweepEngine:
         rows4, cols4 = left_image_pyr[-1].shape[-2:]
 
         # 1. set-up for all N = S*B chains (chain n = s*B + b)
-        T = self.cat0(list(T_right_in_lefts))
-        K0 = self.cat0([K_pyr[0]] * S)
-        K4 = self.cat0([K_pyr[-1]] * S)
-        samples, H4, Hinc, H0, baseline = self.plane_sweep_setup(T, K0, K4, rows4, cols4, D)
+        samples, H4, Hinc, H0, baseline = self.plane_sweep_setup_sources(T_right_in_lefts, K_pyr[0], K_pyr[-1], rows4,
+                                                                         cols4, D)
+        fx_all = self.focal_pyramid(K_pyr)          # (levels, B): every level's focal lengths in one launch
 
         # 2. full-resolution source images on plane 0, 3. one extractor batch
         #    (each source is warped straight into its slot of the extractor's frame batch)
@@ -936,12 +974,12 @@ class PlaneSweepEngine:
         if do_refiners[4]:
             refined = None
             if self.towers and not self.fold_residual_blocks:
-                refined = self.tower_refiner4(self.f32c(left_image_pyr[-1]), left_feats[-1], raw, self.focal(K_pyr[-1]))
+                refined = self.tower_refiner4(self.f32c(left_image_pyr[-1]), left_feats[-1], raw, fx_all[-1])
             if refined is None:
                 # per chain: the guide blocks of its reference image (device copies, no concatenated tensor)
                 img4 = self.cat0([left_image_pyr[-1]] * S)
                 feats4 = self.cat0([left_feats[-1]] * S)
-                fx4 = self.cat0([self.focal(K_pyr[-1])] * S)
+                fx4 = self.cat0([fx_all[-1]] * S)
                 refined = self.idepth_refiner(4, [img4, feats4], raw, fx4)
         else:
             refined = None
@@ -960,7 +998,7 @@ class PlaneSweepEngine:
         for lvl in (3, 2, 1, 0):
             size = left_image_pyr[lvl].shape[-2:]
             if do_refiners[lvl]:
-                fx = self.focal(K_pyr[lvl])
+                fx = fx_all[lvl]
                 prior[lvl], scaled = self.upsample_prior(idepth[lvl + 1], fx, size)
             else:
                 prior[lvl] = self.upsample(idepth[lvl + 1], size)

@@ -75,6 +75,13 @@ def test_plane_sweep_setup(rows, cols, S, B, D):
     inc_ref = torch.linalg.inv(H64[:, :-1]) @ H64[:, 1:]
     close(Hinc[:, 1:], inc_ref, rtol=1e-5, atol=1e-6)
     close(Hinc[:, 0], torch.eye(3).expand(S * B, 3, 3), rtol=0, atol=0)
+    # the same straight from the per-source pose tensors and the batch's intrinsics (no cat / repeat): identical bits
+    got = eng.plane_sweep_setup_sources([t.to(DEV) for t in inp["T_right_in_left"]], inp["K_pyr"][0].to(DEV),
+                                        inp["K_pyr"][4].to(DEV), r4, c4, D)
+    for a, b2 in zip(got, (samples, H4, Hinc, H0, base)):
+        assert torch.equal(a, b2)
+    fx = eng.focal_pyramid([k.to(DEV) for k in inp["K_pyr"]]).cpu()
+    assert torch.equal(fx, torch.stack([k[:, 0, 0] for k in inp["K_pyr"]]))
 
 
 @pytest.mark.parametrize("B,C,n,rows,cols", [(2, 3, 1, 64, 128), (1, 3, 16, 4, 8), (2, 32, 3, 16, 32),
