@@ -391,6 +391,9 @@ def main():
     ap.add_argument("--sustain", type=float, default=0.0, metavar="SECONDS",
                     help="after the timed region: keep stepping for this long and report the rate per 2-second window "
                          "(clock settling under sustained MFMA load); writes nothing, adds a 'sustained' key")
+    ap.add_argument("--single-device-selftest", action="store_true",
+                    help="N > 1 ranks that ALL use cuda:0 and talk over gloo: exercises the multi-rank line (quality fields "
+                         "at every world size) on a one-GPU box.  Its rate is NOT a scaling measurement and is labelled so.")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU ranks over gloo with a stand-in step: checks the launch/timing/gather plumbing only")
     args = ap.parse_args()
@@ -399,7 +402,10 @@ def main():
         # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run on
         # the loopback address; rank 0 of the children prints the JSON line on the inherited stdout
         sys.exit(self_launch(args.gpus))
-    rank, world, local = mdist.init_from_env(backend="gloo" if args.launcher_selftest else None)
+    rank, world, local = mdist.init_from_env(backend="gloo" if (args.launcher_selftest or args.single_device_selftest)
+                                             else None)
+    if args.single_device_selftest:
+        local = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree")
     if args.launcher_selftest:
@@ -425,21 +431,23 @@ def main():
     # weights, opts the kernels into their LDS sizes and grows the allocator pools (one-time work per process)
     step()
     torch.cuda.synchronize()
-    elapsed, per_rank, out = timed_steps(step, args.steps, args.warmup, world, torch.cuda.synchronize, dev)
+    coll_dev = torch.device("cpu") if args.single_device_selftest else dev     # (gloo ranks exchange host tensors)
+    elapsed, per_rank, out = timed_steps(step, args.steps, args.warmup, world, torch.cuda.synchronize, coll_dev)
 
     # per-image metric rows, all-gathered (the path's only exchange step)
     idepth = out["left_idepthmap_pyr"][0]
     rows = torch.stack([idepth.mean(dim=(1, 2, 3)), (idepth > 0).float().mean(dim=(1, 2, 3)),
                         out["left_idepthmap_mask_pyr"][0].float().mean(dim=(1, 2, 3))], 1)
     idx = torch.arange(rank * B, (rank + 1) * B, device=dev)
-    all_rows, all_idx = mdist.gather_metric_rows(rows, idx)
+    all_rows, all_idx = mdist.gather_metric_rows(rows.to(coll_dev), idx.to(coll_dev))
     assert all_rows.shape[0] == B * world and bool(torch.isfinite(all_rows).all())
 
     # ---- quality fields, on EVERY rank (its own device), reduced to rank 0: the line of an N-GPU run carries the
     # same parity / roofline / chain-kernel / CPU-baseline fields as the 1-GPU line (roofline: min over ranks)
     agg = kernel_breakdown(net, inp, Dn)
     total_ms = sum(e["ms"] for e in agg.values())
-    name, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+    # the dominant kernel = the arithmetic kernel with the most device time (the bookkeeping launches carry no flops)
+    name, dom = max(((k, v) for k, v in agg.items() if v["flops"] > 0), key=lambda kv: kv[1]["ms"])
     per_launch_ms = dom["ms"] / dom["launches"]
     # dom["flops"] counts the layer in its direct form (2 * cin * taps * cout per output).  The Winograd
     # kernels execute 16 multiplies per 2x2 outputs and tap plane instead of 36 (x 4/9): the roofline is
@@ -447,9 +455,9 @@ def main():
     wino = " wino" in name
     direct_tfl = dom["flops"] / dom["launches"] / (per_launch_ms * 1e-3) / 1e12
     tfl = direct_tfl * (4.0 / 9.0 if wino else 1.0)
-    fracs = gather_floats(tfl / PEAK_FP32_MFMA_TFLOPS, world, dev)
+    fracs = gather_floats(tfl / PEAK_FP32_MFMA_TFLOPS, world, coll_dev)
     ch = agg.get("mvsn_incremental_cost_volume")
-    chain_ms = gather_floats(ch["ms"] / ch["launches"] if ch else 0.0, world, dev)
+    chain_ms = gather_floats(ch["ms"] / ch["launches"] if ch else 0.0, world, coll_dev)
 
     if rank == 0:
         line = {"metric": "depthmaps/sec at 512x256, 64 hypotheses, 2 src views; L1 vs ref",
@@ -465,6 +473,9 @@ def main():
                            "global_batch": B * world, "parallelism": f"dp{world} (independent images, "
                                                                       "all-gather of metric rows)"},
                 "mean_idepth": float(mdist.average_rows(all_rows)[0])}
+        if args.single_device_selftest:
+            line["selftest"] = ("every rank ran on cuda:0 (gloo): the ranks time-share ONE GPU -- the multi-rank plumbing and "
+                                "the per-N quality fields are what this line shows, its rate is not a scaling measurement")
         if not headline:
             line["metric"] = (f"depthmaps/sec at {cfg['cols']}x{cfg['rows']}, {Dn} hypotheses, {Sn} src views; L1 vs ref "
                               f"(--config {args.config}: NOT the headline configuration)")
