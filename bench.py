@@ -422,6 +422,8 @@ def main():
     net.stream_lanes = args.lanes
     net.options.fold_residual_blocks = args.fold
     net.options.conv_precision = args.precision
+    if args.single_device_selftest:
+        net.options.chain_form = "winograd"    # (the banded chain form needs the device to itself: one process per GPU)
     B = args.batch if args.batch > 0 else cfg["batch"]
     Dn, Sn = cfg["D"], cfg["S"]
     _, inp, ref0 = config_inputs(cfg, B, rank, dev)

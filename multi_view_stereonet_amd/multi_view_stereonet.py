@@ -131,8 +131,9 @@ class EngineOptions:
         # (ForwardPlan: same calls, same arguments, ~2 us of host time per launch instead of ~23); 0 = always eager.
         self.plan_max_chains = 16
         self.plan_graph = True     # ... and from the second replay on the call list is launched as one hipGraph
+        self.plan_max_bytes = 8 << 30   # intermediates all recorded plans together may keep alive
 
-    NAMES = ("towers", "plan_max_chains", "plan_graph", "carry_passes", "carry_min_bytes", "carry_volume_passes", "carry_alternate", "chain_form", "fold_residual_blocks", "conv_precision", "winograd", "winograd_with_input_transform",
+    NAMES = ("towers", "plan_max_chains", "plan_graph", "plan_max_bytes", "carry_passes", "carry_min_bytes", "carry_volume_passes", "carry_alternate", "chain_form", "fold_residual_blocks", "conv_precision", "winograd", "winograd_with_input_transform",
              "winograd_volume", "volume_materialise", "trim_tower_ends", "cat_free_heads")
 
 
@@ -175,6 +176,7 @@ class ForwardPlan:
         self.outputs: Optional[dict] = None
         self.graph = None          # hipGraph of the call list (None: not captured yet, False: capture refused)
         self.uses = 0
+        self.nbytes = 0            # bytes of intermediates the plan keeps alive
 
     def replay(self):
         stream = _native.stream()
@@ -1140,13 +1142,19 @@ class MultiViewStereoNet(nn.Module):
                 plan.outputs = eng.forward(*unflatten(plan.static_inputs), *args, None)
             finally:
                 eng.recording = None
-            if len(eng.plans) >= 8:              # a handful of shapes at most: drop the oldest
+            plan.nbytes = sum(t.numel() * t.element_size() for t in plan.keep)
+            # a handful of shapes at most, and at most ~8 GB of kept intermediates: drop the oldest plans beyond that
+            while eng.plans and (len(eng.plans) >= 8 or plan.nbytes +
+                                 sum(p.nbytes for p in eng.plans.values() if p is not None) > self.options.plan_max_bytes):
                 eng.plans.pop(next(iter(eng.plans)))
             eng.plans[key] = plan if plan.replayable else None
+            if not plan.replayable:
+                plan.keep.clear()
         else:
             torch._foreach_copy_(plan.static_inputs, flat)
             plan.uses += 1
-            if plan.graph is None and self.options.plan_graph and plan.uses >= 2:
+            capturing = torch.cuda.is_current_stream_capturing()     # (the caller is building a graph of its own)
+            if plan.graph is None and self.options.plan_graph and plan.uses >= 2 and not capturing:
                 # every address in the recorded calls is static: from its second replay on, the call list runs as
                 # ONE hipGraph launch (captured by replaying it under stream capture)
                 try:
@@ -1157,7 +1165,7 @@ class MultiViewStereoNet(nn.Module):
                     plan.graph = g
                 except Exception:                       # capture refused (e.g. a foreign capture in progress): stay on the list
                     plan.graph = False
-            if plan.graph:
+            if plan.graph and not capturing:
                 plan.graph.replay()
             else:
                 plan.replay()

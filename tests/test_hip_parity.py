@@ -1398,6 +1398,10 @@ def test_forward_plan_replay_is_bit_identical():
         assert same(run(inputs(2)), eager[1])  # and back (by now the call list runs as a hipGraph)
         assert same(run(inputs(3)), eager[2])
         assert any(p is not None and p.graph for p in eng.plans.values())
+        # a caller that captures the forward into its own graph (GraphedForward) while a plan with a graph exists
+        from multi_view_stereonet_amd.graphed import GraphedForward
+        gf = GraphedForward(net, *inputs(2), D)
+        assert same(gf(*inputs(3)), eager[2])
     finally:
         net.options.plan_max_chains = old
 
