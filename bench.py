@@ -77,7 +77,7 @@ def l1_against(ref0, got0, golden):
             "reference": f"tests/golden/{golden} (reference PyTorch-CPU forward)"}
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 dense peak
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"   # the latest committed FETCH_SIZE / WRITE_SIZE pass (tools/prof_pmc.sh)
+PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"   # the latest committed FETCH_SIZE / WRITE_SIZE pass (tools/prof_pmc.sh)
 
 
 def make_inputs(batch, first_seed, device):
