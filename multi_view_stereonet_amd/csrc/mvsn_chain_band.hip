@@ -25,7 +25,7 @@
 // zeroed by a memset node ahead of every launch; tags count steps within the call (F_d carries d + 1, the conv
 // hand-offs of step d carry d), so a granule is either stale (tag - 1: keep polling) or current.  A buffer can be
 // single: a band cannot publish step d + 1's version of a hand-off before every reader has consumed step d's, because
-// the GroupNorm sums of the hand-off in between need all four bands (see the ordering argument in DESIGN.md 3.1d).
+// the GroupNorm sums of the hand-off in between need all four bands (the ordering argument is spelled out in DESIGN.md 3.1).
 // Spins are bounded: on a time-out the workgroup records it in the status word and stops waiting (the host reports it).
 //
 // Work split inside a workgroup: 256 threads = 4 waves, ONE per SIMD (512 registers each); wave (pt, ct) owns patch
