@@ -98,13 +98,14 @@ int mvsn_homography_warp(const float *image, const float *H, int batch, int chan
                                  GroupNorm statistics of the producing launch, the residual pass, the cost slice):
                                  for coarse grids whose planes do not fit one CU (30x40, 32x64) while fewer chains
                                  than CUs are in flight -- there the one-workgroup-per-chain forms leave the chip idle */
-#define MVSN_CHAIN_BANDED 4   /* one chain on FOUR workgroups (16x32 coarse grid: bands of 4 pixel rows; Winograd
-                                 arithmetic of MVSN_CHAIN_WINOGRAD; per step the bands hand each other the new feature
-                                 rows their gathers reach into, their GroupNorm sums and one halo row per layer as
-                                 tagged 8-byte write-through granules -- no fence, no placement assumption).  For few
-                                 chains in flight (batch 1: the reference's loop, test.py:38,197-200): 4 x n_chains must
-                                 not exceed the device's CUs (all workgroups co-resident), and only ONE such launch may
-                                 be in flight per device.  Needs workspace (..._workspace_bytes_for); the word at
+#define MVSN_CHAIN_BANDED 4   /* one chain on SEVERAL workgroups: the coarse plane cut into bands of pixel rows (16x32: 4
+                                 bands of 4 rows; 30x40: 15 of 2; 32x64: 16 of 2), Winograd arithmetic of
+                                 MVSN_CHAIN_WINOGRAD; per step the bands hand each other the new feature rows their
+                                 gathers reach into, their GroupNorm sums and one halo row per layer as tagged 8-byte
+                                 write-through granules -- no fence, no placement assumption.  For few chains in flight
+                                 (batch 1: the reference's loop, test.py:38,197-200): bands x n_chains must not exceed the
+                                 device's CUs (all workgroups co-resident), and only ONE such launch may be in flight per
+                                 device.  Needs workspace (..._workspace_bytes_for); the word at
                                  mvsn_incremental_cost_volume_status_offset() inside it is 0 after a clean run. */
 size_t mvsn_feature_refiner_packed_floats(void);
 /* Pack the ten FeatureRefiner tensors (state_dict order: conv0.{weight,bias}, bn0.{weight,bias},
@@ -123,7 +124,7 @@ size_t mvsn_incremental_cost_volume_workspace_bytes_for(int n_chains, int num_id
                                                         int form);
 /* MVSN_CHAIN_BANDED only: byte offset, inside the workspace, of the 32-bit status word the launch leaves behind
  * (0 = every inter-workgroup hand-off completed; non-zero = a bounded wait timed out and the outputs are invalid) */
-size_t mvsn_incremental_cost_volume_status_offset(int n_chains);
+size_t mvsn_incremental_cost_volume_status_offset(int n_chains, int rows, int cols);
 int mvsn_incremental_cost_volume(const float *src_image_lvl4, const float *H_lvl4, const float *H_inc,
                                  const float *plane0_features, const float *left_features,
                                  const float *refiner_packed, int n_chains, int batch,

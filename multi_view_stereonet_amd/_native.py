@@ -55,7 +55,7 @@ SIGNATURES = {
     "mvsn_incremental_cost_volume_form": (c_int, [c_int] * 2),
     "mvsn_incremental_cost_volume_form_for": (c_int, [c_int] * 3),
     "mvsn_incremental_cost_volume_workspace_bytes_for": (c_size_t, [c_int] * 5),
-    "mvsn_incremental_cost_volume_status_offset": (c_size_t, [c_int]),
+    "mvsn_incremental_cost_volume_status_offset": (c_size_t, [c_int] * 3),
     "mvsn_incremental_cost_volume": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 4 + [c_size_t, c_int, c_void_p]),
     "mvsn_conv_bf16x3_supported": (c_int, [POINTER(ConvDesc)]),
     "mvsn_conv_winograd_supported": (c_int, [POINTER(ConvDesc)]),

@@ -46,11 +46,11 @@ bool chain_steps_supported(int rows, int cols);
 size_t chain_steps_workspace_bytes(int n_chains, int D, int rows, int cols);
 int chain_steps_launch(const ChainArgs &a, int n_chains, void *workspace, size_t workspace_bytes, hipStream_t stream);
 
-// Banded form (mvsn_chain_band.hip): one chain on four workgroups, 16x32 coarse grid
+// Banded form (mvsn_chain_band.hip): one chain on several workgroups; coarse grids 16x32, 30x40, 32x64
 bool chain_band_supported(int rows, int cols);
-int chain_band_groups();
-size_t chain_band_workspace_bytes(int n_chains);
-size_t chain_band_status_offset(int n_chains);
+int chain_band_groups(int rows, int cols);                 // workgroups per chain (0: no plan for this grid)
+size_t chain_band_workspace_bytes(int n_chains, int rows, int cols);
+size_t chain_band_status_offset(int n_chains, int rows, int cols);
 int chain_band_launch(const ChainArgs &a, int n_chains, void *workspace, size_t workspace_bytes, int flags,
                       hipStream_t stream);
 

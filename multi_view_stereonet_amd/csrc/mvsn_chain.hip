@@ -584,8 +584,8 @@ extern "C" size_t mvsn_incremental_cost_volume_workspace_bytes(int n_chains, int
 
 // What MVSN_CHAIN_AUTO resolves to for this many chains on this coarse grid.
 static int chain_auto_form(int n_chains, int rows, int cols) {
-  // few chains on the 16x32 grid: four workgroups per chain while they all fit the chip at once
-  if (mvsn::chain_band_supported(rows, cols) && n_chains * mvsn::chain_band_groups() <= mvsn::device_cus())
+  // few chains on a grid with a banded plan: several workgroups per chain while they all fit the chip at once
+  if (mvsn::chain_band_supported(rows, cols) && n_chains * mvsn::chain_band_groups(rows, cols) <= mvsn::device_cus())
     return MVSN_CHAIN_BANDED;
   if (mvsn::chain_wino_supported(rows, cols)) return MVSN_CHAIN_WINOGRAD;
   // no plane-resident plan: one workgroup per chain leaves the chip idle below ~one chain per CU
@@ -603,13 +603,13 @@ extern "C" size_t mvsn_incremental_cost_volume_workspace_bytes_for(int n_chains,
   if (n_chains <= 0 || rows <= 0 || cols <= 0 || num_idepth_samples <= 0) return 0;
   if (form == MVSN_CHAIN_AUTO) form = chain_auto_form(n_chains, rows, cols);
   if (form == MVSN_CHAIN_STEPWISE) return mvsn::chain_steps_workspace_bytes(n_chains, num_idepth_samples, rows, cols);
-  if (form == MVSN_CHAIN_BANDED) return mvsn::chain_band_workspace_bytes(n_chains);
+  if (form == MVSN_CHAIN_BANDED) return mvsn::chain_band_workspace_bytes(n_chains, rows, cols);
   if (form == MVSN_CHAIN_WINOGRAD) return 0;
   return mvsn_incremental_cost_volume_workspace_bytes(n_chains, rows, cols);
 }
 
-extern "C" size_t mvsn_incremental_cost_volume_status_offset(int n_chains) {
-  return n_chains > 0 ? mvsn::chain_band_status_offset(n_chains) : 0;
+extern "C" size_t mvsn_incremental_cost_volume_status_offset(int n_chains, int rows, int cols) {
+  return n_chains > 0 ? mvsn::chain_band_status_offset(n_chains, rows, cols) : 0;
 }
 
 #ifdef MVSN_CHAIN_STAMPS
@@ -641,7 +641,7 @@ extern "C" int mvsn_incremental_cost_volume(const float *src_image_lvl4, const f
   const int tiles = (P + 15) / 16;
   const int TP = (tiles + CH_WAVES - 1) / CH_WAVES;
   MVSN_REQUIRE(form != MVSN_CHAIN_BANDED || chain_band_supported(rows, cols), MVSN_E_TOOLARGE,
-               "mvsn_incremental_cost_volume: the banded form covers the 16x32 coarse grid only (%dx%d)", rows, cols);
+               "mvsn_incremental_cost_volume: the banded form has no plan for a %dx%d coarse grid (16x32, 30x40, 32x64)", rows, cols);
   MVSN_REQUIRE(wino || form == MVSN_CHAIN_STEPWISE || form == MVSN_CHAIN_BANDED || TP <= 8, MVSN_E_TOOLARGE,
                "mvsn_incremental_cost_volume: %dx%d coarse grid (%d px) exceeds the 2048 px plan", rows, cols, P);
   ChainArgs a;

@@ -208,7 +208,7 @@ class PlaneSweepEngine:
         # The banded chain form spins on its sibling workgroups: every workgroup of a launch must be resident, so two
         # such launches must not share the device (MultiViewStereoNet._forward_lanes clears this for its lanes).
         self.banded_ok = True
-        self.last_chain_form, self.last_chain_workspace = None, None
+        self.last_chain_form, self.last_chain_workspace, self.last_chain_shape = None, None, None
         self.recording: Optional["ForwardPlan"] = None    # the plan a forward is being recorded into
         self.plans: Dict[tuple, Optional[ForwardPlan]] = {}   # shape key -> plan (None: that shape runs eagerly)
         self.replays = 0
@@ -870,7 +870,7 @@ class PlaneSweepEngine:
             form = _native.CHAIN_DIRECT        # the Winograd convolutions of the stepwise form need cols % 4 == 0
         ws_bytes = self.lib.mvsn_incremental_cost_volume_workspace_bytes_for(N, D, rows, cols, form)
         ws = self.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
-        self.last_chain_form, self.last_chain_workspace = form, ws
+        self.last_chain_form, self.last_chain_workspace, self.last_chain_shape = form, ws, (N, rows, cols)
         P = rows * cols
         self._call("mvsn_incremental_cost_volume", self.lib.mvsn_incremental_cost_volume,
                    _native.ptr(src4), _native.ptr(H4), _native.ptr(Hinc), _native.ptr(plane0), _native.ptr(left_feats),
@@ -885,8 +885,8 @@ class PlaneSweepEngine:
         if self.last_chain_form != _native.CHAIN_BANDED or self.last_chain_workspace is None:
             return 0
         ws = self.last_chain_workspace
-        n = (ws.numel() - 64) // self.lib.mvsn_incremental_cost_volume_status_offset(1)
-        off = self.lib.mvsn_incremental_cost_volume_status_offset(n)
+        n, rows, cols = self.last_chain_shape
+        off = self.lib.mvsn_incremental_cost_volume_status_offset(n, rows, cols)
         return int(ws[off:off + 4].view(torch.int32).item())
 
     def soft_argmin(self, cost: torch.Tensor, samples: torch.Tensor) -> torch.Tensor:

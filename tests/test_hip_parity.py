@@ -687,8 +687,8 @@ def test_incremental_chain_vs_oracle(rows, cols, D, S, B, wname, form):
         pytest.skip(f"no Winograd plan for a {r4}x{c4} coarse grid")
     if form == "stepwise" and c4 % 4 != 0:
         pytest.skip(f"the stepwise form needs cols % 4 == 0 ({r4}x{c4})")
-    if form == "banded" and (r4, c4) != (16, 32):
-        pytest.skip(f"the banded form covers the 16x32 coarse grid ({r4}x{c4})")
+    if form == "banded" and (r4, c4) not in ((16, 32), (30, 40), (32, 64)):
+        pytest.skip(f"the banded form has plans for 16x32, 30x40 and 32x64 ({r4}x{c4})")
     net.options.chain_form = form
     try:
         _chain_vs_oracle(w, eng, rows, cols, D, S, B, form)
@@ -744,7 +744,7 @@ def _oracle_chain(w, src4, H, Hinc, F0, FL):
 
 
 def _motion_family(N, D, kind, seed):
-    """Incremental homographies with a prescribed inter-plane motion on the 16x32 grid (H = their running product)."""
+    """Incremental homographies with a prescribed inter-plane motion (H = their running product)."""
     g = torch.Generator().manual_seed(seed)
     Hinc = torch.eye(3).repeat(N, D, 1, 1)
     for n in range(N):
@@ -767,23 +767,31 @@ def _motion_family(N, D, kind, seed):
     return H, Hinc
 
 
-@pytest.mark.parametrize("kind,N,D", [("small", 1, 12), ("vertical", 2, 10), ("mixed", 3, 13), ("small", 8, 6)])
-def test_banded_chain_gather_paths_vs_oracle(kind, N, D):
+@pytest.mark.parametrize("kind,N,D,grid", [("small", 1, 12, (16, 32)), ("vertical", 2, 10, (16, 32)),
+                                            ("mixed", 3, 13, (16, 32)), ("small", 8, 6, (16, 32)),
+                                            ("small", 1, 9, (30, 40)), ("mixed", 2, 8, (30, 40)), ("vertical", 3, 7, (30, 40)),
+                                            ("small", 2, 8, (32, 64)), ("mixed", 1, 9, (32, 64)), ("vertical", 4, 6, (32, 64))])
+def test_banded_chain_gather_paths_vs_oracle(kind, N, D, grid):
     """The banded form's two gather paths (rows fetched into the LDS window / every tap from the granules) against the
-    oracle's recurrence AND against the plane-resident Winograd kernel on the same inputs."""
+    oracle's recurrence AND against another form of this library on the same inputs (the plane-resident Winograd kernel
+    on 16x32, the stepwise form on the grids that do not fit one CU), on all three banded geometries: 4 bands of 4 rows
+    (16x32), 15 of 2 (30x40: a partly filled patch tile, two halo items per thread), 16 of 2 with a +-1-row window
+    (32x64)."""
     w = load_weights("gta_sfm_150epochs")
     net = net_for("gta_sfm_150epochs")
     eng = net.engine()
     g = torch.Generator().manual_seed(5)
     H, Hinc = _motion_family(N, D, kind, seed=3)
-    src4 = torch.rand(N, 3, 16, 32, generator=g) * 2 - 1
-    F0 = torch.randn(N, 32, 16, 32, generator=g)
-    FL = torch.randn(N, 32, 16, 32, generator=g)
+    r4, c4 = grid
+    src4 = torch.rand(N, 3, r4, c4, generator=g) * 2 - 1
+    F0 = torch.randn(N, 32, r4, c4, generator=g)
+    FL = torch.randn(N, 32, r4, c4, generator=g)
     fvol_ref, cost_ref, mask_ref = _oracle_chain(w, src4, H, Hinc, F0, FL)
     dev = [x.to(DEV) for x in (src4, H, Hinc, F0, FL)]
     got = {}
+    other = "winograd" if grid == (16, 32) else "stepwise"
     try:
-        for form in ("banded", "winograd"):
+        for form in ("banded", other):
             net.options.chain_form = form
             cost, mask, fvol = eng.incremental_cost_volume(*dev, want_features=True)
             assert eng.chain_status() == 0
@@ -796,7 +804,7 @@ def test_banded_chain_gather_paths_vs_oracle(kind, N, D):
             mean_rel, max_rel = rel_err(a, b)
             print(f"chain[{form}] {kind} N={N} D={D} {name}: mean-rel {mean_rel:.3e} max-rel {max_rel:.3e}")
             assert mean_rel < 1e-5 and max_rel < 1e-4, (form, name, mean_rel, max_rel)
-    assert torch.equal(got["banded"][1], got["winograd"][1])
+    assert torch.equal(got["banded"][1], got[other][1])
 
 
 @pytest.mark.parametrize("form", ["winograd", "banded"])
@@ -865,17 +873,18 @@ def test_chain_groupnorm_single_pass_stays_accurate(case, D, form):
     assert vs_spread < 1e-3, (case, D, form, vs_spread)
 
 
-def test_banded_chain_hand_offs_under_uneven_load():
+@pytest.mark.parametrize("grid,N,D", [((16, 32), 5, 64), ((30, 40), 3, 24), ((32, 64), 4, 20)])
+def test_banded_chain_hand_offs_under_uneven_load(grid, N, D):
     """The inter-workgroup hand-offs (tagged granules) must not depend on timing or placement: the same launch
     repeated while a second stream keeps part of the chip busy with streaming copies of varying size must return
     bit-identical volumes every time (every word compared), and no wait may time out."""
     net = net_for("gta_sfm_150epochs")
     eng = net.engine()
-    N, D = 5, 64
+    r4, c4 = grid
     g = torch.Generator().manual_seed(9)
     H, Hinc = _motion_family(N, D, "small", seed=4)
-    dev = [x.to(DEV) for x in (torch.rand(N, 3, 16, 32, generator=g) * 2 - 1, H, Hinc,
-                               torch.randn(N, 32, 16, 32, generator=g), torch.randn(N, 32, 16, 32, generator=g))]
+    dev = [x.to(DEV) for x in (torch.rand(N, 3, r4, c4, generator=g) * 2 - 1, H, Hinc,
+                               torch.randn(N, 32, r4, c4, generator=g), torch.randn(N, 32, r4, c4, generator=g))]
     net.options.chain_form = "banded"
     try:
         cost0, mask0, fvol0 = eng.incremental_cost_volume(*dev, want_features=True)
