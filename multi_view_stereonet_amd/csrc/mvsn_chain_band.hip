@@ -630,6 +630,9 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
                         auto &&meanwhile) {
       float *gs = gstat + layer * 8;                  // [group][mean, rstd] of the previous step: the shift
       const float shift = gs[gown * 2];
+      float hshift[HI];                               // (few bands: every thread forms the statistics it needs itself)
+#pragma unroll
+      for (int it = 0; it < HI; ++it) hshift[it] = gs[hcg[it] * 2];
       float s[2] = {0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -701,26 +704,65 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
       }
       CB_STAMP(18 + layer * 4);
       cb_barrier();
-      // totals in a fixed order (band-major): every workgroup of the chain forms the same statistics bit for bit
-      if (tid0 < 4) {
-        const int g = tid0;
-        float s1 = 0.f, s2 = 0.f;
-        for (int mm = 0; mm < G; ++mm)
+      // totals in a fixed order: every workgroup of the chain forms the same statistics bit for bit
+      float own_mean, own_rstd, h_mean[HI], h_rstd[HI];
+      if constexpr (G <= 4) {
+        // few bands: each thread adds the 2 G records of the groups it needs itself (band-major), no second barrier
+        auto stats_of = [&](int g, float sh, float &mean, float &rstd) {
+          float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-          for (int pp = 0; pp < 2; ++pp) {
-            const float2 rec = *reinterpret_cast<const float2 *>(red + (mm * CB_WAVES + pp * 2 + (g >> 1)) * 4 + (g & 1) * 2);
-            s1 += rec.x;
-            s2 += rec.y;
+          for (int mm = 0; mm < G; ++mm)
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+              const float2 rec = *reinterpret_cast<const float2 *>(red + (mm * CB_WAVES + pp * 2 + (g >> 1)) * 4 + (g & 1) * 2);
+              s1 += rec.x;
+              s2 += rec.y;
+            }
+          const float ms = s1 * inv_n;
+          const float var = fmaxf(s2 * inv_n - ms * ms, 0.0f);
+          mean = sh + ms;
+          rstd = 1.0f / sqrtf(var + CB_GN_EPS);
+        };
+        stats_of(gown, shift, own_mean, own_rstd);
+#pragma unroll
+        for (int it = 0; it < HI; ++it) stats_of(hcg[it], hshift[it], h_mean[it], h_rstd[it]);
+        // (the next step's shift; nobody reads gs again before the barriers that follow)
+        if (pt == 0 && (lane & 31) == 0) gs[gown * 2] = own_mean;   // waves 0, 1 cover the four groups
+      } else {
+        // many bands: wave 0, one 16-lane row per group: lane `sub` adds the records of bands sub, sub + 16, ..., four
+        // DPP steps add the row; everyone reads the result behind a second barrier
+        if (wave == 0) {
+          const int g = lane >> 4, sub = lane & 15;
+          float s2v[2] = {0.f, 0.f};
+          for (int mm = sub; mm < G; mm += 16)
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp) {
+              const float2 rec = *reinterpret_cast<const float2 *>(red + (mm * CB_WAVES + pp * 2 + (g >> 1)) * 4 + (g & 1) * 2);
+              s2v[0] += rec.x;
+              s2v[1] += rec.y;
+            }
+#pragma unroll
+          for (int q2 = 0; q2 < 2; ++q2) {
+            s2v[q2] += dpp_mov<0xB1>(s2v[q2]);
+            s2v[q2] += dpp_mov<0x4E>(s2v[q2]);
+            s2v[q2] += dpp_mov<0x141>(s2v[q2]);
+            s2v[q2] += dpp_mov<0x140>(s2v[q2]);
           }
-        const float ms = s1 * inv_n;
-        const float var = fmaxf(s2 * inv_n - ms * ms, 0.0f);
-        gs[g * 2] = gs[g * 2] + ms;                         // mean = shift + E[x - shift]
-        gs[g * 2 + 1] = 1.0f / sqrtf(var + CB_GN_EPS);
+          if (sub == 0) {
+            const float ms = s2v[0] * inv_n;
+            const float var = fmaxf(s2v[1] * inv_n - ms * ms, 0.0f);
+            gs[g * 2] = gs[g * 2] + ms;                         // mean = shift + E[x - shift]
+            gs[g * 2 + 1] = 1.0f / sqrtf(var + CB_GN_EPS);
+          }
+        }
+        cb_barrier();
+        own_mean = gs[gown * 2], own_rstd = gs[gown * 2 + 1];
+#pragma unroll
+        for (int it = 0; it < HI; ++it) h_mean[it] = gs[hcg[it] * 2], h_rstd[it] = gs[hcg[it] * 2 + 1];
       }
-      cb_barrier();
       CB_STAMP(19 + layer * 4);
       if (pvalid) {
-        const float mean = gs[gown * 2], rstd = gs[gown * 2 + 1];
+        const float mean = own_mean, rstd = own_rstd;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int c = cbase + r;
@@ -739,7 +781,7 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
 #pragma unroll
       for (int it = 0; it < HI; ++it)
         if (hvalid[it]) {
-          const float mean = gs[hcg[it] * 2], rstd = gs[hcg[it] * 2 + 1];
+          const float mean = h_mean[it], rstd = h_rstd[it];
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const int c = hcg[it] * 8 + j;

@@ -11,7 +11,8 @@ ctypes.CDLL(_native.library_path()).mvsn_debug_set_chain_stamps(ctypes.c_void_p(
 net = MultiViewStereoNet(); net.load_state_dict(load_weights("gta_sfm_150epochs")); net = net.cuda().eval()
 eng = net.engine()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-rows, cols, D = 16, 32, 64
+rows, cols = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (16, 32)
+D = 64
 g = torch.Generator().manual_seed(0)
 src4 = (torch.rand(N, 3, rows, cols, generator=g) * 2 - 1).cuda()
 H = torch.eye(3).repeat(N, D, 1, 1); H[:, :, 0, 2] = torch.linspace(0, 12, D)[None]
