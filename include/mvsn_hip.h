@@ -240,6 +240,15 @@ int mvsn_groupnorm_lrelu_apply(const float *x, const float *stats, const float *
 int mvsn_groupnorm_lrelu_add2(const float *x, const float *stats, const float *gamma, const float *beta,
                               const float *r, const float *r_stats, const float *r_gamma, const float *r_beta, int n,
                               long spatial, float *out, mvsn_stream_t stream);
+/* mvsn_groupnorm_lrelu_apply / _add2 handed the producing convolution's RECORDS (N, tiles, 4, 3) instead of finalised
+ * statistics: every workgroup of the pass forms x's (mean, rstd) itself with mvsn_groupnorm_finalize's own code (same
+ * bits), so the dependent finalize launch in front of the pass disappears -- small batches, where that launch (7 us)
+ * costs more than re-reading a few hundred records per workgroup.  r_stats NULL: plain pass (residual optional);
+ * r_stats set (finalised, (N,4,2)): the _add2 form with the raw residual `residual`. */
+int mvsn_groupnorm_lrelu_apply_records(const float *x, const float *records, int tiles, const float *gamma,
+                                       const float *beta, const float *residual, const float *r_stats,
+                                       const float *r_gamma, const float *r_beta, int n, long spatial, float *out,
+                                       mvsn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * 32 -> 1 channel 3x3 (kd = 1) or 3x3x3 (kd = 3) convolution, 'same' padding, dilation 1: the last
@@ -268,6 +277,12 @@ int mvsn_conv_to1_volume_norm(const float *in_raw, const float *in_stats, const 
 int mvsn_conv_to1_block(const float *in_raw, const float *in_stats, const float *in_gamma, const float *in_beta,
                         const float *in_residual, const float *weight, const float *bias, const float *prior,
                         const float *fx, int n, int rows, int cols, float *out, mvsn_stream_t stream);
+/* The same with in_raw's statistics formed inside the launch from its records (N, tiles, 4, 3), see
+ * mvsn_groupnorm_lrelu_apply_records. */
+int mvsn_conv_to1_block_records(const float *in_raw, const float *in_records, int tiles, const float *in_gamma,
+                                const float *in_beta, const float *in_residual, const float *weight, const float *bias,
+                                const float *prior, const float *fx, int n, int rows, int cols, float *out,
+                                mvsn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Soft-argmin over the hypothesis axis: out = sum_d softmax(-cost)_d * idepth_d.

@@ -146,4 +146,90 @@ __device__ __forceinline__ Bilinear bilinear_taps(float ix, float iy, int rows, 
   return b;
 }
 
+
+// ---- GroupNorm statistics of ONE sample from the producing convolution's records -------------------------------------
+// Combination of the per-record (count, mean, M2) in double by a 256-thread workgroup; a thread reads whole 48-byte
+// records (all four groups), one pass:  N = sum c,  S = sum c*mean,  Q = sum (M2 + c*mean^2)  ->  var = Q/N - (S/N)^2
+// (the subtraction is done in double on sums of fp32 data: ~1e-16 relative, far below the fp32 inputs' own rounding).
+// `out8` = [group][mean, rstd], global or LDS; written by threads 0..3, NOT yet published to the other threads.
+// Every caller runs this very code with 256 threads, so a statistic is the same bit pattern wherever it is formed
+// (mvsn_groupnorm_finalize's own launch, or a consumer that was handed the records: `gn_stats_here`).
+constexpr float GN_FINALIZE_EPS = 1e-5f;
+// `only` >= 0 (workgroup-uniform): just that group's statistics are formed (same operations in the same order for it).
+__device__ __forceinline__ void gn_finalize_block(const float *__restrict__ records, int tiles, float *out8,
+                                                  int only = -1) {
+  const int tid = threadIdx.x;
+  const floatx4 *p = reinterpret_cast<const floatx4 *>(records);
+  double acc[4][3];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) acc[g][0] = acc[g][1] = acc[g][2] = 0.0;
+  auto add = [&](const floatx4 &a, const floatx4 &b, const floatx4 &c) {
+    const float e[12] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3]};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (only >= 0 && g != only) continue;
+      const double cnt = (double)e[g * 3], mean = (double)e[g * 3 + 1];
+      acc[g][0] += cnt;
+      acc[g][1] += cnt * mean;
+      acc[g][2] += (double)e[g * 3 + 2] + cnt * mean * mean;
+    }
+  };
+  // eight records in flight per thread: a level-0 refiner layer leaves 8192 records per sample, and with one record
+  // per iteration the launch was 32 dependent round trips long (25-32 us, 45 launches per forward)
+  constexpr int GF_U = 8;
+  int t = tid;
+  for (; t + (GF_U - 1) * 256 < tiles; t += GF_U * 256) {
+    floatx4 r[GF_U][3];
+#pragma unroll
+    for (int u = 0; u < GF_U; ++u)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) r[u][k] = p[(size_t)(t + u * 256) * 3 + k];
+#pragma unroll
+    for (int u = 0; u < GF_U; ++u) add(r[u][0], r[u][1], r[u][2]);   // (same order as the one-by-one loop)
+  }
+  for (; t < tiles; t += 256) add(p[(size_t)t * 3], p[(size_t)t * 3 + 1], p[(size_t)t * 3 + 2]);
+  __shared__ double gn_red[4][12];   // per wave
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (only >= 0 && g != only) continue;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      double v = acc[g][k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      acc[g][k] = v;
+    }
+  }
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gn_red[tid >> 6][g * 3 + k] = acc[g][k];
+  }
+  __syncthreads();
+  if (tid < 4 && (only < 0 || tid == only)) {
+    const int g = tid;
+    const double N = gn_red[0][g * 3] + gn_red[1][g * 3] + gn_red[2][g * 3] + gn_red[3][g * 3];
+    const double S = gn_red[0][g * 3 + 1] + gn_red[1][g * 3 + 1] + gn_red[2][g * 3 + 1] + gn_red[3][g * 3 + 1];
+    const double Q = gn_red[0][g * 3 + 2] + gn_red[1][g * 3 + 2] + gn_red[2][g * 3 + 2] + gn_red[3][g * 3 + 2];
+    const double mean = S / N;
+    double var = Q / N - mean * mean;
+    if (var < 0.0) var = 0.0;
+    out8[g * 2 + 0] = (float)mean;
+    out8[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)GN_FINALIZE_EPS));
+  }
+}
+
+// The statistics a consumer of sample n works with: `stats` is either the finalised (N,4,2) array (tiles == 0) or the
+// producer's records (N, tiles, 4, 3) -- then this workgroup (256 threads, all of them must call) forms them itself,
+// which saves the dependent mvsn_groupnorm_finalize launch in front of it (small batches: the launch costs more than
+// re-reading a few hundred records per workgroup).  Returns 8 floats [group][mean, rstd]; `lds8` is the caller's.
+__device__ __forceinline__ const float *gn_stats_here(const float *__restrict__ stats, int tiles, int n, float *lds8,
+                                                      int only = -1) {
+  if (tiles == 0) return stats + (size_t)n * 8;
+  gn_finalize_block(stats + (size_t)n * tiles * 12, tiles, lds8, only);
+  __syncthreads();
+  return lds8;
+}
+
 }  // namespace mvsn

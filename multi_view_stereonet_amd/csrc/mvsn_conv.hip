@@ -850,68 +850,11 @@ __global__ __launch_bounds__(256) void conv5x5s2_head_kernel(const float *__rest
   }   // tiles of this workgroup
 }
 
-// Combination of the per-record (count, mean, M2) in double; one workgroup per sample, a thread reads whole 48-byte
-// records (all four groups), one pass:  N = sum c,  S = sum c*mean,  Q = sum (M2 + c*mean^2)  ->  var = Q/N - (S/N)^2
-// (the subtraction is done in double on sums of fp32 data: ~1e-16 relative, far below the fp32 inputs' own rounding).
+// One workgroup per sample: gn_finalize_block (mvsn_common.h).
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restrict__ partials, int tiles,
                                                           float *__restrict__ stats) {
-  const int n = blockIdx.x, tid = threadIdx.x;
-  const floatx4 *p = reinterpret_cast<const floatx4 *>(partials + (size_t)n * tiles * 12);
-  double acc[4][3];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) acc[g][0] = acc[g][1] = acc[g][2] = 0.0;
-  auto add = [&](const floatx4 &a, const floatx4 &b, const floatx4 &c) {
-    const float e[12] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3]};
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const double cnt = (double)e[g * 3], mean = (double)e[g * 3 + 1];
-      acc[g][0] += cnt;
-      acc[g][1] += cnt * mean;
-      acc[g][2] += (double)e[g * 3 + 2] + cnt * mean * mean;
-    }
-  };
-  // eight records in flight per thread: a level-0 refiner layer leaves 8192 records per sample, and with one record
-  // per iteration the launch was 32 dependent round trips long (25-32 us, 45 launches per forward)
-  constexpr int GF_U = 8;
-  int t = tid;
-  for (; t + (GF_U - 1) * 256 < tiles; t += GF_U * 256) {
-    floatx4 r[GF_U][3];
-#pragma unroll
-    for (int u = 0; u < GF_U; ++u)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) r[u][k] = p[(size_t)(t + u * 256) * 3 + k];
-#pragma unroll
-    for (int u = 0; u < GF_U; ++u) add(r[u][0], r[u][1], r[u][2]);   // (same order as the one-by-one loop)
-  }
-  for (; t < tiles; t += 256) add(p[(size_t)t * 3], p[(size_t)t * 3 + 1], p[(size_t)t * 3 + 2]);
-  __shared__ double red[4][12];   // per wave
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      double v = acc[g][k];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-      acc[g][k] = v;
-    }
-  if ((tid & 63) == 0) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) red[tid >> 6][g * 3 + k] = acc[g][k];
-  }
-  __syncthreads();
-  if (tid < 4) {
-    const int g = tid;
-    const double N = red[0][g * 3] + red[1][g * 3] + red[2][g * 3] + red[3][g * 3];
-    const double S = red[0][g * 3 + 1] + red[1][g * 3 + 1] + red[2][g * 3 + 1] + red[3][g * 3 + 1];
-    const double Q = red[0][g * 3 + 2] + red[1][g * 3 + 2] + red[2][g * 3 + 2] + red[3][g * 3 + 2];
-    const double mean = S / N;
-    double var = Q / N - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[((size_t)n * 4 + g) * 2 + 0] = (float)mean;
-    stats[((size_t)n * 4 + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)CV_EPS));
-  }
+  const int n = blockIdx.x;
+  gn_finalize_block(partials + (size_t)n * tiles * 12, tiles, stats + (size_t)n * 8);
 }
 
 // out = [residual +] LeakyReLU(GroupNorm(x)), (N,32,spatial), float4 per thread.
@@ -927,11 +870,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
                                                        const float *__restrict__ r_stats,
                                                        const float *__restrict__ r_gamma,
                                                        const float *__restrict__ r_beta, long spatial,
-                                                       float *__restrict__ out) {
+                                                       int stat_tiles, float *__restrict__ out) {
   const int plane = blockIdx.y;  // n*32 + c
   const int n = plane >> 5, c = plane & 31;
-  const float mean = stats[((size_t)n * 4 + (c >> 3)) * 2 + 0];
-  const float rstd = stats[((size_t)n * 4 + (c >> 3)) * 2 + 1];
+  __shared__ float gst[8];
+  const float *st = gn_stats_here(stats, stat_tiles, n, gst, c >> 3);   // (stat_tiles > 0: x's statistics from its records)
+  const float mean = st[(c >> 3) * 2 + 0];
+  const float rstd = st[(c >> 3) * 2 + 1];
   const float sc = rstd * gamma[c];
   const float sh = beta[c] - mean * sc;
   float rsc = 1.0f, rsh = 0.0f;
@@ -1243,21 +1188,37 @@ extern "C" int mvsn_groupnorm_finalize(const float *partials, int n, int tiles, 
   return mvsn::check_launch("mvsn_groupnorm_finalize");
 }
 
+// stat_tiles == 0: `stats` is the finalised (N,4,2) array; > 0: the producer's records (N, stat_tiles, 4, 3), finalised by
+// every workgroup of the pass itself (gn_stats_here)
+static int gn_apply_launch(const char *what, const float *x, const float *stats, int stat_tiles, const float *gamma,
+                           const float *beta, const float *residual, const float *r_stats, const float *r_gamma,
+                           const float *r_beta, int n, long spatial, float *out, mvsn_stream_t stream) {
+  long per = (spatial + 4095) / 4096;   // 4 float4 per thread per pass
+  int gx = (int)(per < 1 ? 1 : (per > 32 ? 32 : per));
+  const long sstride = stat_tiles > 0 ? (long)stat_tiles * 12 : 8;
+  for (int n0 = 0; n0 < n; n0 += mvsn::GN_APPLY_MAX_N) {   // grid.y carries (sample, channel): 2047 samples per launch
+    const int nn = n - n0 < mvsn::GN_APPLY_MAX_N ? n - n0 : mvsn::GN_APPLY_MAX_N;
+    const long off = (long)n0 * 32 * spatial;
+    if (r_stats)
+      hipLaunchKernelGGL(mvsn::gn_apply_kernel<true>, dim3(gx, nn * 32), dim3(256), 0, (hipStream_t)stream, x + off,
+                         stats + (long)n0 * sstride, gamma, beta, residual + off, r_stats + (long)n0 * 8, r_gamma, r_beta,
+                         spatial, stat_tiles, out + off);
+    else
+      hipLaunchKernelGGL(mvsn::gn_apply_kernel<false>, dim3(gx, nn * 32), dim3(256), 0, (hipStream_t)stream, x + off,
+                         stats + (long)n0 * sstride, gamma, beta, residual ? residual + off : residual,
+                         (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, spatial, stat_tiles,
+                         out + off);
+  }
+  return mvsn::check_launch(what);
+}
+
 extern "C" int mvsn_groupnorm_lrelu_apply(const float *x, const float *stats, const float *gamma, const float *beta,
                                           const float *residual, int n, long spatial, float *out,
                                           mvsn_stream_t stream) {
   MVSN_REQUIRE(x && stats && gamma && beta && out && n > 0 && spatial > 0, MVSN_E_BADARG,
                "mvsn_groupnorm_lrelu_apply: bad argument");
-  long per = (spatial + 4095) / 4096;   // 4 float4 per thread per pass
-  int gx = (int)(per < 1 ? 1 : (per > 32 ? 32 : per));
-  for (int n0 = 0; n0 < n; n0 += mvsn::GN_APPLY_MAX_N) {   // grid.y carries (sample, channel): 2047 samples per launch
-    const int nn = n - n0 < mvsn::GN_APPLY_MAX_N ? n - n0 : mvsn::GN_APPLY_MAX_N;
-    const long off = (long)n0 * 32 * spatial;
-    hipLaunchKernelGGL(mvsn::gn_apply_kernel<false>, dim3(gx, nn * 32), dim3(256), 0, (hipStream_t)stream, x + off,
-                       stats + (long)n0 * 8, gamma, beta, residual ? residual + off : residual, (const float *)nullptr,
-                       (const float *)nullptr, (const float *)nullptr, spatial, out + off);
-  }
-  return mvsn::check_launch("mvsn_groupnorm_lrelu_apply");
+  return gn_apply_launch("mvsn_groupnorm_lrelu_apply", x, stats, 0, gamma, beta, residual, nullptr, nullptr, nullptr, n,
+                         spatial, out, stream);
 }
 
 extern "C" int mvsn_groupnorm_lrelu_add2(const float *x, const float *stats, const float *gamma, const float *beta,
@@ -1265,16 +1226,20 @@ extern "C" int mvsn_groupnorm_lrelu_add2(const float *x, const float *stats, con
                                          const float *r_beta, int n, long spatial, float *out, mvsn_stream_t stream) {
   MVSN_REQUIRE(x && stats && gamma && beta && r && r_stats && r_gamma && r_beta && out && n > 0 && spatial > 0,
                MVSN_E_BADARG, "mvsn_groupnorm_lrelu_add2: bad argument");
-  long per = (spatial + 4095) / 4096;
-  int gx = (int)(per < 1 ? 1 : (per > 32 ? 32 : per));
-  for (int n0 = 0; n0 < n; n0 += mvsn::GN_APPLY_MAX_N) {
-    const int nn = n - n0 < mvsn::GN_APPLY_MAX_N ? n - n0 : mvsn::GN_APPLY_MAX_N;
-    const long off = (long)n0 * 32 * spatial;
-    hipLaunchKernelGGL(mvsn::gn_apply_kernel<true>, dim3(gx, nn * 32), dim3(256), 0, (hipStream_t)stream, x + off,
-                       stats + (long)n0 * 8, gamma, beta, r + off, r_stats + (long)n0 * 8, r_gamma, r_beta, spatial,
-                       out + off);
-  }
-  return mvsn::check_launch("mvsn_groupnorm_lrelu_add2");
+  return gn_apply_launch("mvsn_groupnorm_lrelu_add2", x, stats, 0, gamma, beta, r, r_stats, r_gamma, r_beta, n, spatial,
+                         out, stream);
+}
+
+extern "C" int mvsn_groupnorm_lrelu_apply_records(const float *x, const float *records, int tiles, const float *gamma,
+                                                  const float *beta, const float *residual, const float *r_stats,
+                                                  const float *r_gamma, const float *r_beta, int n, long spatial,
+                                                  float *out, mvsn_stream_t stream) {
+  MVSN_REQUIRE(x && records && tiles > 0 && gamma && beta && out && n > 0 && spatial > 0, MVSN_E_BADARG,
+               "mvsn_groupnorm_lrelu_apply_records: bad argument");
+  MVSN_REQUIRE(!r_stats || (residual && r_gamma && r_beta), MVSN_E_BADARG,
+               "mvsn_groupnorm_lrelu_apply_records: a raw residual needs its statistics, gamma and beta");
+  return gn_apply_launch("mvsn_groupnorm_lrelu_apply_records", x, records, tiles, gamma, beta, residual, r_stats, r_gamma,
+                         r_beta, n, spatial, out, stream);
 }
 
 extern "C" int mvsn_conv_forward_carry(const mvsn_conv_desc *desc, const float *in, const float *weight_packed,

@@ -621,7 +621,8 @@ __global__ __launch_bounds__(256) void conv_to1_2d_mfma_kernel(const float *__re
                                                                const float *__restrict__ in_beta,
                                                                const float *__restrict__ in_residual,
                                                                const float *__restrict__ prior, const float *__restrict__ fx,
-                                                               int H, int W, int ntx, float *__restrict__ out) {
+                                                               int H, int W, int ntx, int stat_tiles,
+                                                               float *__restrict__ out) {
   constexpr int T2_XS = T2<T2_TX>::XS, T2_SLOTS = T2<T2_TX>::SLOTS, T2_GROUPS = T2<T2_TX>::GROUPS;
   __shared__ __attribute__((aligned(16))) float P[T2<T2_TX>::LDS_FLOATS];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -637,13 +638,16 @@ __global__ __launch_bounds__(256) void conv_to1_2d_mfma_kernel(const float *__re
 
   float a[8];   // A fragments: w[cin = 4 ks + kc][tap = lane & 15]
   float sc[8], sh[8];
+  __shared__ float gst[8];
+  const float *st = nullptr;
+  if constexpr (XFORM) st = gn_stats_here(in_stats, stat_tiles, n, gst);   // (stat_tiles > 0: from the producer's records)
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) {
     const int tap = lane & 15, c = ks * 4 + kc;
     a[ks] = tap < 9 ? w[c * 9 + tap] : 0.0f;
     if constexpr (XFORM) {
-      const float mean = in_stats[((size_t)n * 4 + (c >> 3)) * 2 + 0];
-      const float rstd = in_stats[((size_t)n * 4 + (c >> 3)) * 2 + 1];
+      const float mean = st[(c >> 3) * 2 + 0];
+      const float rstd = st[(c >> 3) * 2 + 1];
       sc[ks] = rstd * in_gamma[c];
       sh[ks] = in_beta[c] - mean * sc[ks];
     }
@@ -768,12 +772,12 @@ extern "C" int mvsn_conv_to1(const float *in, const float *weight, const float *
       const int ntx = (cols + 63) / 64;
       hipLaunchKernelGGL((mvsn::conv_to1_2d_mfma_kernel<false, 64>), dim3(nty * ntx, n), dim3(256), 0,
                          (hipStream_t)stream, in, weight, bias, (const float *)nullptr, (const float *)nullptr,
-                         (const float *)nullptr, (const float *)nullptr, prior, fx, rows, cols, ntx, out);
+                         (const float *)nullptr, (const float *)nullptr, prior, fx, rows, cols, ntx, 0, out);
     } else {
       const int ntx = (cols + 31) / 32;
       hipLaunchKernelGGL((mvsn::conv_to1_2d_mfma_kernel<false, 32>), dim3(nty * ntx, n), dim3(256), 0,
                          (hipStream_t)stream, in, weight, bias, (const float *)nullptr, (const float *)nullptr,
-                         (const float *)nullptr, (const float *)nullptr, prior, fx, rows, cols, ntx, out);
+                         (const float *)nullptr, (const float *)nullptr, prior, fx, rows, cols, ntx, 0, out);
     }
   }
   return mvsn::check_launch("mvsn_conv_to1");
@@ -789,25 +793,43 @@ extern "C" int mvsn_conv_to1_volume_norm(const float *in_raw, const float *in_st
   return conv_to1_volume(in_raw, weight, bias, in_stats, in_gamma, in_beta, n, depth, rows, cols, out, stream);
 }
 
-extern "C" int mvsn_conv_to1_block(const float *in_raw, const float *in_stats, const float *in_gamma,
-                                   const float *in_beta, const float *in_residual, const float *weight,
-                                   const float *bias, const float *prior, const float *fx, int n, int rows, int cols,
-                                   float *out, mvsn_stream_t stream) {
-  MVSN_REQUIRE(in_raw && in_stats && in_gamma && in_beta && weight && out, MVSN_E_BADARG,
-               "mvsn_conv_to1_block: null pointer");
-  MVSN_REQUIRE(n > 0 && rows > 0 && cols > 0, MVSN_E_BADARG, "mvsn_conv_to1_block: bad sizes");
-  MVSN_REQUIRE(cols % 4 == 0, MVSN_E_BADARG, "mvsn_conv_to1_block: cols must be a multiple of 4");
-  MVSN_REQUIRE(!prior || fx, MVSN_E_BADARG, "mvsn_conv_to1_block: refiner epilogue needs fx");
-  MVSN_REQUIRE(n <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_to1_block: grid");
+static int conv_to1_block_launch(const char *what, const float *in_raw, const float *in_stats, int stat_tiles,
+                                 const float *in_gamma, const float *in_beta, const float *in_residual,
+                                 const float *weight, const float *bias, const float *prior, const float *fx, int n,
+                                 int rows, int cols, float *out, mvsn_stream_t stream) {
+  MVSN_REQUIRE(in_raw && in_stats && in_gamma && in_beta && weight && out, MVSN_E_BADARG, "%s: null pointer", what);
+  MVSN_REQUIRE(n > 0 && rows > 0 && cols > 0, MVSN_E_BADARG, "%s: bad sizes", what);
+  MVSN_REQUIRE(cols % 4 == 0, MVSN_E_BADARG, "%s: cols must be a multiple of 4", what);
+  MVSN_REQUIRE(!prior || fx, MVSN_E_BADARG, "%s: refiner epilogue needs fx", what);
+  MVSN_REQUIRE(n <= 65535, MVSN_E_TOOLARGE, "%s: grid", what);
   const int nty = (rows + mvsn::T2_TY - 1) / mvsn::T2_TY;
   if (mvsn::to1_wide_tiles(n, rows, cols)) {
     const int ntx = (cols + 63) / 64;
     hipLaunchKernelGGL((mvsn::conv_to1_2d_mfma_kernel<true, 64>), dim3(nty * ntx, n), dim3(256), 0, (hipStream_t)stream,
-                       in_raw, weight, bias, in_stats, in_gamma, in_beta, in_residual, prior, fx, rows, cols, ntx, out);
+                       in_raw, weight, bias, in_stats, in_gamma, in_beta, in_residual, prior, fx, rows, cols, ntx,
+                       stat_tiles, out);
   } else {
     const int ntx = (cols + 31) / 32;
     hipLaunchKernelGGL((mvsn::conv_to1_2d_mfma_kernel<true, 32>), dim3(nty * ntx, n), dim3(256), 0, (hipStream_t)stream,
-                       in_raw, weight, bias, in_stats, in_gamma, in_beta, in_residual, prior, fx, rows, cols, ntx, out);
+                       in_raw, weight, bias, in_stats, in_gamma, in_beta, in_residual, prior, fx, rows, cols, ntx,
+                       stat_tiles, out);
   }
-  return mvsn::check_launch("mvsn_conv_to1_block");
+  return mvsn::check_launch(what);
+}
+
+extern "C" int mvsn_conv_to1_block(const float *in_raw, const float *in_stats, const float *in_gamma,
+                                   const float *in_beta, const float *in_residual, const float *weight,
+                                   const float *bias, const float *prior, const float *fx, int n, int rows, int cols,
+                                   float *out, mvsn_stream_t stream) {
+  return conv_to1_block_launch("mvsn_conv_to1_block", in_raw, in_stats, 0, in_gamma, in_beta, in_residual, weight, bias,
+                               prior, fx, n, rows, cols, out, stream);
+}
+
+extern "C" int mvsn_conv_to1_block_records(const float *in_raw, const float *in_records, int tiles,
+                                           const float *in_gamma, const float *in_beta, const float *in_residual,
+                                           const float *weight, const float *bias, const float *prior, const float *fx,
+                                           int n, int rows, int cols, float *out, mvsn_stream_t stream) {
+  MVSN_REQUIRE(tiles > 0, MVSN_E_BADARG, "mvsn_conv_to1_block_records: tiles");
+  return conv_to1_block_launch("mvsn_conv_to1_block_records", in_raw, in_records, tiles, in_gamma, in_beta, in_residual,
+                               weight, bias, prior, fx, n, rows, cols, out, stream);
 }

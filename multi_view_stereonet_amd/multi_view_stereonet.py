@@ -106,6 +106,11 @@ class EngineOptions:
         # Skip the stand-alone normalise/activate pass at both ends of a refiner tower (see
         # residual_tower_unfused); False keeps one pass per block (tests compare the two).
         self.trim_tower_ends = True
+        # Small batches: hand a normalise/activate pass (or the folded 32 -> 1 tail) the producing convolution's RECORDS
+        # instead of finalised statistics -- its workgroups run mvsn_groupnorm_finalize's code themselves (same bits) and
+        # the dependent 7 us finalize launch in front of it disappears.  Limits: samples per launch, records per sample.
+        self.lazy_stats_max_samples = 8
+        self.lazy_stats_max_records = 2048
         self.cat_free_heads = True         # refiner heads read [image, features, idepth] in place (no torch.cat)
         # The fused chain's three 3x3 convolutions: "auto" = Winograd F(2x2,3x3) where the coarse grid has a plan
         # (16x32 at 512x256 frames); elsewhere one plane per round of full-chip launches ("stepwise") while fewer
@@ -134,7 +139,17 @@ class EngineOptions:
         self.plan_max_bytes = 8 << 30   # intermediates all recorded plans together may keep alive
 
     NAMES = ("towers", "plan_max_chains", "plan_graph", "plan_max_bytes", "carry_passes", "carry_min_bytes", "carry_volume_passes", "carry_alternate", "chain_form", "fold_residual_blocks", "conv_precision", "winograd", "winograd_with_input_transform",
-             "winograd_volume", "volume_materialise", "trim_tower_ends", "cat_free_heads")
+             "winograd_volume", "volume_materialise", "trim_tower_ends", "cat_free_heads", "lazy_stats_max_samples",
+             "lazy_stats_max_records")
+
+
+class _Records:
+    """GroupNorm records of a convolution's output, (N, tiles, 4, 3), not finalised: a consumer that takes them
+    (gn_lrelu, gn_lrelu_add2, conv_to1_block) forms the statistics inside its own launch."""
+    __slots__ = ("partials", "tiles")
+
+    def __init__(self, partials: torch.Tensor):
+        self.partials, self.tiles = partials, int(partials.shape[1])
 
 
 class _Job:
@@ -393,8 +408,11 @@ class PlaneSweepEngine:
 
     def conv(self, c: _Conv, x: torch.Tensor, in_stats=None, in_norm: Optional[_Norm] = None, want_stats=False,
              in_residual: Optional[torch.Tensor] = None, write_staged: bool = False, carry: Optional["_Job"] = None,
-             out: Optional[torch.Tensor] = None, prefer_fp32_wino: bool = False):
+             out: Optional[torch.Tensor] = None, prefer_fp32_wino: bool = False, lazy_stats: bool = False):
         """x (N,C,[D,]H,W) -> (out, stats or None[, staged]).
+
+        `lazy_stats`: the caller's consumer of the statistics takes records (`_Records`); returned instead of the
+        finalised tensor when the batch is small enough for that to pay (lazy_stats_max_*).
 
         `in_stats`/`in_norm` fold LReLU(GN(x)) into the tile load; `in_residual` adds the residual
         branch on top (a whole SimpleBasicBlock folded into the NEXT layer's load); `write_staged`
@@ -476,9 +494,12 @@ class PlaneSweepEngine:
                        _native.stream(), flops=2.0 * c.cin * taps * c.cout * out[:, 0].numel(), nbytes=nbytes)
         stats = None
         if want_stats:
-            stats = self.empty((n, 4, 2), dtype=torch.float32, device=x.device)
-            self._call("mvsn_groupnorm_finalize", lib.mvsn_groupnorm_finalize, _native.ptr(partials), n,
-                       partials.shape[1], _native.ptr(stats), _native.stream())
+            if lazy_stats and n <= self.lazy_stats_max_samples and partials.shape[1] <= self.lazy_stats_max_records:
+                stats = _Records(partials)
+            else:
+                stats = self.empty((n, 4, 2), dtype=torch.float32, device=x.device)
+                self._call("mvsn_groupnorm_finalize", lib.mvsn_groupnorm_finalize, _native.ptr(partials), n,
+                           partials.shape[1], _native.ptr(stats), _native.stream())
         if write_staged:
             return out, stats, staged
         return out, stats
@@ -558,9 +579,9 @@ class PlaneSweepEngine:
         for i, (conv, norm) in enumerate(blocks):
             if pend is not None:
                 r0, st0, n0 = pend
-                r, st = self.conv(conv, r0, in_stats=st0, in_norm=n0, want_stats=True)
+                r, st = self.conv(conv, r0, in_stats=st0, in_norm=n0, want_stats=True, lazy_stats=True)
             else:
-                r, st = self.conv(conv, x, want_stats=True)
+                r, st = self.conv(conv, x, want_stats=True, lazy_stats=True)
             if i == len(blocks) - 1 and to1_ok and self.trim_tower_ends and pend is None:
                 return self.conv_to1_block(final, r, st, norm, x, prior, fx), prior is not None
             if pend is not None:
@@ -625,6 +646,12 @@ class PlaneSweepEngine:
     def gn_lrelu_add2(self, r, st, norm: _Norm, r0, st0, norm0: _Norm, out=None):
         n, spatial = r.shape[0], r[0, 0].numel()
         out = self.empty(r.shape, r.dtype, r.device) if out is None else out
+        if isinstance(st, _Records):
+            self._call("mvsn_groupnorm_lrelu_add2", self.lib.mvsn_groupnorm_lrelu_apply_records, _native.ptr(r),
+                       _native.ptr(st.partials), st.tiles, _native.ptr(norm.gamma), _native.ptr(norm.beta),
+                       _native.ptr(r0), _native.ptr(st0), _native.ptr(norm0.gamma), _native.ptr(norm0.beta), n, spatial,
+                       _native.ptr(out), _native.stream(), nbytes=4.0 * r.numel() * 3)
+            return out
         self._call("mvsn_groupnorm_lrelu_add2", self.lib.mvsn_groupnorm_lrelu_add2, _native.ptr(r), _native.ptr(st),
                    _native.ptr(norm.gamma), _native.ptr(norm.beta), _native.ptr(r0), _native.ptr(st0),
                    _native.ptr(norm0.gamma), _native.ptr(norm0.beta), n, spatial, _native.ptr(out), _native.stream(),
@@ -637,6 +664,13 @@ class PlaneSweepEngine:
         if out is None:
             out = self.empty((n, 1, rows, cols), dtype=torch.float32, device=r.device)
         assert tuple(out.shape) == (n, 1, rows, cols) and out.is_contiguous()
+        if isinstance(st, _Records):
+            self._call("mvsn_conv_to1_block", self.lib.mvsn_conv_to1_block_records, _native.ptr(r),
+                       _native.ptr(st.partials), st.tiles, _native.ptr(norm.gamma), _native.ptr(norm.beta),
+                       _native.ptr(x), _native.ptr(c.weight), _native.ptr(c.bias), _native.ptr(prior), _native.ptr(fx),
+                       n, rows, cols, _native.ptr(out), _native.stream(), flops=2.0 * 32 * 9 * out.numel(),
+                       nbytes=4.0 * (2 * r.numel() + out.numel()))
+            return out
         self._call("mvsn_conv_to1_block", self.lib.mvsn_conv_to1_block, _native.ptr(r), _native.ptr(st),
                    _native.ptr(norm.gamma), _native.ptr(norm.beta), _native.ptr(x), _native.ptr(c.weight),
                    _native.ptr(c.bias), _native.ptr(prior), _native.ptr(fx), n, rows, cols, _native.ptr(out),
@@ -674,6 +708,12 @@ class PlaneSweepEngine:
         n = r.shape[0]
         spatial = r[0, 0].numel()
         out = self.empty(r.shape, r.dtype, r.device) if out is None else out
+        if isinstance(stats, _Records):
+            self._call("mvsn_groupnorm_lrelu_apply", self.lib.mvsn_groupnorm_lrelu_apply_records, _native.ptr(r),
+                       _native.ptr(stats.partials), stats.tiles, _native.ptr(norm.gamma), _native.ptr(norm.beta),
+                       _native.ptr(residual), None, None, None, n, spatial, _native.ptr(out), _native.stream(),
+                       nbytes=4.0 * r.numel() * (3 if residual is not None else 2))
+            return out
         self._call("mvsn_groupnorm_lrelu_apply", self.lib.mvsn_groupnorm_lrelu_apply, _native.ptr(r),
                    _native.ptr(stats), _native.ptr(norm.gamma), _native.ptr(norm.beta), _native.ptr(residual), n,
                    spatial, _native.ptr(out), _native.stream(),
@@ -705,13 +745,14 @@ class PlaneSweepEngine:
                 self.conv_precision == "fp32" and to1 and n >= 2 and (depth * rows * cols) % 256 == 0 and
                 (n // 2) * 128 * depth * rows * cols >= self.carry_min_bytes):
             return self.cost_volume_filter_sliced(cost)
-        x, st = self.conv(self.vf_convs[0], cost, want_stats=True)
+        mat = self.volume_materialise and self.winograd and self.winograd_volume and self.conv_precision == "fp32"
+        x, st = self.conv(self.vf_convs[0], cost, want_stats=True, lazy_stats=mat)
         for i in range(1, 4):
-            if self.volume_materialise and self.winograd and self.winograd_volume and self.conv_precision == "fp32":
+            if mat:
                 # the volume Winograd kernel fetches every plane for three output planes: normalising it once in
                 # place (one HBM pass) is cheaper than three in-LDS passes inside the convolution
                 x = self.gn_lrelu(x, st, self.vf_norms[i - 1], out=x)
-                x, st = self.conv(self.vf_convs[i], x, want_stats=True)
+                x, st = self.conv(self.vf_convs[i], x, want_stats=True, lazy_stats=i < 3)
             else:
                 x, st = self.conv(self.vf_convs[i], x, in_stats=st, in_norm=self.vf_norms[i - 1], want_stats=True)
         last = self.vf_convs[4]

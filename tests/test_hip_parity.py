@@ -425,6 +425,40 @@ def test_refiner_tower_end_trimming_is_equivalent():
         close(a, b.cpu(), rtol=2e-5, atol=2e-6)
 
 
+def test_statistics_formed_by_the_consumer_are_bit_identical():
+    """Small batches: the normalise/activate passes and the folded 32 -> 1 tail are handed the producing convolution's
+    GroupNorm RECORDS and finalise them inside their own launch (mvsn_groupnorm_lrelu_apply_records,
+    mvsn_conv_to1_block_records) -- the same bits as with the stand-alone mvsn_groupnorm_finalize launch, fewer
+    launches; the regulariser's in-place passes likewise."""
+    eng = net_for("gta_sfm_150epochs").engine()
+    g = torch.Generator().manual_seed(21)
+    keep = (eng.lazy_stats_max_samples, eng.lazy_stats_max_records)
+    try:
+        for lvl, (rows, cols) in zip((3, 2, 1, 0), ((32, 64), (64, 128), (128, 256), (256, 512))):
+            cin = eng.refiners[lvl]["conv0"].cin
+            guide = torch.rand(2, cin - 1, rows, cols, generator=g).to(DEV)
+            prior = (torch.rand(2, 1, rows, cols, generator=g) * 0.5).to(DEV)
+            fx = torch.tensor([300.0 / 2 ** lvl, 260.0 / 2 ** lvl], device=DEV)
+            got = {}
+            for mode, (ms, mr) in (("records", (8, 1 << 20)), ("finalize", (0, 0))):
+                eng.lazy_stats_max_samples, eng.lazy_stats_max_records = ms, mr
+                eng.timeline = []
+                got[mode] = eng.idepth_refiner(lvl, guide, prior, fx)
+                got[mode + "_launches"] = sum(1 for e in eng.timeline if e[0] == "mvsn_groupnorm_finalize")
+            eng.timeline = None
+            assert torch.equal(got["records"], got["finalize"])
+            assert got["records_launches"] == 1 and got["finalize_launches"] == 7, got   # only the head's stay
+        cost = torch.randn(2, 32, 16, 16, 32, generator=g).to(DEV)
+        out = {}
+        for mode, (ms, mr) in (("records", (8, 1 << 20)), ("finalize", (0, 0))):
+            eng.lazy_stats_max_samples, eng.lazy_stats_max_records = ms, mr
+            out[mode] = eng.cost_volume_filter(cost.clone())
+        assert torch.equal(out["records"], out["finalize"])
+    finally:
+        eng.lazy_stats_max_samples, eng.lazy_stats_max_records = keep
+        eng.timeline = None
+
+
 def test_refiner_heads_without_concatenation_are_identical():
     """Refiner input handed to the head conv as [image, features, idepth] blocks vs. one torch.cat: bit-identical,
     for every refiner of the pretrained weights (the level-0 head has no feature block: 3 + 1 channels)."""

@@ -10,7 +10,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 dev = torch.device("cuda")
 net = MultiViewStereoNet(); net.load_state_dict(load_weights(bench.WEIGHTS)); net = net.to(dev).eval()
 _, inp = bench.make_inputs(B, 7, dev)
-variants = [dict(), dict(fold_residual_blocks=True), dict(winograd=False), dict(winograd=False, fold_residual_blocks=True),
+variants = [dict(), dict(lazy_stats_max_samples=0), dict(lazy_stats_max_records=512), dict(lazy_stats_max_records=8192),
+            dict(fold_residual_blocks=True), dict(winograd=False), dict(winograd=False, fold_residual_blocks=True),
             dict(trim_tower_ends=False), dict(winograd_volume=False), dict(cat_free_heads=False), dict(chain_form="winograd")]
 for opts in variants:
     old = {k: getattr(net.options, k) for k in opts}
