@@ -440,6 +440,12 @@ int mvsn_copy(void *dst, const void *src, size_t nbytes, mvsn_stream_t stream);
 int mvsn_gather_focal(const float *const *K_pyr, int levels, int batch, float *fx, mvsn_stream_t stream);
 int mvsn_gather_strided(const float *src, int count, long stride, float *dst, mvsn_stream_t stream);
 
+/* Test hook for the banded chain's failure path (process-wide, 0 = off): bit 1 = the last band of every chain never
+ * runs (what a shared device can do to a launch whose workgroups must be co-resident); bits 8.. = log2 of the spin
+ * limit of a hand-off (default 2^21).  With it the other bands time out: the status word is set, the cost slice carries
+ * a NaN (so the depth maps of that forward are NaN), nothing hangs. */
+int mvsn_debug_set_band_flags(int flags);
+
 /* Device self-test of the MFMA fragment mapping the conv kernels rely on (A = 16x4, B = 4x16
  * fp32, asymmetric operands); returns 0 when the on-device result matches the scalar product. */
 int mvsn_selftest_mfma(mvsn_stream_t stream);

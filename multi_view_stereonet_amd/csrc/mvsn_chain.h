@@ -51,6 +51,7 @@ bool chain_band_supported(int rows, int cols);
 int chain_band_groups(int rows, int cols);                 // workgroups per chain (0: no plan for this grid)
 size_t chain_band_workspace_bytes(int n_chains, int rows, int cols);
 size_t chain_band_status_offset(int n_chains, int rows, int cols);
+void chain_band_debug_flags(int flags);   // test hook, see mvsn_debug_set_band_flags
 int chain_band_launch(const ChainArgs &a, int n_chains, void *workspace, size_t workspace_bytes, int flags,
                       hipStream_t stream);
 

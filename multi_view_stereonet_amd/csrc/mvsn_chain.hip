@@ -612,6 +612,11 @@ extern "C" size_t mvsn_incremental_cost_volume_status_offset(int n_chains, int r
   return n_chains > 0 ? mvsn::chain_band_status_offset(n_chains, rows, cols) : 0;
 }
 
+extern "C" int mvsn_debug_set_band_flags(int flags) {
+  mvsn::chain_band_debug_flags(flags);
+  return 0;
+}
+
 #ifdef MVSN_CHAIN_STAMPS
 static unsigned long long *g_chain_stamps = nullptr;
 extern "C" int mvsn_debug_set_chain_stamps(void *buf) {

@@ -110,7 +110,8 @@ __device__ __forceinline__ void cb_publish2(gu64 *g, unsigned tag, float v0, flo
 // Re-read this lane's N granules until every tag in the wave matches.  `addr(j)` = granule j of this lane; lanes
 // with !active take no part.  Returns with v[] filled; after a time-out (recorded in *status) it gives up at once.
 template <int N, class Addr>
-__device__ __forceinline__ void cb_sweep(Addr addr, unsigned tag, bool active, float (&v)[N], bool &dead, gu32 *status) {
+__device__ __forceinline__ void cb_sweep(Addr addr, unsigned tag, bool active, float (&v)[N], bool &dead, gu32 *status,
+                                         unsigned spin_limit) {
   for (unsigned spins = 0;; ++spins) {
     bool ok = true;
     if (active) {
@@ -122,7 +123,7 @@ __device__ __forceinline__ void cb_sweep(Addr addr, unsigned tag, bool active, f
       }
     }
     if (__all(ok) || dead) return;
-    if (spins >= CB_SPIN_LIMIT) {
+    if (spins >= spin_limit) {
       dead = true;
       __hip_atomic_store(status, 1u, CB_RLX_AGENT);
       return;
@@ -253,6 +254,10 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
   const int lo = m * BR, hi = lo + BR - 1, wlo = lo - W;
   const int D = a.D;
   int tid = tid0;
+  // test hooks (mvsn_debug_set_band_flags): bits 8.. = log2 of the spin limit; bit 1 = the chain's last band never runs,
+  // as if the dispatcher had not found it a CU (what a shared device can do to a launch that needs co-residency)
+  const unsigned spin_limit = (flags >> 8) ? 1u << ((flags >> 8) & 31) : CB_SPIN_LIMIT;
+  if ((flags & 2) && m == G - 1) return;
 
   float *U = smem;
   float *sparams = U + CW_U0_FLOATS;
@@ -512,7 +517,7 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
               }
             }
           if (__all(ok) || dead) break;
-          if (spins >= CB_SPIN_LIMIT) {
+          if (spins >= spin_limit) {
             dead = true;
             __hip_atomic_store(status, 2u, CB_RLX_AGENT);
             break;
@@ -569,11 +574,11 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
         const int c0 = e < 4 ? cbase : hcg[it] * 8;
         float t00[NCH_MAX], t01[NCH_MAX], t10[NCH_MAX], t11[NCH_MAX];
         const gu64 *g = Fg + (size_t)c0 * P + (act_e ? y0 * cols + x0 : 0);
-        cb_sweep<NCH_MAX>([&](int j) { return g + (size_t)(j < nch ? j : 0) * P; }, d, act_e, t00, dead, status);
-        cb_sweep<NCH_MAX>([&](int j) { return g + (size_t)(j < nch ? j : 0) * P + (x1 ? 1 : 0); }, d, act_e, t01, dead, status);
-        cb_sweep<NCH_MAX>([&](int j) { return g + (size_t)(j < nch ? j : 0) * P + (y1 ? cols : 0); }, d, act_e, t10, dead, status);
+        cb_sweep<NCH_MAX>([&](int j) { return g + (size_t)(j < nch ? j : 0) * P; }, d, act_e, t00, dead, status, spin_limit);
+        cb_sweep<NCH_MAX>([&](int j) { return g + (size_t)(j < nch ? j : 0) * P + (x1 ? 1 : 0); }, d, act_e, t01, dead, status, spin_limit);
+        cb_sweep<NCH_MAX>([&](int j) { return g + (size_t)(j < nch ? j : 0) * P + (y1 ? cols : 0); }, d, act_e, t10, dead, status, spin_limit);
         cb_sweep<NCH_MAX>([&](int j) { return g + (size_t)(j < nch ? j : 0) * P + (y1 ? cols : 0) + (x1 ? 1 : 0); }, d, act_e,
-                          t11, dead, status);
+                          t11, dead, status, spin_limit);
 #pragma unroll
         for (int j = 0; j < NCH_MAX; ++j) {
           const float v01 = x1 ? t01[j] : 0.0f, v10 = y1 ? t10[j] : 0.0f, v11 = (x1 && y1) ? t11[j] : 0.0f;
@@ -693,7 +698,7 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
               }
             }
           if (__all(ok) || dead) break;
-          if (spins >= CB_SPIN_LIMIT) {
+          if (spins >= spin_limit) {
             dead = true;
             __hip_atomic_store(status, 3u + layer, CB_RLX_AGENT);
             break;
@@ -833,6 +838,11 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
   }
 #undef CB_STAMP
   dma_landed();       // the last step's look-ahead fetch must not outlive the workgroup's LDS
+  // A hand-off that timed out (the chain's workgroups were not co-resident: the device is shared with other work) leaves
+  // wrong numbers behind.  Besides the status word, make that impossible to miss without a host round trip: one NaN in
+  // the cost slice turns the regulariser's GroupNorm statistics -- and with them the whole depth map -- into NaN.
+  // (written by the thread that owns the element: program order puts it behind the last step's own store)
+  if (__syncthreads_or(dead) && pvalid) costg[(size_t)(D - 1) * P + slice_off] = __builtin_nanf("");
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------
@@ -876,8 +886,12 @@ size_t chain_band_status_offset(int n_chains, int rows, int cols) {
 }
 
 // status word behind the granules: 0 = every hand-off completed; otherwise the code of the hand-off that timed out
+static int g_band_debug_flags = 0;
+void chain_band_debug_flags(int flags) { g_band_debug_flags = flags; }
+
 int chain_band_launch(const ChainArgs &a, int n_chains, void *workspace, size_t workspace_bytes, int flags,
                       hipStream_t stream) {
+  flags |= g_band_debug_flags;
   BandPlan p;
   MVSN_REQUIRE(band_plan(a.rows, a.cols, &p), MVSN_E_TOOLARGE,
                "mvsn_incremental_cost_volume(banded): no plan for a %dx%d coarse grid", a.rows, a.cols);

@@ -85,6 +85,9 @@ __device__ __forceinline__ float dpp_mov(float v) {
 // LeakyReLU(0.2) as max(v, 0.2 v): two VALU instructions (multiply, max) instead of multiply / compare / select.
 // Identical for every finite v (0.2 v < v exactly when v > 0); -0.0 maps to -0.0 either way.
 __device__ __forceinline__ float lrelu02(float v) { return fmaxf(v, 0.2f * v); }
+// F.relu as ATen computes it: a NaN stays a NaN (fmaxf(NaN, 0) would return 0 and turn a poisoned volume -- see
+// chain_band_kernel's time-out path -- or a NaN input into a plausible-looking depth)
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.0f ? 0.0f : v; }
 
 // Workgroup b is observed to run on XCD b % 8, each XCD with its own L2.  Neighbouring tiles share halo
 // rows, so hand each XCD a contiguous range of tiles instead of every 8th one (bijective for any tile

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void idepth_gain_kernel(const float *__restric
   const float f = fx[blockIdx.y];
   const size_t i = (size_t)blockIdx.y * P + p;
   const float scaled = prior[i] * f;
-  if constexpr (EPI) out[i] = fmaxf(scaled + delta[i], 0.0f) / f;
+  if constexpr (EPI) out[i] = relu_nan(scaled + delta[i]) / f;
   else out[i] = scaled;
 }
 
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(256) void conv_to1_2d_mfma_kernel(const float *__re
       const float g = fx[n];
       const float2 pv = *reinterpret_cast<const float2 *>(prior + o);
       const float s0v = pv.x * g + res.x, s1v = pv.y * g + res.y;
-      res = make_float2((s0v > 0.0f ? s0v : 0.0f) / g, (s1v > 0.0f ? s1v : 0.0f) / g);
+      res = make_float2(relu_nan(s0v) / g, relu_nan(s1v) / g);
     }
     *reinterpret_cast<float2 *>(out + o) = res;
   }

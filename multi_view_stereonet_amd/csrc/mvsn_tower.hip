@@ -373,7 +373,7 @@ __global__ __launch_bounds__(TW_THREADS) void tower_kernel(TowerArgs a) {
       }
     const float fx = a.fx[n % a.fx_mod];
     const float pr = a.prior[(size_t)n * TW_P + tid];
-    a.out[(size_t)n * TW_P + tid] = fmaxf(pr * fx + acc, 0.0f) / fx;
+    a.out[(size_t)n * TW_P + tid] = relu_nan(pr * fx + acc) / fx;
   }
 }
 

@@ -1110,6 +1110,20 @@ class MultiViewStereoNet(nn.Module):
         """Drop the packed weight copies now (after replacing Parameter objects by hand)."""
         self._invalidate()
 
+    def check_device_status(self):
+        """Raise if the last forward's banded chain (one chain on several workgroups, small batches) reported a
+        hand-off that timed out -- its workgroups were not co-resident, i.e. the device was shared with other work.
+        Synchronises; the wrappers call it where they synchronise anyway (multi_view_forward's timer, evaluate's
+        final sync).  Independently of this check such a forward returns NaN depth maps (the kernel poisons its cost
+        slice), never plausible-looking wrong ones."""
+        eng = self._engine
+        status = eng.chain_status() if eng is not None else 0
+        if status:
+            raise RuntimeError(
+                "mvsn_incremental_cost_volume(banded): inter-workgroup hand-off %d timed out -- the chain's workgroups "
+                "were not co-resident (is the device shared with other work?).  The outputs of that forward are "
+                "NaN; set net.options.chain_form = 'winograd' (one workgroup per chain) to run without hand-offs." % status)
+
     def engine(self) -> PlaneSweepEngine:
         # The packed copies go stale when a parameter is rebound (.to(), load_state_dict: both invalidate above) or
         # updated in place (bumps its version counter).  Walking the module tree for 202 (data_ptr, version) pairs on

@@ -939,6 +939,59 @@ def test_banded_chain_hand_offs_under_uneven_load(grid, N, D):
         net.options.chain_form = "auto"
 
 
+@pytest.mark.parametrize("grid,N,D", [((16, 32), 2, 12), ((32, 64), 1, 8)])
+def test_banded_chain_missing_band_fails_loudly(grid, N, D):
+    """The banded chain needs its workgroups co-resident.  If one never runs (test hook: the last band of every chain
+    returns at once, what a device shared with other work can do), the others' waits are BOUNDED: the launch ends, the
+    status word names the hand-off, the cost slice carries NaN (so a forward's depth maps are NaN, not plausible-looking
+    wrong numbers), and MultiViewStereoNet.check_device_status raises.  The next launch is clean again."""
+    net = net_for("gta_sfm_150epochs")
+    eng = net.engine()
+    r4, c4 = grid
+    g = torch.Generator().manual_seed(19)
+    H, Hinc = _motion_family(N, D, "small", seed=2)
+    dev = [x.to(DEV) for x in (torch.rand(N, 3, r4, c4, generator=g) * 2 - 1, H, Hinc,
+                               torch.randn(N, 32, r4, c4, generator=g), torch.randn(N, 32, r4, c4, generator=g))]
+    net.options.chain_form = "banded"
+    try:
+        good, _, _ = eng.incremental_cost_volume(*dev)
+        torch.cuda.synchronize()
+        assert eng.chain_status() == 0 and bool(torch.isfinite(good).all())
+        eng.lib.mvsn_debug_set_band_flags(2 | (10 << 8))       # last band absent, 1024 polls per hand-off
+        try:
+            bad, _, _ = eng.incremental_cost_volume(*dev)
+            torch.cuda.synchronize()
+        finally:
+            eng.lib.mvsn_debug_set_band_flags(0)
+        assert eng.chain_status() != 0
+        assert bool(torch.isnan(bad).any()), "a timed-out chain must poison its cost slice"
+        with pytest.raises(RuntimeError, match="hand-off"):
+            net.check_device_status()
+        again, _, _ = eng.incremental_cost_volume(*dev)
+        torch.cuda.synchronize()
+        assert eng.chain_status() == 0 and torch.equal(again, good)
+        net.check_device_status()
+    finally:
+        net.options.chain_form = "auto"
+    if grid == (16, 32):       # ... and end to end: the forward's depth maps are NaN, the wrapper's check raises
+        fix = load_golden("g2_gta_512x256_d64_s2.npz")
+        net.options.plan_max_chains = 0
+        eng.lib.mvsn_debug_set_band_flags(2 | (10 << 8))
+        try:
+            out = _forward(net, fix)
+            torch.cuda.synchronize()
+        finally:
+            eng.lib.mvsn_debug_set_band_flags(0)
+            net.options.plan_max_chains = 16
+        assert net.engine().last_chain_form == _native.CHAIN_BANDED
+        assert not bool(torch.isfinite(out["left_idepthmap_pyr"][0]).all())
+        with pytest.raises(RuntimeError, match="hand-off"):
+            net.check_device_status()
+        out = _forward(net, fix)
+        assert bool(torch.isfinite(out["left_idepthmap_pyr"][0]).all())
+        net.check_device_status()
+
+
 def _forward(net, fix, smooth=False, **kw):
     batch, D = batch_from_meta(fix["meta"], fix.get("jitter", 0.0), smooth)
     inp = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
