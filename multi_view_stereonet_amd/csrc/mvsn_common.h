@@ -158,7 +158,8 @@ __device__ __forceinline__ Bilinear bilinear_taps(float ix, float iy, int rows, 
 // Every caller runs this very code with 256 threads, so a statistic is the same bit pattern wherever it is formed
 // (mvsn_groupnorm_finalize's own launch, or a consumer that was handed the records: `gn_stats_here`).
 constexpr float GN_FINALIZE_EPS = 1e-5f;
-// `only` >= 0 (workgroup-uniform): just that group's statistics are formed (same operations in the same order for it).
+// ONE: just group `only`'s statistics are formed (workgroup-uniform; same operations in the same order for it).
+template <bool ONE = false>
 __device__ __forceinline__ void gn_finalize_block(const float *__restrict__ records, int tiles, float *out8,
                                                   int only = -1) {
   const int tid = threadIdx.x;
@@ -170,7 +171,7 @@ __device__ __forceinline__ void gn_finalize_block(const float *__restrict__ reco
     const float e[12] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3]};
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      if (only >= 0 && g != only) continue;
+      if (ONE && g != only) continue;
       const double cnt = (double)e[g * 3], mean = (double)e[g * 3 + 1];
       acc[g][0] += cnt;
       acc[g][1] += cnt * mean;
@@ -194,7 +195,7 @@ __device__ __forceinline__ void gn_finalize_block(const float *__restrict__ reco
   __shared__ double gn_red[4][12];   // per wave
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    if (only >= 0 && g != only) continue;
+    if (ONE && g != only) continue;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       double v = acc[g][k];
@@ -210,7 +211,7 @@ __device__ __forceinline__ void gn_finalize_block(const float *__restrict__ reco
       for (int k = 0; k < 3; ++k) gn_red[tid >> 6][g * 3 + k] = acc[g][k];
   }
   __syncthreads();
-  if (tid < 4 && (only < 0 || tid == only)) {
+  if (tid < 4 && (!ONE || tid == only)) {
     const int g = tid;
     const double N = gn_red[0][g * 3] + gn_red[1][g * 3] + gn_red[2][g * 3] + gn_red[3][g * 3];
     const double S = gn_red[0][g * 3 + 1] + gn_red[1][g * 3 + 1] + gn_red[2][g * 3 + 1] + gn_red[3][g * 3 + 1];
@@ -227,10 +228,11 @@ __device__ __forceinline__ void gn_finalize_block(const float *__restrict__ reco
 // producer's records (N, tiles, 4, 3) -- then this workgroup (256 threads, all of them must call) forms them itself,
 // which saves the dependent mvsn_groupnorm_finalize launch in front of it (small batches: the launch costs more than
 // re-reading a few hundred records per workgroup).  Returns 8 floats [group][mean, rstd]; `lds8` is the caller's.
+template <bool ONE = false>
 __device__ __forceinline__ const float *gn_stats_here(const float *__restrict__ stats, int tiles, int n, float *lds8,
                                                       int only = -1) {
   if (tiles == 0) return stats + (size_t)n * 8;
-  gn_finalize_block(stats + (size_t)n * tiles * 12, tiles, lds8, only);
+  gn_finalize_block<ONE>(stats + (size_t)n * tiles * 12, tiles, lds8, only);
   __syncthreads();
   return lds8;
 }

@@ -874,7 +874,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
   const int plane = blockIdx.y;  // n*32 + c
   const int n = plane >> 5, c = plane & 31;
   __shared__ float gst[8];
-  const float *st = gn_stats_here(stats, stat_tiles, n, gst, c >> 3);   // (stat_tiles > 0: x's statistics from its records)
+  const float *st = gn_stats_here<true>(stats, stat_tiles, n, gst, c >> 3);   // (stat_tiles > 0: x's statistics from its records)
   const float mean = st[(c >> 3) * 2 + 0];
   const float rstd = st[(c >> 3) * 2 + 1];
   const float sc = rstd * gamma[c];
