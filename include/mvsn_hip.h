@@ -96,16 +96,17 @@ int mvsn_homography_warp(const float *image, const float *H, int batch, int chan
 #define MVSN_CHAIN_WINOGRAD 2
 #define MVSN_CHAIN_STEPWISE 3 /* one plane per round of full-chip launches (warp, three Winograd convolutions with the
                                  GroupNorm statistics of the producing launch, the residual pass, the cost slice):
-                                 for coarse grids whose planes do not fit one CU (30x40, 32x64) while fewer chains
-                                 than CUs are in flight -- there the one-workgroup-per-chain forms leave the chip idle */
+                                 for coarse grids whose planes do not fit one CU (30x40, 32x64), any number of chains
+                                 (cols % 4 == 0); AUTO's choice there once the banded form would need three passes */
 #define MVSN_CHAIN_BANDED 4   /* one chain on SEVERAL workgroups: the coarse plane cut into bands of pixel rows (16x32: 4
                                  bands of 4 rows; 30x40: 15 of 2; 32x64: 16 of 2), Winograd arithmetic of
                                  MVSN_CHAIN_WINOGRAD; per step the bands hand each other the new feature rows their
                                  gathers reach into, their GroupNorm sums and one halo row per layer as tagged 8-byte
                                  write-through granules -- no fence, no placement assumption.  For few chains in flight
-                                 (batch 1: the reference's loop, test.py:38,197-200): bands x n_chains must not exceed the
-                                 device's CUs (all workgroups co-resident), and only ONE such launch may be in flight per
-                                 device.  Needs workspace (..._workspace_bytes_for); the word at
+                                 (batch 1: the reference's loop, test.py:38,197-200): the workgroups of a launch must be
+                                 co-resident, so more chains than CUs / bands run as consecutive passes inside the call
+                                 (AUTO: one pass on 16x32, up to two on 30x40 / 32x64), and only ONE such call may be in
+                                 flight per device.  Needs workspace (..._workspace_bytes_for); the word at
                                  mvsn_incremental_cost_volume_status_offset() inside it is 0 after a clean run. */
 size_t mvsn_feature_refiner_packed_floats(void);
 /* Pack the ten FeatureRefiner tensors (state_dict order: conv0.{weight,bias}, bn0.{weight,bias},

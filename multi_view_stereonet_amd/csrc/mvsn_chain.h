@@ -34,6 +34,8 @@ struct ChainArgs {
   float *fvol;           // (N,32,D,P) or null
   float *workspace;      // global activation planes or null
   int B, D, rows, cols, CS;
+  int chain0;            // banded form, launched in passes: global index of this pass's first chain (0 otherwise)
+  int ws_chains;         // ... and the number of chains its workspace holds (the status word sits behind them)
   unsigned long long *dbg;  // optional: s_memtime stamps of block 0 / lane 0 at phase boundaries (tuning only)
 };
 
@@ -49,6 +51,7 @@ int chain_steps_launch(const ChainArgs &a, int n_chains, void *workspace, size_t
 // Banded form (mvsn_chain_band.hip): one chain on several workgroups; coarse grids 16x32, 30x40, 32x64
 bool chain_band_supported(int rows, int cols);
 int chain_band_groups(int rows, int cols);                 // workgroups per chain (0: no plan for this grid)
+int chain_band_chains_per_pass(int rows, int cols);        // chains whose workgroups are co-resident (one per CU)
 size_t chain_band_workspace_bytes(int n_chains, int rows, int cols);
 size_t chain_band_status_offset(int n_chains, int rows, int cols);
 void chain_band_debug_flags(int flags);   // test hook, see mvsn_debug_set_band_flags

@@ -584,12 +584,19 @@ extern "C" size_t mvsn_incremental_cost_volume_workspace_bytes(int n_chains, int
 
 // What MVSN_CHAIN_AUTO resolves to for this many chains on this coarse grid.
 static int chain_auto_form(int n_chains, int rows, int cols) {
-  // few chains on a grid with a banded plan: several workgroups per chain while they all fit the chip at once
-  if (mvsn::chain_band_supported(rows, cols) && n_chains * mvsn::chain_band_groups(rows, cols) <= mvsn::device_cus())
-    return MVSN_CHAIN_BANDED;
+  // few chains on a grid with a banded plan: several workgroups per chain.  Where a plane-resident plan exists
+  // (16x32) only while all of them fit the chip at once; on the 30x40 / 32x64 grids also as two consecutive passes
+  // (measured, MI355X: 32 chains 5.1 / 7.1 ms against the stepwise form's 7.3 / 10.4 ms; three passes tie with it)
+  if (mvsn::chain_band_supported(rows, cols)) {
+    const int cap = mvsn::chain_band_chains_per_pass(rows, cols);
+    const int passes = cap > 0 ? (n_chains + cap - 1) / cap : 1 << 20;
+    if (passes <= (mvsn::chain_wino_supported(rows, cols) ? 1 : 2)) return MVSN_CHAIN_BANDED;
+  }
   if (mvsn::chain_wino_supported(rows, cols)) return MVSN_CHAIN_WINOGRAD;
-  // no plane-resident plan: one workgroup per chain leaves the chip idle below ~one chain per CU
-  if (mvsn::chain_steps_supported(rows, cols) && n_chains < mvsn::device_cus()) return MVSN_CHAIN_STEPWISE;
+  // no plane-resident plan: one plane per round of full-chip launches, whatever the number of chains (re-measured in
+  // round 3 with tools/chain_bench.py: 30x40, 256 / 512 chains 25.4 / 48.0 ms against the direct form's 41.5 / 86.8;
+  // the direct form -- one workgroup per chain, planes in a global workspace -- remains for cols % 4 != 0)
+  if (mvsn::chain_steps_supported(rows, cols)) return MVSN_CHAIN_STEPWISE;
   return MVSN_CHAIN_DIRECT;
 }
 
@@ -650,6 +657,8 @@ extern "C" int mvsn_incremental_cost_volume(const float *src_image_lvl4, const f
   MVSN_REQUIRE(wino || form == MVSN_CHAIN_STEPWISE || form == MVSN_CHAIN_BANDED || TP <= 8, MVSN_E_TOOLARGE,
                "mvsn_incremental_cost_volume: %dx%d coarse grid (%d px) exceeds the 2048 px plan", rows, cols, P);
   ChainArgs a;
+  a.chain0 = 0;
+  a.ws_chains = 0;
   a.src = src_image_lvl4;
   a.H = H_lvl4;
   a.Hinc = H_inc;

@@ -249,7 +249,8 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
   constexpr int CSA = GEO::CSA, CSW = GEO::CSW, HI = GEO::HITEMS;
   const int tid0 = threadIdx.x, lane = tid0 & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-  const int n = blockIdx.x / G, m = blockIdx.x % G;
+  const int nl = blockIdx.x / G, m = blockIdx.x % G;   // chain within this pass (workspace), band
+  const int n = a.chain0 + nl;                        // chain of the call (data)
   const int pt = wave >> 1, ct = wave & 1;
   const int lo = m * BR, hi = lo + BR - 1, wlo = lo - W;
   const int D = a.D;
@@ -270,9 +271,9 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
   float *act = tabw + GEO::TABW + GEO::TABI;
   float *win = act + 36 * CSA;
 
-  gu64 *ws = (gu64 *)(reinterpret_cast<u64 *>(a.workspace) + (size_t)n * GEO::CHAIN_U64);
+  gu64 *ws = (gu64 *)(reinterpret_cast<u64 *>(a.workspace) + (size_t)nl * GEO::CHAIN_U64);
   gu64 *Fg = ws + GEO::FG, *Rg = ws + GEO::RG, *Sg = ws + GEO::SG;
-  gu32 *status = (gu32 *)(reinterpret_cast<u64 *>(a.workspace) + (size_t)(gridDim.x / G) * GEO::CHAIN_U64);
+  gu32 *status = (gu32 *)(reinterpret_cast<u64 *>(a.workspace) + (size_t)a.ws_chains * GEO::CHAIN_U64);
   bool dead = false;
 
   const float *upk = a.packed + CH_DIRECT_FLOATS;
@@ -875,20 +876,33 @@ int chain_band_groups(int rows, int cols) {
   return band_plan(rows, cols, &p) ? p.G : 0;
 }
 
+// chains per pass: every workgroup of a pass must be co-resident (one per CU)
+int chain_band_chains_per_pass(int rows, int cols) {
+  BandPlan p;
+  return band_plan(rows, cols, &p) ? device_cus() / p.G : 0;
+}
+
+static int band_ws_chains(const BandPlan &p, int n_chains) {
+  const int cap = device_cus() / p.G;
+  return n_chains < cap ? n_chains : cap;
+}
+
 size_t chain_band_workspace_bytes(int n_chains, int rows, int cols) {
   BandPlan p;
-  return band_plan(rows, cols, &p) ? ((size_t)n_chains * p.chain_u64 + 8) * sizeof(u64) : 0;
+  return band_plan(rows, cols, &p) ? ((size_t)band_ws_chains(p, n_chains) * p.chain_u64 + 8) * sizeof(u64) : 0;
 }
 
 size_t chain_band_status_offset(int n_chains, int rows, int cols) {
   BandPlan p;
-  return band_plan(rows, cols, &p) ? (size_t)n_chains * p.chain_u64 * sizeof(u64) : 0;
+  return band_plan(rows, cols, &p) ? (size_t)band_ws_chains(p, n_chains) * p.chain_u64 * sizeof(u64) : 0;
 }
 
-// status word behind the granules: 0 = every hand-off completed; otherwise the code of the hand-off that timed out
 static int g_band_debug_flags = 0;
 void chain_band_debug_flags(int flags) { g_band_debug_flags = flags; }
 
+// status word behind the granules: 0 = every hand-off completed; otherwise the code of the hand-off that timed out.
+// More chains than fit the chip at one workgroup per band run as consecutive passes over the same workspace (the
+// chains are independent; within a pass every workgroup is co-resident).
 int chain_band_launch(const ChainArgs &a, int n_chains, void *workspace, size_t workspace_bytes, int flags,
                       hipStream_t stream) {
   flags |= g_band_debug_flags;
@@ -898,21 +912,29 @@ int chain_band_launch(const ChainArgs &a, int n_chains, void *workspace, size_t 
   const size_t need = chain_band_workspace_bytes(n_chains, a.rows, a.cols);
   MVSN_REQUIRE(workspace && workspace_bytes >= need, MVSN_E_WORKSPACE,
                "mvsn_incremental_cost_volume(banded): workspace of %zu bytes required", need);
-  MVSN_REQUIRE(n_chains * p.G <= device_cus(), MVSN_E_TOOLARGE,
-               "mvsn_incremental_cost_volume(banded): %d chains x %d bands exceed the %d CUs that must be co-resident",
-               n_chains, p.G, device_cus());
-  // every polled word starts from tag 0 (no step carries it): a memset node ahead of the launch, replayed with it
-  hipError_t e = hipMemsetAsync(workspace, 0, need, stream);
+  const int cap = device_cus() / p.G, wsn = band_ws_chains(p, n_chains);
+  MVSN_REQUIRE(cap >= 1, MVSN_E_TOOLARGE, "mvsn_incremental_cost_volume(banded): %d bands exceed the %d CUs", p.G,
+               device_cus());
+  static LdsOptIn opt[3];
+  LdsOptIn &o = opt[a.rows == 16 ? 0 : (a.rows == 30 ? 1 : 2)];
+  if (int rc = ensure_lds(o, (const void *)p.kernel, p.lds_bytes, "mvsn_incremental_cost_volume(banded)")) return rc;
+  const size_t status_off = (size_t)wsn * p.chain_u64 * sizeof(u64);
+  hipError_t e = hipMemsetAsync((char *)workspace + status_off, 0, 8 * sizeof(u64), stream);
+  for (int n0 = 0; n0 < n_chains && e == hipSuccess; n0 += cap) {
+    const int nn = n_chains - n0 < cap ? n_chains - n0 : cap;
+    // every polled word starts from tag 0 (no step carries it): a memset node ahead of each pass, replayed with it
+    e = hipMemsetAsync(workspace, 0, (size_t)nn * p.chain_u64 * sizeof(u64), stream);
+    if (e != hipSuccess) break;
+    ChainArgs b = a;
+    b.workspace = (float *)workspace;
+    b.chain0 = n0;
+    b.ws_chains = wsn;
+    hipLaunchKernelGGL(p.kernel, dim3(nn * p.G), dim3(CB_THREADS), p.lds_bytes, stream, b, flags);
+  }
   if (e != hipSuccess) {
     set_error("mvsn_incremental_cost_volume(banded): memset failed: %s", hipGetErrorString(e));
     return (int)e;
   }
-  ChainArgs b = a;
-  b.workspace = (float *)workspace;
-  static LdsOptIn opt[3];
-  LdsOptIn &o = opt[a.rows == 16 ? 0 : (a.rows == 30 ? 1 : 2)];
-  if (int rc = ensure_lds(o, (const void *)p.kernel, p.lds_bytes, "mvsn_incremental_cost_volume(banded)")) return rc;
-  hipLaunchKernelGGL(p.kernel, dim3(n_chains * p.G), dim3(CB_THREADS), p.lds_bytes, stream, b, flags);
   return check_launch("mvsn_incremental_cost_volume(banded)");
 }
 

@@ -112,11 +112,11 @@ class EngineOptions:
         self.lazy_stats_max_samples = 8
         self.lazy_stats_max_records = 2048
         self.cat_free_heads = True         # refiner heads read [image, features, idepth] in place (no torch.cat)
-        # The fused chain's three 3x3 convolutions: "auto" = Winograd F(2x2,3x3) where the coarse grid has a plan
-        # (16x32 at 512x256 frames); elsewhere one plane per round of full-chip launches ("stepwise") while fewer
-        # chains than CUs are in flight, the fused direct implicit GEMM otherwise; on the 16x32 grid with at most 64
-        # chains (4 workgroups each: all co-resident on the 256 CUs) one chain runs on FOUR workgroups ("banded").  "direct" / "winograd" /
-        # "stepwise" / "banded" force one form.
+        # The fused chain's three 3x3 convolutions: "auto" = one chain on SEVERAL workgroups ("banded") while few chains
+        # are in flight (16x32: up to 64 chains, one pass; 30x40 / 32x64: up to two passes of 17 / 16 chains); otherwise
+        # Winograd F(2x2,3x3) with the plane resident in one CU where the coarse grid has such a plan (16x32 at 512x256
+        # frames), elsewhere one plane per round of full-chip launches ("stepwise"; cols % 4 == 0) or the fused direct
+        # implicit GEMM.  "direct" / "winograd" / "stepwise" / "banded" force one form.
         self.chain_form = "auto"
         # Refiner towers on two batch slices, software-pipelined: slice B's convolution (matrix-pipe-bound) carries
         # slice A's normalise/activate/add pass (HBM-bound) inside its own launch (mvsn_conv_forward_carry).  Used
@@ -904,7 +904,8 @@ class PlaneSweepEngine:
         if form == _native.CHAIN_AUTO:
             form = self.lib.mvsn_incremental_cost_volume_form_for(N, rows, cols)
             if form == _native.CHAIN_BANDED and not self.banded_ok:
-                form = self.lib.mvsn_incremental_cost_volume_form(rows, cols)   # lanes on several streams: see forward
+                # lanes on several streams (see forward): what AUTO picks once the banded form is out of reach
+                form = self.lib.mvsn_incremental_cost_volume_form_for(1 << 20, rows, cols)
         if form == _native.CHAIN_WINOGRAD and self.lib.mvsn_incremental_cost_volume_form(rows, cols) != form:
             form = _native.CHAIN_DIRECT        # no Winograd plan for this coarse grid
         if form == _native.CHAIN_STEPWISE and cols % 4 != 0:

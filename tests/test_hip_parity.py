@@ -907,6 +907,51 @@ def test_chain_groupnorm_single_pass_stays_accurate(case, D, form):
     assert vs_spread < 1e-3, (case, D, form, vs_spread)
 
 
+@pytest.mark.parametrize("grid,N,D", [((30, 40), 20, 5), ((32, 64), 19, 5), ((16, 32), 70, 4)])
+def test_banded_chain_in_passes(grid, N, D):
+    """More chains than fit the chip at one workgroup per band: the banded call runs consecutive passes over one
+    workspace (17 / 16 / 64 chains per pass on an MI355X).  Every chain must come out exactly as when it runs in a call
+    of its own (chains are independent: `torch.equal`), agree with another form of the library, and leave status 0;
+    AUTO picks the banded form for up to two passes where no plane-resident plan exists."""
+    net = net_for("gta_sfm_150epochs")
+    eng = net.engine()
+    r4, c4 = grid
+    B = 5                               # left features are shared: chain n reads batch item n % B
+    g = torch.Generator().manual_seed(23)
+    H, Hinc = _motion_family(N, D, "mixed", seed=6)
+    src4 = torch.rand(N, 3, r4, c4, generator=g) * 2 - 1
+    F0, FL = torch.randn(N, 32, r4, c4, generator=g), torch.randn(B, 32, r4, c4, generator=g)
+    dev = [x.to(DEV) for x in (src4, H, Hinc, F0, FL)]
+    cap = 256 // {16: 4, 30: 15, 32: 16}[r4]
+    assert N > cap
+    lib = eng.lib
+    want = _native.CHAIN_BANDED if r4 != 16 else _native.CHAIN_WINOGRAD
+    assert lib.mvsn_incremental_cost_volume_form_for(N, r4, c4) == want
+    assert lib.mvsn_incremental_cost_volume_form_for(cap, r4, c4) == _native.CHAIN_BANDED
+    assert lib.mvsn_incremental_cost_volume_form_for(2 * cap + 1, r4, c4) == (
+        _native.CHAIN_STEPWISE if r4 != 16 else _native.CHAIN_WINOGRAD)
+    net.options.chain_form = "banded"
+    try:
+        cost, mask, fvol = eng.incremental_cost_volume(*dev, want_features=True)
+        torch.cuda.synchronize()
+        assert eng.chain_status() == 0
+        # the second pass's chains on their own: batch index n % B must follow the chain's GLOBAL index
+        tail = list(range(cap, N))
+        idx = torch.tensor([n % B for n in tail])
+        c2, m2, f2 = eng.incremental_cost_volume(dev[0][cap:], dev[1][cap:], dev[2][cap:], dev[3][cap:],
+                                                 FL[idx].to(DEV), want_features=True)
+        assert eng.chain_status() == 0
+        assert torch.equal(cost[cap:], c2) and torch.equal(mask[cap:], m2) and torch.equal(fvol[cap:], f2)
+        net.options.chain_form = "winograd" if r4 == 16 else "stepwise"
+        c3, m3, f3 = eng.incremental_cost_volume(*dev, want_features=True)
+        assert torch.equal(mask, m3)
+        for name, a, b in (("features", fvol, f3), ("cost", cost, c3)):
+            mean_rel, max_rel = rel_err(a.cpu(), b.cpu())
+            assert mean_rel < 1e-5 and max_rel < 2e-4, (name, mean_rel, max_rel)
+    finally:
+        net.options.chain_form = "auto"
+
+
 @pytest.mark.parametrize("grid,N,D", [((16, 32), 5, 64), ((30, 40), 3, 24), ((32, 64), 4, 20)])
 def test_banded_chain_hand_offs_under_uneven_load(grid, N, D):
     """The inter-workgroup hand-offs (tagged granules) must not depend on timing or placement: the same launch

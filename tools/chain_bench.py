@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Time the fused chain alone (mvsn_incremental_cost_volume) in its forms: ms per launch, us per step,
-algorithmic TFLOP/s and GB/s.   python tools/chain_bench.py [N ...]   (N = chains per launch; default 2 and 256)"""
+algorithmic TFLOP/s and GB/s.   python tools/chain_bench.py [N ...]   (N = chains per launch; default 2 and 256)
+MVSN_GRID=rows,cols,D selects another coarse grid (default 16,32,64)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multi_view_stereonet_amd import MultiViewStereoNet
@@ -8,7 +9,7 @@ from multi_view_stereonet_amd.weights import load_weights
 torch.set_grad_enabled(False)
 net = MultiViewStereoNet(); net.load_state_dict(load_weights("gta_sfm_150epochs")); net = net.cuda().eval()
 eng = net.engine()
-rows, cols, D = 16, 32, 64
+rows, cols, D = [int(v) for v in os.environ.get("MVSN_GRID", "16,32,64").split(",")]
 P = rows * cols
 g = torch.Generator().manual_seed(0)
 for N in [int(a) for a in sys.argv[1:]] or [2, 256]:
@@ -19,15 +20,17 @@ for N in [int(a) for a in sys.argv[1:]] or [2, 256]:
     Hinc = torch.eye(3).repeat(N, D, 1, 1); Hinc[:, 1:, 0, 2] = 12.0 / (D - 1)
     F0 = torch.randn(N, 32, rows, cols, generator=g).cuda(); FL = torch.randn(B, 32, rows, cols, generator=g).cuda()
     H, Hinc = H.cuda(), Hinc.cuda()
-    for form in ("direct", "winograd", "banded"):
-        if form == "banded" and N * 4 > 256:
+    for form in ("direct", "winograd", "stepwise", "banded"):
+        if form == "winograd" and (rows, cols) != (16, 32):
+            continue
+        if form == "stepwise" and (rows, cols) == (16, 32):
             continue
         net.options.chain_form = form
         for _ in range(3):
             eng.incremental_cost_volume(src4, H, Hinc, F0, FL)
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 20
+        reps = 5 if N >= 32 else 20
         a.record()
         for _ in range(reps):
             eng.incremental_cost_volume(src4, H, Hinc, F0, FL)
