@@ -39,6 +39,12 @@ struct ChainArgs {
   unsigned long long *dbg;  // optional: s_memtime stamps of block 0 / lane 0 at phase boundaries (tuning only)
 };
 
+// the chain's buffers as plain pointer arguments behind the struct (MVSN_VIS10, mvsn_common.h)
+#define CHAIN_VISIBLE(a)                                                                                              \
+  (const void *)(a).src, (const void *)(a).H, (const void *)(a).Hinc, (const void *)(a).f0, (const void *)(a).fl,     \
+      (const void *)(a).packed, (const void *)(a).cost, (const void *)(a).mask, (const void *)(a).fvol,               \
+      (const void *)(a).workspace
+
 // Winograd form: does this coarse grid have a plan (even rows / cols, <= 128 patches, LDS fits)?
 bool chain_wino_supported(int rows, int cols);
 int chain_wino_launch(const ChainArgs &a, int n_chains, hipStream_t stream);

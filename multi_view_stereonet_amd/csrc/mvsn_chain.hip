@@ -270,7 +270,7 @@ __device__ __forceinline__ void store_weights_to_lds(float *wbuf, const floatx4 
 }
 
 template <int TP, bool LDS_ACT>
-__global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a) {
+__global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a, MVSN_VIS10) {   // (MVSN_VIS10: mvsn_common.h)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = blockIdx.x;
@@ -702,7 +702,7 @@ extern "C" int mvsn_incremental_cost_volume(const float *src_image_lvl4, const f
     auto kern = chain_kernel<TPV, LDSV>;                                                                       \
     static LdsOptIn opt;                                                                                       \
     if (int rc = ensure_lds(opt, (const void *)kern, lds, "mvsn_incremental_cost_volume")) return rc;          \
-    hipLaunchKernelGGL(kern, dim3(n_chains), dim3(CH_THREADS), lds, (hipStream_t)stream, a);                   \
+    hipLaunchKernelGGL(kern, dim3(n_chains), dim3(CH_THREADS), lds, (hipStream_t)stream, a, CHAIN_VISIBLE(a));    \
   } while (0)
 
   MVSN_REQUIRE(!lds_act || TP <= 3, MVSN_E_TOOLARGE, "mvsn_incremental_cost_volume: internal plan error");

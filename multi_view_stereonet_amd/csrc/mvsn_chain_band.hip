@@ -28,7 +28,7 @@
 // `global_store_dwordx4 sc1`) and read by agent-scope relaxed loads (`sc1`: served past the reader's L1) that are
 // repeated until the tag matches.  The data is its own flag: no release fence (the 14 us per launch HISTORY 3.6
 // measured for buffer_wbl2), no acquire, no dependence on which XCD a workgroup landed on.  The granule region is
-// zeroed by a memset node ahead of every launch; tags count steps within the call (F_d carries d + 1, the conv
+// zeroed by a fill kernel ahead of every pass; tags count steps within the call (F_d carries d + 1, the conv
 // hand-offs of step d carry d), so a granule is either stale (tag - 1: keep polling) or current.  A buffer can be
 // single: a band cannot publish step d + 1's version of a hand-off before every reader has consumed step d's, because
 // the GroupNorm sums of the hand-off in between need all bands (the ordering argument is spelled out in DESIGN.md 3.1).
@@ -243,7 +243,7 @@ __device__ __forceinline__ void cb_wave_minmax(int &lo, int &hi) {
 }
 
 template <class GEO>
-__global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int flags) {
+__global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int flags, MVSN_VIS10) {   // (mvsn_common.h)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int rows = GEO::rows, cols = GEO::cols, P = GEO::P, RS = GEO::RS, BR = GEO::BR, G = GEO::G, W = GEO::W;
   constexpr int CSA = GEO::CSA, CSW = GEO::CSW, HI = GEO::HITEMS;
@@ -846,11 +846,19 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
   if (__syncthreads_or(dead) && pvalid) costg[(size_t)(D - 1) * P + slice_off] = __builtin_nanf("");
 }
 
+// Zero fill of the hand-off workspace (granules + status word) as a plain kernel: inside a captured graph a
+// hipMemsetAsync node of a few bytes at an offset pointer was observed to leave pointer-like garbage behind on replay
+// (ROCm 7.2: the status word read 0x7890... after every graph launch, never after a stream launch); a kernel node has no
+// such surprises and costs the same launch.
+__global__ __launch_bounds__(256) void band_zero_kernel(u64 *__restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0;
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------
 struct BandPlan {
   int G;
   size_t chain_u64, lds_bytes;
-  void (*kernel)(ChainArgs, int);
+  void (*kernel)(ChainArgs, int, MVSN_VIS10);
 };
 
 template <class GEO>
@@ -918,22 +926,24 @@ int chain_band_launch(const ChainArgs &a, int n_chains, void *workspace, size_t 
   static LdsOptIn opt[3];
   LdsOptIn &o = opt[a.rows == 16 ? 0 : (a.rows == 30 ? 1 : 2)];
   if (int rc = ensure_lds(o, (const void *)p.kernel, p.lds_bytes, "mvsn_incremental_cost_volume(banded)")) return rc;
-  const size_t status_off = (size_t)wsn * p.chain_u64 * sizeof(u64);
-  hipError_t e = hipMemsetAsync((char *)workspace + status_off, 0, 8 * sizeof(u64), stream);
-  for (int n0 = 0; n0 < n_chains && e == hipSuccess; n0 += cap) {
+  for (int n0 = 0; n0 < n_chains; n0 += cap) {
     const int nn = n_chains - n0 < cap ? n_chains - n0 : cap;
-    // every polled word starts from tag 0 (no step carries it): a memset node ahead of each pass, replayed with it
-    e = hipMemsetAsync(workspace, 0, (size_t)nn * p.chain_u64 * sizeof(u64), stream);
-    if (e != hipSuccess) break;
+    // every polled word starts from tag 0 (no step carries it): zeroed ahead of each pass -- with the first pass (which
+    // fills the workspace: nn == wsn) also the status block behind the granules, so that a later pass keeps what an
+    // earlier one reported
+    const size_t words = (size_t)nn * p.chain_u64 + (n0 == 0 ? 8 : 0);
+    const unsigned blocks = (unsigned)((words + 1023) / 1024 < 1024 ? (words + 1023) / 1024 : 1024);
+    hipLaunchKernelGGL(band_zero_kernel, dim3(blocks), dim3(256), 0, stream, (u64 *)workspace, words);
     ChainArgs b = a;
     b.workspace = (float *)workspace;
     b.chain0 = n0;
     b.ws_chains = wsn;
-    hipLaunchKernelGGL(p.kernel, dim3(nn * p.G), dim3(CB_THREADS), p.lds_bytes, stream, b, flags);
-  }
-  if (e != hipSuccess) {
-    set_error("mvsn_incremental_cost_volume(banded): memset failed: %s", hipGetErrorString(e));
-    return (int)e;
+#ifdef MVSN_BAND_HIDE_PTRS   // A/B aid (see MVSN_VIS10): the buffers reach the kernel through the by-value struct only
+    const ChainArgs hidden{};
+    hipLaunchKernelGGL(p.kernel, dim3(nn * p.G), dim3(CB_THREADS), p.lds_bytes, stream, b, flags, CHAIN_VISIBLE(hidden));
+#else
+    hipLaunchKernelGGL(p.kernel, dim3(nn * p.G), dim3(CB_THREADS), p.lds_bytes, stream, b, flags, CHAIN_VISIBLE(b));
+#endif
   }
   return check_launch("mvsn_incremental_cost_volume(banded)");
 }

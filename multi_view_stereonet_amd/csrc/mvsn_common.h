@@ -150,6 +150,18 @@ __device__ __forceinline__ Bilinear bilinear_taps(float ix, float iy, int rows, 
 }
 
 
+// ---- "visible" buffer arguments ------------------------------------------------------------------------------------
+// A kernel that reaches a buffer only through a by-value argument STRUCT (ChainArgs, TowerArgs, WinoArgs::in1 ...)
+// repeats the buffer as a plain pointer argument at the end of its signature.  The kernel never reads these
+// arguments; the runtime does: a captured hipGraph decides the cache maintenance between two kernel nodes from the
+// buffers it finds among their pointer arguments, and a pointer inside a struct is invisible to it.  Measured on
+// MI355X / ROCm 7.2 (tools/soak.py, alternating inputs over graph replays of the batch-1 forward): with the banded
+// chain's buffers only inside ChainArgs ~0.3 % of the replayed forwards came out wrong by 1e-3..4e-3 (a consumer on
+// another XCD read the previous replay's lines from its L2); with the pointers repeated as arguments 0 of 6000.
+// Stream launches were never affected (every dispatch there carries agent-scope acquire / release fences).
+#define MVSN_VIS10 const void *, const void *, const void *, const void *, const void *, const void *, const void *, \
+                   const void *, const void *, const void *
+
 // ---- GroupNorm statistics of ONE sample from the producing convolution's records -------------------------------------
 // Combination of the per-record (count, mean, M2) in double by a 256-thread workgroup; a thread reads whole 48-byte
 // records (all four groups), one pass:  N = sum c,  S = sum c*mean,  Q = sum (M2 + c*mean^2)  ->  var = Q/N - (S/N)^2

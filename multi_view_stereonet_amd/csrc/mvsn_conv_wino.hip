@@ -189,7 +189,8 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
                                                                   const float *__restrict__ in_gamma,
                                                                   const float *__restrict__ in_beta,
                                                                   float *__restrict__ out,
-                                                                  float *__restrict__ out_partials, RideArgs rd) {
+                                                                  float *__restrict__ out_partials, RideArgs rd,
+                                                                  MVSN_VIS10) {   // (MVSN_VIS10: mvsn_common.h)
   extern __shared__ __attribute__((aligned(16))) float smem[];
 #ifdef MVSN_WN_FORCE_DMA   // tuning aid: 0 builtin everywhere, 1 inline assembly everywhere
   constexpr bool ASM_DMA = MVSN_WN_FORCE_DMA;
@@ -944,7 +945,9 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
       return rc;                                                                                                   \
     hipLaunchKernelGGL((conv_wino_kernel<M, K, N, D, ##__VA_ARGS__>), grid, dim3(WN_THREADS), lds, stream, a, in,  \
                        upk, bias,                                                                                  \
-                       in_stats, in_gamma, in_beta, out, out_partials, rd);                                        \
+                       in_stats, in_gamma, in_beta, out, out_partials, rd, (const void *)a.in1, (const void *)a.in2, \
+                       (const void *)rd.x, (const void *)rd.stats, (const void *)rd.res, (const void *)rd.r_stats,  \
+                       (const void *)rd.out, (const void *)nullptr, (const void *)nullptr, (const void *)nullptr);  \
   } while (0)
   const long total = (long)g.n * g.D * g.tiles;
   grid = dim3((unsigned)(total < cus ? total : cus));   // persistent: one workgroup per CU walks items grid-strided

@@ -274,7 +274,7 @@ namespace mvsn {
 struct FocalSrc {
   const float *K[8];
 };
-__global__ void gather_focal_kernel(FocalSrc src, int levels, int batch, float *__restrict__ out) {
+__global__ void gather_focal_kernel(FocalSrc src, int levels, int batch, float *__restrict__ out, MVSN_VIS10) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < levels * batch) out[i] = src.K[i / batch][(size_t)(i % batch) * 16];
 }
@@ -289,7 +289,9 @@ extern "C" int mvsn_gather_focal(const float *const *K_pyr, int levels, int batc
   }
   const int total = levels * batch;
   hipLaunchKernelGGL(mvsn::gather_focal_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, levels,
-                     batch, fx);
+                     batch, fx, (const void *)src.K[0], (const void *)src.K[1], (const void *)src.K[2],
+                     (const void *)src.K[3], (const void *)src.K[4], (const void *)src.K[5], (const void *)src.K[6],
+                     (const void *)src.K[7], (const void *)nullptr, (const void *)nullptr);   // MVSN_VIS10
   return mvsn::check_launch("mvsn_gather_focal");
 }
 

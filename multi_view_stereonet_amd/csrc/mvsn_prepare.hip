@@ -19,7 +19,7 @@ struct PyramidOut {
 // One 32x32 tile of level 0 per workgroup (16x16 threads, a 2x2 block each); level l+1 is formed from level l's
 // ROUNDED values (the reference calls interpolate once per level), summed in row-major order like the pooling loop.
 __global__ __launch_bounds__(256) void image_pyramid_kernel(const float *__restrict__ in, int rows, int cols, int levels,
-                                                            PyramidOut out) {
+                                                            PyramidOut out, MVSN_VIS10) {   // (MVSN_VIS10: mvsn_common.h)
   __shared__ float buf[2][16][16];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const size_t plane = blockIdx.z;
@@ -135,7 +135,10 @@ extern "C" int mvsn_image_pyramid(const float *in, int n, int channels, int rows
   }
   dim3 grid((cols + 31) / 32, (rows + 31) / 32, n * channels);
   MVSN_REQUIRE(grid.y <= 65535, MVSN_E_TOOLARGE, "mvsn_image_pyramid: grid");
-  hipLaunchKernelGGL(mvsn::image_pyramid_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, rows, cols, levels, o);
+  hipLaunchKernelGGL(mvsn::image_pyramid_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, rows, cols, levels, o,
+                     (const void *)o.level[0], (const void *)o.level[1], (const void *)o.level[2], (const void *)o.level[3],
+                     (const void *)o.level[4], (const void *)o.level[5], (const void *)nullptr, (const void *)nullptr,
+                     (const void *)nullptr, (const void *)nullptr);
   return mvsn::check_launch("mvsn_image_pyramid");
 }
 

@@ -52,7 +52,7 @@ struct SetupSrc {
 __global__ __launch_bounds__(SETUP_THREADS) void plane_sweep_setup_kernel(
     SetupSrc src, const float *__restrict__ K0_in, const float *__restrict__ K4_in, int rows4,
     int cols4, int D, float *__restrict__ samples_out, float *__restrict__ H4_out, float *__restrict__ Hinc_out,
-    float *__restrict__ H0_out, float *__restrict__ baseline_out) {
+    float *__restrict__ H0_out, float *__restrict__ baseline_out, MVSN_VIS10) {   // (MVSN_VIS10: mvsn_common.h)
   const int n = blockIdx.x;
   const int tid = threadIdx.x;
   const int kb = src.per_source ? n % src.B : n;
@@ -178,7 +178,9 @@ extern "C" int mvsn_plane_sweep_setup(const float *T_right_in_left, const float 
   src.T[0] = T_right_in_left;
   hipLaunchKernelGGL(mvsn::plane_sweep_setup_kernel, dim3(n_chains), dim3(mvsn::SETUP_THREADS), 0,
                      (hipStream_t)stream, src, K_lvl0, K_lvl4, rows4, cols4, num_idepth_samples,
-                     idepth_samples, H_lvl4, H_inc, H_lvl0_plane0, baseline);
+                     idepth_samples, H_lvl4, H_inc, H_lvl0_plane0, baseline, (const void *)src.T[0], (const void *)src.T[1],
+                     (const void *)src.T[2], (const void *)src.T[3], (const void *)src.T[4], (const void *)src.T[5],
+                     (const void *)src.T[6], (const void *)src.T[7], (const void *)nullptr, (const void *)nullptr);
   return mvsn::check_launch("mvsn_plane_sweep_setup");
 }
 
@@ -198,6 +200,8 @@ extern "C" int mvsn_plane_sweep_setup_sources(const float *const *T_right_in_lef
   src.B = batch, src.per_source = 1;
   hipLaunchKernelGGL(mvsn::plane_sweep_setup_kernel, dim3(n_sources * batch), dim3(mvsn::SETUP_THREADS), 0,
                      (hipStream_t)stream, src, K_lvl0, K_lvl4, rows4, cols4, num_idepth_samples, idepth_samples, H_lvl4,
-                     H_inc, H_lvl0_plane0, baseline);
+                     H_inc, H_lvl0_plane0, baseline, (const void *)src.T[0], (const void *)src.T[1],
+                     (const void *)src.T[2], (const void *)src.T[3], (const void *)src.T[4], (const void *)src.T[5],
+                     (const void *)src.T[6], (const void *)src.T[7], (const void *)nullptr, (const void *)nullptr);
   return mvsn::check_launch("mvsn_plane_sweep_setup_sources");
 }

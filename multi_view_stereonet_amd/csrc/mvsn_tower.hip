@@ -158,7 +158,7 @@ __device__ __forceinline__ void tw_half_wave_sums(float (&s)[2]) {
     s[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s[k]), 0x142, 0xA, 0xF, false));
 }
 
-__global__ __launch_bounds__(TW_THREADS) void tower_kernel(TowerArgs a) {
+__global__ __launch_bounds__(TW_THREADS) void tower_kernel(TowerArgs a, MVSN_VIS10) {   // (MVSN_VIS10: mvsn_common.h)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -418,6 +418,9 @@ extern "C" int mvsn_tower_16x32(const mvsn_tower_desc *d, int n_samples, mvsn_st
   const size_t lds = (size_t)TW_LDS_FLOATS * sizeof(float);
   static LdsOptIn opt;
   if (int rc = ensure_lds(opt, (const void *)tower_kernel, lds, "mvsn_tower_16x32")) return rc;
-  hipLaunchKernelGGL(tower_kernel, dim3(n_samples), dim3(TW_THREADS), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(tower_kernel, dim3(n_samples), dim3(TW_THREADS), lds, (hipStream_t)stream, a, (const void *)a.in[0],
+                     (const void *)a.in[1], (const void *)a.in[2], (const void *)a.scale, (const void *)a.U,
+                     (const void *)a.params, (const void *)a.prior, (const void *)a.fx, (const void *)a.out,
+                     (const void *)nullptr);
   return check_launch("mvsn_tower_16x32");
 }

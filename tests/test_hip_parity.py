@@ -1037,6 +1037,55 @@ def test_banded_chain_missing_band_fails_loudly(grid, N, D):
         net.check_device_status()
 
 
+def test_graph_replays_on_changing_inputs_match_eager():
+    """A recorded forward replayed as one hipGraph launch on inputs that CHANGE from call to call must give what the
+    eager forward gives on each of them, bit for bit.  (Regression: the banded chain's buffers were visible to the
+    runtime only inside a by-value struct; under graph replay nothing ordered the caches between it and its
+    neighbours, and a fraction of a percent of the forwards read lines of the previous replay -- invisible while the
+    inputs repeat.  tools/soak.py is the long form of this test; csrc/mvsn_common.h MVSN_VIS10 the rule.)"""
+    net = net_for("gta_sfm_150epochs")
+    fix = load_golden("gc3_gta_512x256_d64_s5.npz")
+    sets = []
+    for k in range(3):
+        meta = fix["meta"].copy()
+        meta[5] = int(meta[5]) + 11 * k                      # the fixture's seed, then two others
+        batch, D = batch_from_meta(meta, fix.get("jitter", 0.0), False)
+        sets.append(to_dev(snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)))
+    keep = net.options.plan_max_chains
+    net.options.plan_max_chains = 0
+    try:
+        refs = [net(*x, D, True, [True] * 5)["left_idepthmap_pyr"][0].clone() for x in sets]
+    finally:
+        net.options.plan_max_chains = keep
+    assert not torch.equal(refs[0], refs[1])
+    before = net.engine().replays
+    for i in range(600):
+        j = (i * 5 + i // 7) % 3
+        got = net(*sets[j], D, True, [True] * 5)["left_idepthmap_pyr"][0]
+        assert torch.equal(got, refs[j]), (i, j, float((got - refs[j]).abs().max()))
+    assert net.engine().replays - before >= 590 and net.engine().chain_status() == 0
+
+
+def test_wrapper_status_check_across_graph_replays():
+    """multi_view_forward (the reference's wrapper: timer with synchronize, then check_device_status) on a batch-1
+    forward that goes eager -> recorded list -> hipGraph: the banded chain's status word must read 0 after every one of
+    them (regression: a 64-byte hipMemset node in front of the chain left garbage in it on graph replay, and the
+    wrapper raised on a healthy forward), and the outputs stay bit-identical."""
+    net = net_for("gta_sfm_150epochs")
+    fix = load_golden("g2_gta_512x256_d64_s2.npz")
+    batch, D = batch_from_meta(fix["meta"], fix.get("jitter", 0.0), False)
+    inp = snu.multi_view_unpack_batch(batch, DEV, 5)
+    params = {"num_idepth_samples": D}
+    first = None
+    for i in range(8):
+        out = snu.multi_view_forward(net, inp, params)          # raises if the status word is not 0
+        assert net.engine().last_chain_form == _native.CHAIN_BANDED and net.engine().chain_status() == 0, i
+        if first is None:
+            first = out["left_idepthmap_pyr"][0].clone()
+        assert torch.equal(out["left_idepthmap_pyr"][0], first), i
+    assert net.engine().replays >= 6
+
+
 def _forward(net, fix, smooth=False, **kw):
     batch, D = batch_from_meta(fix["meta"], fix.get("jitter", 0.0), smooth)
     inp = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
