@@ -4,16 +4,20 @@ For each (config, batch): K = 4 DIFFERENT input sets, each with an eager referen
 forwards cycling through the sets in an irregular order -- every output must equal its set's reference bit for bit (a
 replay that reads anything left over from the previous replay shows up, because the previous replay ran on other inputs),
 the banded chain's status word must stay 0 and every depth map finite.  Prints one JSON line.
-    python tools/soak.py [reps] [option=value ...]          (default 400 per case)"""
+    python tools/soak.py [reps] [option=value ...] [graphed]          (default 400 per case)
+`graphed`: every case runs through GraphedForward (the whole forward, ATen copies included, captured by
+torch.cuda.graph) instead of the module's own recorded plan."""
 import json, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from multi_view_stereonet_amd import MultiViewStereoNet, _native
+from multi_view_stereonet_amd.graphed import GraphedForward
 from multi_view_stereonet_amd.weights import load_weights
 torch.set_grad_enabled(False)
 args = sys.argv[1:]
 reps = int(args[0]) if args and args[0].isdigit() else 400
 opts = dict(kv.split("=") for kv in args if "=" in kv)
+graphed = "graphed" in args
 dev = torch.device("cuda")
 K = 4
 cases = [("headline", 1), ("headline", 2), ("headline", 8), ("config3", 1), ("config3", 3), ("config4", 1), ("config4", 16),
@@ -38,11 +42,16 @@ for name, b in cases:
     for k, v in opts.items():
         setattr(net.options, k, int(v) if v.lstrip("-").isdigit() else v)
     bad, worst = 0, 0.0
+    run = lambda x: bench.run_forward(net, x, cfg["D"])
+    if graphed:
+        x0 = inps[0]
+        gf = GraphedForward(net, x0["left_image_pyr"], x0["K_pyr"], x0["T_right_in_left"], x0["right_image_pyr"], cfg["D"])
+        run = lambda x: gf(x["left_image_pyr"], x["K_pyr"], x["T_right_in_left"], x["right_image_pyr"])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(reps):
         j = (i * 7 + i // 5) % K
-        got = flat(bench.run_forward(net, inps[j], cfg["D"]))
+        got = flat(run(inps[j]))
         same = all(torch.equal(a, r) for a, r in zip(got, refs[j]))
         if not same:
             bad += 1
@@ -57,5 +66,5 @@ for name, b in cases:
                 "ms_per_forward": round((time.perf_counter() - t0) / reps * 1e3, 3)})
     del net, inps, refs
     torch.cuda.empty_cache()
-print(json.dumps({"soak": res, "options": opts, "input_sets": K, "seconds": round(time.perf_counter() - t_all, 1),
+print(json.dumps({"soak": res, "options": opts, "graphed_forward": graphed, "input_sets": K, "seconds": round(time.perf_counter() - t_all, 1),
                   "all_bit_identical": all(r["wrong_forwards"] == 0 for r in res)}))
