@@ -187,6 +187,11 @@ __global__ __launch_bounds__(TW_THREADS) void tower_kernel(TowerArgs a, MVSN_VIS
   for (int i = tid; i < n_params; i += TW_THREADS) params[i] = a.params[i];
   for (int i = tid; i < 36 * (TW_CS - TW_P); i += TW_THREADS) {       // zero slots (and the skew padding) of every plane
     const int c = i / (TW_CS - TW_P), o = i - c * (TW_CS - TW_P);
+    // NOT index 512 of a skewed plane: that is its pixel 511 (tw_chan adds 1), which another wave's input load below
+    // writes with no barrier in between.  Zeroing it here lost the race about once in 10^4 launches when this wave's
+    // parameter loads (behind the U DMA in the vmcnt queue) came back late: a feature map with one pixel of every
+    // other channel pair zeroed (tools/soak.py; HISTORY 11.5).
+    if (o == 0 && ((c >> 1) & 1)) continue;
     planes[c * TW_CS + TW_P + o] = 0.0f;
   }
   {

@@ -1207,7 +1207,8 @@ class MultiViewStereoNet(nn.Module):
             if not plan.replayable:
                 plan.keep.clear()
         else:
-            torch._foreach_copy_(plan.static_inputs, flat)
+            for d_, s_ in zip(plan.static_inputs, flat):     # EXPERIMENT: per-tensor copies (hipMemcpyAsync)
+                d_.copy_(s_)
             plan.uses += 1
             capturing = torch.cuda.is_current_stream_capturing()     # (the caller is building a graph of its own)
             if plan.graph is None and self.options.plan_graph and plan.uses >= 2 and not capturing:
@@ -1238,8 +1239,8 @@ class MultiViewStereoNet(nn.Module):
                 out[k].append(n)
                 news.append(n)
                 olds.append(t)
-        for dt in {t.dtype for t in olds}:
-            torch._foreach_copy_([n for n in news if n.dtype == dt], [o for o in olds if o.dtype == dt])
+        for n_, o_ in zip(news, olds):
+            n_.copy_(o_)
         return out
 
     def _forward_lanes(self, eng, lanes, left_image_pyr, K_pyr, T_right_in_lefts, right_image_pyrs, args):

@@ -4,7 +4,7 @@ For each (config, batch): K = 4 DIFFERENT input sets, each with an eager referen
 forwards cycling through the sets in an irregular order -- every output must equal its set's reference bit for bit (a
 replay that reads anything left over from the previous replay shows up, because the previous replay ran on other inputs),
 the banded chain's status word must stay 0 and every depth map finite.  Prints one JSON line.
-    python tools/soak.py [reps] [option=value ...] [graphed]          (default 400 per case)
+    python tools/soak.py [reps] [option=value ...] [cases=config3:1,config5:4] [graphed]     (default 400 per case)
 `graphed`: every case runs through GraphedForward (the whole forward, ATen copies included, captured by
 torch.cuda.graph) instead of the module's own recorded plan."""
 import json, os, sys, time, torch
@@ -22,6 +22,8 @@ dev = torch.device("cuda")
 K = 4
 cases = [("headline", 1), ("headline", 2), ("headline", 8), ("config3", 1), ("config3", 3), ("config4", 1), ("config4", 16),
          ("config5", 1), ("config5", 4)]
+if "cases" in opts:                                          # cases=config3:1,config3:3
+    cases = [(c.split(":")[0], int(c.split(":")[1])) for c in opts.pop("cases").split(",")]
 FORMS = {_native.CHAIN_BANDED: "banded", _native.CHAIN_WINOGRAD: "winograd", _native.CHAIN_STEPWISE: "stepwise",
          _native.CHAIN_DIRECT: "direct"}
 
