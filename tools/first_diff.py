@@ -1,3 +1,9 @@
+#!/usr/bin/env python3
+"""Which intermediate deviates first when a planned forward goes wrong?  Every tensor the recorded plan keeps alive is
+snapshotted after a good replay of each input set; after a replay whose outputs differ from the eager reference the kept
+tensors are diffed in allocation (= execution) order and the first few that differ are printed with the recorded calls
+that touch them.  (Round 3: this is what pointed at the extractor tower, HISTORY 11.5.)
+    python tools/first_diff.py <config> <batch> <reps> [option=value ...]"""
 import os, sys, torch, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench

@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""mvsn_tower_16x32 alone, launched densely through the C ABI: its input buffer is rewritten before every launch (by
+mvsn_copy / by an elementwise library kernel), the output goes to a ring of 64 buffers that is compared with the
+references every 64 launches.    python tools/tower_stress.py [samples] [launches]"""
 import os, sys, torch, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multi_view_stereonet_amd import MultiViewStereoNet, _native
