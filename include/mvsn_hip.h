@@ -436,6 +436,9 @@ int mvsn_depth_metrics(const float *idepth_est, const float *depth_true, const f
  * else): a device-to-device copy on the stream (the torch.cat / repeat of poses, intrinsics and coarse source images,
  * multi_view_stereonet.py:553,:587-592) and dst[i] = src[i * stride] (the focal lengths K[:, 0, 0], :607). */
 int mvsn_copy(void *dst, const void *src, size_t nbytes, mvsn_stream_t stream);
+/* `count` independent device-to-device copies, eight per launch, every buffer a plain pointer argument of the kernel (the
+ * input / output copies of a replayed forward plan: what torch._foreach_copy_ did with pointers the runtime cannot see) */
+int mvsn_copy_many(void *const *dst, const void *const *src, const size_t *nbytes, int count, mvsn_stream_t stream);
 /* fx[l * batch + b] = K_pyr[l][b][0][0] for every pyramid level in one launch (K_pyr: host array of `levels` <= 8 device
  * pointers to (batch, 4, 4) intrinsics) */
 int mvsn_gather_focal(const float *const *K_pyr, int levels, int batch, float *fx, mvsn_stream_t stream);

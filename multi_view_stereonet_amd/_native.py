@@ -70,6 +70,7 @@ SIGNATURES = {
     "mvsn_groupnorm_lrelu_add2": (c_int, [c_void_p] * 8 + [c_int, c_long, c_void_p, c_void_p]),
     "mvsn_conv_to1_block": (c_int, [c_void_p] * 9 + [c_int] * 3 + [c_void_p, c_void_p]),
     "mvsn_debug_set_band_flags": (c_int, [c_int]),
+    "mvsn_copy_many": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "mvsn_conv_to1_block_records": (c_int, [c_void_p] * 2 + [c_int] + [c_void_p] * 7 + [c_int] * 3 + [c_void_p, c_void_p]),
     "mvsn_groupnorm_lrelu_apply_records": (c_int, [c_void_p] * 2 + [c_int] + [c_void_p] * 6 + [c_int, c_long, c_void_p, c_void_p]),
     "mvsn_conv_to1_supported": (c_int, [c_int, c_int]),

@@ -306,6 +306,58 @@ extern "C" int mvsn_copy(void *dst, const void *src, size_t nbytes, mvsn_stream_
   return 0;
 }
 
+namespace mvsn {
+// Up to eight independent device-to-device copies in ONE launch, every buffer a plain pointer argument (the runtime
+// sees what is written and read: MVSN_VIS10's rule; ATen's multi-tensor copy carries its pointers inside a struct).
+// grid.y = pair; 16-byte accesses where both pointers and the size allow it, bytes otherwise.
+struct CopySizes {
+  size_t n[8];
+};
+__global__ __launch_bounds__(256) void copy8_kernel(void *d0, const void *s0, void *d1, const void *s1, void *d2,
+                                                    const void *s2, void *d3, const void *s3, void *d4, const void *s4,
+                                                    void *d5, const void *s5, void *d6, const void *s6, void *d7,
+                                                    const void *s7, CopySizes sz) {
+  void *const d[8] = {d0, d1, d2, d3, d4, d5, d6, d7};
+  const void *const s[8] = {s0, s1, s2, s3, s4, s5, s6, s7};
+  const int k = blockIdx.y;
+  char *dst = nullptr;
+  const char *src = nullptr;
+  size_t n = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i == k) dst = (char *)d[i], src = (const char *)s[i], n = sz.n[i];
+  const size_t stride = (size_t)gridDim.x * 256, t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if ((((size_t)dst | (size_t)src | n) & 15) == 0) {
+    for (size_t i = t; i < n / 16; i += stride) reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+  } else {
+    for (size_t i = t; i < n; i += stride) dst[i] = src[i];
+  }
+}
+}  // namespace mvsn
+
+extern "C" int mvsn_copy_many(void *const *dst, const void *const *src, const size_t *nbytes, int count,
+                              mvsn_stream_t stream) {
+  MVSN_REQUIRE(count >= 0 && (count == 0 || (dst && src && nbytes)), MVSN_E_BADARG, "mvsn_copy_many: bad arguments");
+  for (int at = 0; at < count; at += 8) {
+    const int m = count - at < 8 ? count - at : 8;
+    void *d[8] = {};
+    const void *s[8] = {};
+    mvsn::CopySizes sz = {};
+    size_t largest = 0;
+    for (int i = 0; i < m; ++i) {
+      MVSN_REQUIRE(nbytes[at + i] == 0 || (dst[at + i] && src[at + i]), MVSN_E_BADARG, "mvsn_copy_many: null pointer");
+      d[i] = dst[at + i], s[i] = src[at + i], sz.n[i] = nbytes[at + i];
+      if (sz.n[i] > largest) largest = sz.n[i];
+    }
+    if (largest == 0) continue;
+    size_t blocks = (largest / 16 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    hipLaunchKernelGGL(mvsn::copy8_kernel, dim3((unsigned)blocks, m), dim3(256), 0, (hipStream_t)stream, d[0], s[0], d[1],
+                       s[1], d[2], s[2], d[3], s[3], d[4], s[4], d[5], s[5], d[6], s[6], d[7], s[7], sz);
+  }
+  return mvsn::check_launch("mvsn_copy_many");
+}
+
 extern "C" int mvsn_gather_strided(const float *src, int count, long stride, float *dst, mvsn_stream_t stream) {
   MVSN_REQUIRE(src && dst && count > 0 && stride > 0, MVSN_E_BADARG, "mvsn_gather_strided: bad arguments");
   hipLaunchKernelGGL(mvsn::gather_strided_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, count,

@@ -192,6 +192,7 @@ class ForwardPlan:
         self.graph = None          # hipGraph of the call list (None: not captured yet, False: capture refused)
         self.uses = 0
         self.nbytes = 0            # bytes of intermediates the plan keeps alive
+        self.chain_info = (None, None, None)   # (form, workspace, shape) of the recorded chain call
 
     def replay(self):
         stream = _native.stream()
@@ -373,6 +374,23 @@ class PlaneSweepEngine:
         assert dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and dst.numel() == src.numel()
         self._call("mvsn_copy", self.lib.mvsn_copy, _native.ptr(dst), _native.ptr(src),
                    dst.numel() * dst.element_size(), _native.stream(), nbytes=2.0 * dst.numel() * dst.element_size())
+
+    def copy_many(self, dsts, srcs):
+        """dst[i] <- src[i] for dense same-shape pairs, eight pairs per launch with every buffer visible to the runtime
+        as a kernel argument (mvsn_copy_many); pairs of different dtype / layout fall back to Tensor.copy_."""
+        pairs = []
+        for d, s in zip(dsts, srcs):
+            if d.dtype == s.dtype and d.shape == s.shape and d.is_contiguous() and s.is_contiguous() and s.is_cuda:
+                pairs.append((d, s))
+            else:
+                d.copy_(s)
+        if not pairs:
+            return
+        n = len(pairs)
+        dp = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in pairs])
+        sp = (ctypes.c_void_p * n)(*[s.data_ptr() for _, s in pairs])
+        nb = (ctypes.c_size_t * n)(*[d.numel() * d.element_size() for d, _ in pairs])
+        _native.check(self.lib.mvsn_copy_many(dp, sp, nb, n, _native.stream()), "mvsn_copy_many")
 
     def cat0(self, parts) -> torch.Tensor:
         """torch.cat(parts, 0) of dense fp32 tensors as device copies into one allocation."""
@@ -1199,6 +1217,7 @@ class MultiViewStereoNet(nn.Module):
             finally:
                 eng.recording = None
             plan.nbytes = sum(t.numel() * t.element_size() for t in plan.keep)
+            plan.chain_info = (eng.last_chain_form, eng.last_chain_workspace, eng.last_chain_shape)
             # a handful of shapes at most, and at most ~8 GB of kept intermediates: drop the oldest plans beyond that
             while eng.plans and (len(eng.plans) >= 8 or plan.nbytes +
                                  sum(p.nbytes for p in eng.plans.values() if p is not None) > self.options.plan_max_bytes):
@@ -1207,8 +1226,7 @@ class MultiViewStereoNet(nn.Module):
             if not plan.replayable:
                 plan.keep.clear()
         else:
-            for d_, s_ in zip(plan.static_inputs, flat):     # EXPERIMENT: per-tensor copies (hipMemcpyAsync)
-                d_.copy_(s_)
+            eng.copy_many(plan.static_inputs, flat)
             plan.uses += 1
             capturing = torch.cuda.is_current_stream_capturing()     # (the caller is building a graph of its own)
             if plan.graph is None and self.options.plan_graph and plan.uses >= 2 and not capturing:
@@ -1227,6 +1245,8 @@ class MultiViewStereoNet(nn.Module):
             else:
                 plan.replay()
             eng.replays += 1
+            # (chain_status / check_device_status look at the chain call of THIS forward, not of the last recording)
+            eng.last_chain_form, eng.last_chain_workspace, eng.last_chain_shape = plan.chain_info
         # fresh output tensors (a caller may keep them across forwards)
         out, news, olds = {}, [], []
         for k, lst in plan.outputs.items():
@@ -1239,8 +1259,7 @@ class MultiViewStereoNet(nn.Module):
                 out[k].append(n)
                 news.append(n)
                 olds.append(t)
-        for n_, o_ in zip(news, olds):
-            n_.copy_(o_)
+        eng.copy_many(news, olds)
         return out
 
     def _forward_lanes(self, eng, lanes, left_image_pyr, K_pyr, T_right_in_lefts, right_image_pyrs, args):
