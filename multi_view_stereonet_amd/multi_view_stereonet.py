@@ -315,7 +315,7 @@ class PlaneSweepEngine:
         if pack is None or tuple(x.shape[1:]) != (32, 16, 32):
             return None
         U, params, dils = pack
-        x = x.contiguous()
+        x = self.dense(x)
         out = self.empty(x.shape, x.dtype, x.device)
         d = _native.TowerDesc()
         d.inp[0], d.channels[0], d.sample_mod[0] = x.data_ptr(), 32, x.shape[0]
@@ -369,6 +369,14 @@ class PlaneSweepEngine:
             return t
         self._aten()
         return t.float().contiguous()
+
+    def dense(self, t: torch.Tensor) -> torch.Tensor:
+        """t as a dense tensor -- itself when it already is; an ATen copy (which makes a forward being recorded
+        non-replayable: the copy is not part of the plan) otherwise."""
+        if t.is_contiguous():
+            return t
+        self._aten()
+        return t.contiguous()
 
     def copy_into(self, dst: torch.Tensor, src: torch.Tensor):
         assert dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and dst.numel() == src.numel()
@@ -535,7 +543,7 @@ class PlaneSweepEngine:
         d = c.desc(n, 1, rows, cols, _native.CONV_FP32_WINO)
         if not lib.mvsn_conv_winograd_supported(ctypes.byref(d)) or sum(b.shape[1] for b in blocks) != c.cin:
             return None
-        blocks = [b.contiguous() for b in blocks]
+        blocks = [self.dense(b) for b in blocks]
         if any(b.data_ptr() % 16 for b in blocks):
             return None
         if out is None:
@@ -818,7 +826,7 @@ class PlaneSweepEngine:
         [guide..., prior * fx] is assembled with ONE concatenation.  `scaled` = prior * fx when the caller already
         has it (upsample_prior forms it in the upsampling pass)."""
         p = self.refiners[level]
-        prior, fx = prior.contiguous(), fx.contiguous()
+        prior, fx = self.dense(prior), self.dense(fx)
         n, pixels = prior.shape[0], prior[0].numel()
         if scaled is None:
             scaled = self.empty(prior.shape, prior.dtype, prior.device)
@@ -833,6 +841,7 @@ class PlaneSweepEngine:
                 self.lib.mvsn_conv_to1_supported(rows, cols) and p["final"].dilation == 1):
             return self.residual_tower_sliced(x_in, (p["conv0"], p["bn0"]), p["res"], p["final"], prior, fx)
         if self.fold_residual_blocks or len(x_in) > 3:
+            self._aten()                    # (an ATen kernel: a forward being recorded is not replayable)
             x_in = torch.cat(x_in, 1)       # those towers take one tensor
         if self.fold_residual_blocks:
             delta, done = self.residual_tower(x_in, (p["conv0"], p["bn0"]), p["res"], p["final"]), False
@@ -843,7 +852,7 @@ class PlaneSweepEngine:
             return delta            # epilogue relu(prior*fx + delta)/fx already applied in the kernel
         out = self.empty(prior.shape, prior.dtype, prior.device)
         self._call("mvsn_refiner_epilogue", self.lib.mvsn_refiner_epilogue, _native.ptr(prior), _native.ptr(fx),
-                   _native.ptr(delta.contiguous()), n, pixels, _native.ptr(out), _native.stream(),
+                   _native.ptr(self.dense(delta)), n, pixels, _native.ptr(out), _native.stream(),
                    nbytes=12.0 * prior.numel())
         return out
 
@@ -952,7 +961,7 @@ class PlaneSweepEngine:
     def soft_argmin(self, cost: torch.Tensor, samples: torch.Tensor) -> torch.Tensor:
         N, D, rows, cols = cost.shape
         out = self.empty((N, 1, rows, cols), dtype=torch.float32, device=cost.device)
-        self._call("mvsn_soft_argmin", self.lib.mvsn_soft_argmin, _native.ptr(cost.contiguous()), _native.ptr(samples),
+        self._call("mvsn_soft_argmin", self.lib.mvsn_soft_argmin, _native.ptr(self.dense(cost)), _native.ptr(samples),
                    N, D, rows * cols, _native.ptr(out), _native.stream(), nbytes=4.0 * (cost.numel() + out.numel()))
         return out
 

@@ -1071,6 +1071,34 @@ def test_graph_replays_on_changing_inputs_match_eager(chain_form, plan_graph, re
         net.options.plan_max_chains, net.options.chain_form, net.options.plan_graph = keep
 
 
+@pytest.mark.parametrize("opt,val", [("fold_residual_blocks", True), ("winograd", False), ("towers", False),
+                                     ("trim_tower_ends", False), ("conv_precision", "bf16x3")])
+def test_planned_forward_matches_eager_under_option_variants(opt, val):
+    """Every launch-sequence option must give the same bits planned (recorded once, replayed) as eager -- or mark its
+    forward as not replayable.  (Regression: with fold_residual_blocks the refiner input was assembled by an unrecorded
+    torch.cat, and every replay of that plan returned the first call's depth maps; found by tools/soak.py.)"""
+    net = net_for("gta_sfm_150epochs")
+    fix = load_golden("g2_gta_512x256_d64_s2.npz")
+    sets = []
+    for k in range(2):
+        meta = fix["meta"].copy()
+        meta[5] = int(meta[5]) + 7 * k
+        batch, D = batch_from_meta(meta, fix.get("jitter", 0.0), False)
+        sets.append(to_dev(snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)))
+    keep = (getattr(net.options, opt), net.options.plan_max_chains)
+    setattr(net.options, opt, val)
+    try:
+        net.options.plan_max_chains = 0
+        refs = [net(*x, D, True, [True] * 5)["left_idepthmap_pyr"][0].clone() for x in sets]
+        net.options.plan_max_chains = keep[1]
+        for i in range(8):
+            got = net(*sets[i % 2], D, True, [True] * 5)["left_idepthmap_pyr"][0]
+            assert torch.equal(got, refs[i % 2]), (opt, i, float((got - refs[i % 2]).abs().max()))
+    finally:
+        setattr(net.options, opt, keep[0])
+        net.options.plan_max_chains = keep[1]
+
+
 def test_wrapper_status_check_across_graph_replays():
     """multi_view_forward (the reference's wrapper: timer with synchronize, then check_device_status) on a batch-1
     forward that goes eager -> recorded list -> hipGraph: the banded chain's status word must read 0 after every one of

@@ -38,11 +38,17 @@ for name, b in cases:
     cfg = bench.CONFIGS[name]
     net = MultiViewStereoNet(); net.load_state_dict(load_weights(cfg["weights"]), strict=True); net = net.to(dev).eval()
     inps = [bench.config_inputs(cfg, b, r, dev)[1] for r in range(K)]
+    # arithmetic options (conv_precision, winograd, towers ...) apply to the references too; the replay options
+    # (plan_*, chain_form: same arithmetic, other mapping) only to the soaked forwards
+    late = {k: v for k, v in opts.items() if k.startswith("plan_") or k == "chain_form"}
+    for k, v in opts.items():
+        if k not in late:
+            setattr(net.options, k, int(v) if v.lstrip("-").isdigit() else v)
     keep = net.options.plan_max_chains
     net.options.plan_max_chains = 0
     refs = [[t.clone() for t in flat(bench.run_forward(net, x, cfg["D"]))] for x in inps]
     net.options.plan_max_chains = keep
-    for k, v in opts.items():
+    for k, v in late.items():
         setattr(net.options, k, int(v) if v.lstrip("-").isdigit() else v)
     bad, worst = 0, 0.0
     run = lambda x: bench.run_forward(net, x, cfg["D"])
