@@ -56,7 +56,7 @@ int chain_steps_launch(const ChainArgs &a, int n_chains, void *workspace, size_t
 
 // Banded form (mvsn_chain_band.hip): one chain on several workgroups; coarse grids 16x32, 30x40, 32x64
 bool chain_band_supported(int rows, int cols);
-int chain_band_groups(int rows, int cols);                 // workgroups per chain (0: no plan for this grid)
+int chain_band_groups(int n_chains, int rows, int cols);    // workgroups per chain (0: no plan for this grid)
 int chain_band_chains_per_pass(int rows, int cols);        // chains whose workgroups are co-resident (one per CU)
 size_t chain_band_workspace_bytes(int n_chains, int rows, int cols);
 size_t chain_band_status_offset(int n_chains, int rows, int cols);

@@ -46,6 +46,8 @@
 //                win 32 x CSW: gather window = feature rows lo-W .. hi+W+1 of the previous plane (own band written by
 //                      the epilogue, the others fetched from the neighbours' granules when the step's gather needs
 //                      them; rows outside the image stay zero and double as the bilinear taps' zero halo)
+#include <type_traits>
+
 #include "mvsn_chain.h"
 #include "mvsn_common.h"
 
@@ -55,9 +57,13 @@ constexpr int CB_THREADS = 256, CB_WAVES = 4;
 constexpr float CB_GN_EPS = 1e-5f;
 constexpr unsigned CB_SPIN_LIMIT = 1u << 21;
 
-template <int ROWS, int COLS, int BR_, int W_, int CSA_>
+template <int ROWS, int COLS, int BR_, int W_, int CSA_, bool HS_ = false>
 struct BandGeo {
   static constexpr int rows = ROWS, cols = COLS, BR = BR_, W = W_, G = ROWS / BR_, P = ROWS * COLS, RS = COLS + 2;
+  // HS ("half split"): a band of ONE patch tile; the waves that would own the second tile take the second
+  // transform-row half of every layer instead (wave = (half h, cout tile ct)), the halves are added through LDS
+  static constexpr bool HS = HS_;
+  static constexpr int COMB = HS_ ? 2 * 64 * 16 : 0;              // [cout tile][r][lane][e]: half 1's outputs
   static constexpr int PCOLS = COLS / 2, PROWS = BR_ / 2, NPATCH = PROWS * PCOLS;
   static constexpr int AROWS = BR_ + 2, CSA = CSA_;             // layer input planes: rows, channel stride
   static constexpr int WSLOTS = BR_ + 2 * W_ + 1, CSW = WSLOTS * RS + 2;   // gather window: row slots, channel stride
@@ -68,20 +74,22 @@ struct BandGeo {
   static constexpr int FROW = (32 * COLS) / CB_THREADS;          // granules per thread and fetched window row
   static constexpr int TABW = EXT * 4, TABI = EXT * 2;
   static constexpr int MASK = BR_ * COLS;
-  static constexpr int LDS_FLOATS = CW_U0_FLOATS + CH_SP_FLOATS + RED + 32 + 16 + MASK + TABW + TABI + 36 * CSA + 32 * CSW;
+  static constexpr int LDS_FLOATS =
+      CW_U0_FLOATS + CH_SP_FLOATS + RED + 32 + 16 + MASK + TABW + TABI + 36 * CSA + 32 * CSW + COMB;
   // granule workspace of one chain (u64 units)
   static constexpr size_t FG = 0;                                          // [32 ch][rows][cols]
   static constexpr size_t RG = FG + 32 * (size_t)P;                        // [layer 2][band][side 2][32 ch][cols]
   static constexpr size_t SG = RG + 2 * (size_t)G * 2 * 32 * COLS;         // [layer 2][band][wave 4][4]
   static constexpr size_t CHAIN_U64 = SG + 2 * (size_t)G * CB_WAVES * 4;
   static_assert(ROWS % BR_ == 0 && BR_ % 2 == 0 && COLS % 2 == 0, "bands of whole 2x2 patches");
-  static_assert(NPATCH <= 32, "a band is at most two MFMA patch tiles");
+  static_assert(NPATCH <= (HS_ ? 16 : 32), "a band is at most two MFMA patch tiles (half split: one)");
   static_assert(EXT <= CB_THREADS, "one thread per pixel of the band + halo rows");
   static_assert((32 * COLS) % CB_THREADS == 0, "window rows are fetched in whole rounds");
   static_assert(CSA % 2 == 0 && CSA >= AROWS * RS, "activation planes: 8-byte aligned rows");
   static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS plan");
 };
 typedef BandGeo<16, 32, 4, 3, 224> Band16x32;   // CSA = 32 (mod 64): the four channels of a k-step read disjoint banks
+typedef BandGeo<16, 32, 2, 3, 160, true> Band16x32H;   // 8 bands of 2 rows, half split (few chains: <= CUs / 8)
 typedef BandGeo<30, 40, 2, 3, 168> Band30x40;
 typedef BandGeo<32, 64, 2, 1, 264> Band32x64;
 
@@ -136,13 +144,16 @@ __device__ __forceinline__ void cb_sweep(Addr addr, unsigned tag, bool active, f
 // (wino_layer of mvsn_chain_wino.hip with the cout-tile dimension dealt to the waves).  The pinned order -- transform,
 // then the eight multiplies back to back -- is the measured best: interleaving the next k-step's transform with the
 // multiplies (one wave per SIMD has nobody else to fill the pipe) took 24.2 us per step against 22.8 (HISTORY 3.6).
-template <int NC, int CSA, int RS>
+// HSEL = -1: both transform-row halves (y = half 0's outputs + half 1's); 0 / 1: that half alone (y = its outputs; the
+// caller adds the two waves' results in the same order, so the sum is bit for bit the one-wave form's).
+template <int NC, int CSA, int RS, int HSEL = -1>
 __device__ __forceinline__ void band_layer(const float *__restrict__ act, const float *__restrict__ U, int ct, int wb,
                                            int lane, float (&y)[4][4]) {
   const float *wbase = act + (lane >> 4) * CSA + wb;
   const float *ub = U + ct * 1024 + lane * 4;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
+    if (HSEL >= 0 && half != HSEL) continue;
     floatx4 acc[8];
     float d[2][3][4];
     floatx4 u[2][2];
@@ -206,7 +217,7 @@ __device__ __forceinline__ void band_layer(const float *__restrict__ act, const 
       }
       const float y0 = s0[0] + s0[1] + s0[2], y1 = s0[1] - s0[2] - s0[3];
       const float y2 = s1[0] + s1[1] + s1[2], y3 = s1[1] - s1[2] - s1[3];
-      if (half == 0) y[r][0] = y0, y[r][1] = y1, y[r][2] = y2, y[r][3] = y3;
+      if (half == 0 || HSEL == 1) y[r][0] = y0, y[r][1] = y1, y[r][2] = y2, y[r][3] = y3;
       else y[r][0] += y0, y[r][1] += y1, y[r][2] += y2, y[r][3] += y3;
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -251,7 +262,9 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int nl = blockIdx.x / G, m = blockIdx.x % G;   // chain within this pass (workspace), band
   const int n = a.chain0 + nl;                        // chain of the call (data)
-  const int pt = wave >> 1, ct = wave & 1;
+  constexpr bool HS = GEO::HS;
+  const int hsel = wave >> 1;                        // half split: this wave's transform-row half (owner of the patches: 0)
+  const int pt = HS ? 0 : wave >> 1, ct = wave & 1;
   const int lo = m * BR, hi = lo + BR - 1, wlo = lo - W;
   const int D = a.D;
   int tid = tid0;
@@ -270,6 +283,7 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
   int *tabi = reinterpret_cast<int *>(tabw + GEO::TABW);     // [pixel][y0 * RS + x0 + 1, row step]
   float *act = tabw + GEO::TABW + GEO::TABI;
   float *win = act + 36 * CSA;
+  float *comb = win + 32 * CSW;                              // (half split only)
 
   gu64 *ws = (gu64 *)(reinterpret_cast<u64 *>(a.workspace) + (size_t)nl * GEO::CHAIN_U64);
   gu64 *Fg = ws + GEO::FG, *Rg = ws + GEO::RG, *Sg = ws + GEO::SG;
@@ -299,10 +313,11 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
   // this lane's patch: patch q of the band (row-major), outputs (lo + 2 prow + a, 2 pc + b), e = a*2 + b
   const int k = lane >> 4;
   const int q = pt * 16 + (lane & 15);
-  const bool pvalid = q < GEO::NPATCH;
-  const int qq = pvalid ? q : 0;
+  const bool qvalid = q < GEO::NPATCH;
+  const bool pvalid = qvalid && (!HS || hsel == 0);     // owner of the patch's outputs (gather, statistics, epilogue)
+  const int qq = qvalid ? q : 0;
   const int prow = qq / GEO::PCOLS, pc = qq - prow * GEO::PCOLS;
-  const bool tile_live = pt * 16 < GEO::NPATCH;          // wave-uniform
+  const bool tile_live = HS || pt * 16 < GEO::NPATCH;    // wave-uniform
   const int wb = (2 * prow) * RS + 2 * pc;            // window origin inside an act plane (local row 0 = image row lo-1)
   const int ob = wb + RS + 1;                         // output (0,0)
   const int cbase = ct * 16 + k * 4;                  // this lane's couts: cbase + r
@@ -540,13 +555,15 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
       cb_barrier();   // B2: window complete
       // A2 gather.  The +1 column tap is read unclamped: where the clamp would act its weight is exactly zero and the
       // slot read is the zero halo column; the +1 row tap re-reads row y0 there (weight exactly zero as well).
+      if (!HS || hsel == 0) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float *fc = win + (cbase + r) * CSW + (to[e] - wlo * RS);
-          fp[r][e] = fc[0] * tw[e][0] + fc[1] * tw[e][1] + fc[tdy[e]] * tw[e][2] + fc[tdy[e] + 1] * tw[e][3];
-        }
+          for (int r = 0; r < 4; ++r) {
+            const float *fc = win + (cbase + r) * CSW + (to[e] - wlo * RS);
+            fp[r][e] = fc[0] * tw[e][0] + fc[1] * tw[e][1] + fc[tdy[e]] * tw[e][2] + fc[tdy[e] + 1] * tw[e][3];
+          }
+      }
 #pragma unroll
       for (int it = 0; it < HI; ++it) {
 #pragma unroll
@@ -625,10 +642,38 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
     CB_STAMP(4);
 
     float y[4][4] = {};
-    if (tile_live) band_layer<9, CSA, RS>(act, U, ct, wb, lane, y);
+    // half split: wave (h, ct) runs transform-row half h of the layer; half 1's outputs reach the owner through LDS
+    // (written before, read after the barrier that follows every layer anyway) and are added in the one-wave order
+    auto layer = [&](auto nc) {
+      constexpr int NC = decltype(nc)::value;
+      if constexpr (HS) {
+        if (hsel == 0) band_layer<NC, CSA, RS, 0>(act, U, ct, wb, lane, y);
+        else {
+          band_layer<NC, CSA, RS, 1>(act, U, ct, wb, lane, y);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<floatx4 *>(comb + ((ct * 4 + r) * 64 + lane) * 4) = floatx4{y[r][0], y[r][1], y[r][2], y[r][3]};
+        }
+      } else {
+        if (tile_live) band_layer<NC, CSA, RS>(act, U, ct, wb, lane, y);
+      }
+    };
+    auto combine = [&]() {
+      if constexpr (HS) {
+        if (hsel == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const floatx4 o = *reinterpret_cast<const floatx4 *>(comb + ((ct * 4 + r) * 64 + lane) * 4);
+            y[r][0] += o[0], y[r][1] += o[1], y[r][2] += o[2], y[r][3] += o[3];
+          }
+        }
+      }
+    };
+    layer(std::integral_constant<int, 9>{});
     CB_STAMP(5);
     cb_barrier();   // B4: act and U free
     dma_u(upk + CW_U0_FLOATS, 8);
+    combine();
 
     // E2 / E3: bias, partial GroupNorm sums (shifted by the previous step's mean, as chain_wino_kernel), publish
     // them with the band's boundary rows; collect the other bands'; normalise + activate own outputs and halo rows
@@ -712,14 +757,16 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
       cb_barrier();
       // totals in a fixed order: every workgroup of the chain forms the same statistics bit for bit
       float own_mean, own_rstd, h_mean[HI], h_rstd[HI];
-      if constexpr (G <= 4) {
-        // few bands: each thread adds the 2 G records of the groups it needs itself (band-major), no second barrier
+      if constexpr (G <= 4 || HS) {
+        // few bands: each thread adds the 2 G records of the groups it needs itself (band-major), no second barrier.
+        // Half split: G owner records per group -- the 2-row band m is patch tile m % 2 of the 4-row band m / 2, so
+        // the records AND their order are those of the 4-band geometry: the same statistics bit for bit.
         auto stats_of = [&](int g, float sh, float &mean, float &rstd) {
           float s1 = 0.f, s2 = 0.f;
 #pragma unroll
           for (int mm = 0; mm < G; ++mm)
 #pragma unroll
-            for (int pp = 0; pp < 2; ++pp) {
+            for (int pp = 0; pp < (HS ? 1 : 2); ++pp) {
               const float2 rec = *reinterpret_cast<const float2 *>(red + (mm * CB_WAVES + pp * 2 + (g >> 1)) * 4 + (g & 1) * 2);
               s1 += rec.x;
               s2 += rec.y;
@@ -733,7 +780,7 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
 #pragma unroll
         for (int it = 0; it < HI; ++it) stats_of(hcg[it], hshift[it], h_mean[it], h_rstd[it]);
         // (the next step's shift; nobody reads gs again before the barriers that follow)
-        if (pt == 0 && (lane & 31) == 0) gs[gown * 2] = own_mean;   // waves 0, 1 cover the four groups
+        if (hsel == 0 && (lane & 31) == 0) gs[gown * 2] = own_mean;   // waves 0, 1 cover the four groups
       } else {
         // many bands: wave 0, one 16-lane row per group: lane `sub` adds the records of bands sub, sub + 16, ..., four
         // DPP steps add the row; everyone reads the result behind a second barrier
@@ -805,10 +852,11 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
     cb_barrier();   // B6
     CB_STAMP(7);
 
-    if (tile_live) band_layer<8, CSA, RS>(act, U, ct, wb, lane, y);
+    layer(std::integral_constant<int, 8>{});
     CB_STAMP(8);
     cb_barrier();   // B7
     dma_u(upk + CW_U0_FLOATS + CW_U1_FLOATS, 8);
+    combine();
     exchange(1, bias1, gn1w, gn1b, true, [&] {   // x2 = x1 + LReLU(GN(conv1(x1)))
       if (d + 1 < D) prepare(d + 1);
     });
@@ -817,12 +865,13 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
     cb_barrier();   // B10
     CB_STAMP(10);
 
-    if (tile_live) band_layer<8, CSA, RS>(act, U, ct, wb, lane, y);
+    layer(std::integral_constant<int, 8>{});
     float2 fl[4][2];
     load_left(fl);
     CB_STAMP(11);
     cb_barrier();   // B11
     dma_u(upk, 9);  // conv0 of the next step
+    combine();
 
     // epilogue: F_d = moved + conv_final(...); window rows, granules for the other bands, cost slice
     {
@@ -866,9 +915,17 @@ static BandPlan band_plan_of() {
   return BandPlan{GEO::G, GEO::CHAIN_U64, (size_t)GEO::LDS_FLOATS * sizeof(float), chain_band_kernel<GEO>};
 }
 
-static bool band_plan(int rows, int cols, BandPlan *p) {
-  if (rows == 16 && cols == 32) *p = band_plan_of<Band16x32>();
-  else if (rows == 30 && cols == 40) *p = band_plan_of<Band30x40>();
+static int g_band_debug_flags = 0;
+void chain_band_debug_flags(int flags) { g_band_debug_flags = flags; }
+
+// 16x32 has two plans: 8 bands of 2 rows (half split) while that many workgroups per chain fit the chip in one pass,
+// 4 bands of 4 rows beyond (bit-identical results: same arithmetic per output, same GroupNorm records in the same
+// order).  Debug flag bit 2 pins the 4-band plan (A/B, tests).
+static bool band_plan(int rows, int cols, int n_chains, BandPlan *p) {
+  if (rows == 16 && cols == 32) {
+    if (!(g_band_debug_flags & 4) && n_chains <= device_cus() / Band16x32H::G) *p = band_plan_of<Band16x32H>();
+    else *p = band_plan_of<Band16x32>();
+  } else if (rows == 30 && cols == 40) *p = band_plan_of<Band30x40>();
   else if (rows == 32 && cols == 64) *p = band_plan_of<Band32x64>();
   else return false;
   return true;
@@ -876,18 +933,19 @@ static bool band_plan(int rows, int cols, BandPlan *p) {
 
 bool chain_band_supported(int rows, int cols) {
   BandPlan p;
-  return band_plan(rows, cols, &p);
+  return band_plan(rows, cols, 1 << 20, &p);
 }
 
-int chain_band_groups(int rows, int cols) {
+int chain_band_groups(int n_chains, int rows, int cols) {
   BandPlan p;
-  return band_plan(rows, cols, &p) ? p.G : 0;
+  return band_plan(rows, cols, n_chains, &p) ? p.G : 0;
 }
 
-// chains per pass: every workgroup of a pass must be co-resident (one per CU)
+// chains per pass: every workgroup of a pass must be co-resident (one per CU).  (Of the plan for MANY chains: the
+// largest number a single pass can take on this grid.)
 int chain_band_chains_per_pass(int rows, int cols) {
   BandPlan p;
-  return band_plan(rows, cols, &p) ? device_cus() / p.G : 0;
+  return band_plan(rows, cols, 1 << 20, &p) ? device_cus() / p.G : 0;
 }
 
 static int band_ws_chains(const BandPlan &p, int n_chains) {
@@ -897,16 +955,13 @@ static int band_ws_chains(const BandPlan &p, int n_chains) {
 
 size_t chain_band_workspace_bytes(int n_chains, int rows, int cols) {
   BandPlan p;
-  return band_plan(rows, cols, &p) ? ((size_t)band_ws_chains(p, n_chains) * p.chain_u64 + 8) * sizeof(u64) : 0;
+  return band_plan(rows, cols, n_chains, &p) ? ((size_t)band_ws_chains(p, n_chains) * p.chain_u64 + 8) * sizeof(u64) : 0;
 }
 
 size_t chain_band_status_offset(int n_chains, int rows, int cols) {
   BandPlan p;
-  return band_plan(rows, cols, &p) ? (size_t)band_ws_chains(p, n_chains) * p.chain_u64 * sizeof(u64) : 0;
+  return band_plan(rows, cols, n_chains, &p) ? (size_t)band_ws_chains(p, n_chains) * p.chain_u64 * sizeof(u64) : 0;
 }
-
-static int g_band_debug_flags = 0;
-void chain_band_debug_flags(int flags) { g_band_debug_flags = flags; }
 
 // status word behind the granules: 0 = every hand-off completed; otherwise the code of the hand-off that timed out.
 // More chains than fit the chip at one workgroup per band run as consecutive passes over the same workspace (the
@@ -915,7 +970,7 @@ int chain_band_launch(const ChainArgs &a, int n_chains, void *workspace, size_t 
                       hipStream_t stream) {
   flags |= g_band_debug_flags;
   BandPlan p;
-  MVSN_REQUIRE(band_plan(a.rows, a.cols, &p), MVSN_E_TOOLARGE,
+  MVSN_REQUIRE(band_plan(a.rows, a.cols, n_chains, &p), MVSN_E_TOOLARGE,
                "mvsn_incremental_cost_volume(banded): no plan for a %dx%d coarse grid", a.rows, a.cols);
   const size_t need = chain_band_workspace_bytes(n_chains, a.rows, a.cols);
   MVSN_REQUIRE(workspace && workspace_bytes >= need, MVSN_E_WORKSPACE,
@@ -923,8 +978,8 @@ int chain_band_launch(const ChainArgs &a, int n_chains, void *workspace, size_t 
   const int cap = device_cus() / p.G, wsn = band_ws_chains(p, n_chains);
   MVSN_REQUIRE(cap >= 1, MVSN_E_TOOLARGE, "mvsn_incremental_cost_volume(banded): %d bands exceed the %d CUs", p.G,
                device_cus());
-  static LdsOptIn opt[3];
-  LdsOptIn &o = opt[a.rows == 16 ? 0 : (a.rows == 30 ? 1 : 2)];
+  static LdsOptIn opt[4];
+  LdsOptIn &o = opt[a.rows == 16 ? (p.G == 8 ? 3 : 0) : (a.rows == 30 ? 1 : 2)];
   if (int rc = ensure_lds(o, (const void *)p.kernel, p.lds_bytes, "mvsn_incremental_cost_volume(banded)")) return rc;
   for (int n0 = 0; n0 < n_chains; n0 += cap) {
     const int nn = n_chains - n0 < cap ? n_chains - n0 : cap;

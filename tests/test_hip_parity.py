@@ -841,6 +841,38 @@ def test_banded_chain_gather_paths_vs_oracle(kind, N, D, grid):
     assert torch.equal(got["banded"][1], got[other][1])
 
 
+@pytest.mark.parametrize("kind,N,D", [("small", 1, 64), ("mixed", 5, 20), ("vertical", 2, 9), ("small", 32, 6), ("mixed", 17, 7)])
+def test_banded_chain_half_split_is_bit_identical_to_four_bands(kind, N, D):
+    """16x32 has two banded plans: up to CUs / 8 chains run on 8 bands of 2 rows whose waves split every layer by
+    transform-row half (the halves are added through LDS in the one-wave order), more on 4 bands of 4 rows.  Same
+    arithmetic per output, same GroupNorm records in the same order: cost, mask and feature volumes must agree bit for
+    bit (debug flag 4 pins the 4-band plan), on both gather paths."""
+    net = net_for("gta_sfm_150epochs")
+    eng = net.engine()
+    g = torch.Generator().manual_seed(31)
+    H, Hinc = _motion_family(N, D, kind, seed=8)
+    B = max(1, N // 2)
+    dev = [x.to(DEV) for x in (torch.rand(N, 3, 16, 32, generator=g) * 2 - 1, H, Hinc,
+                               torch.randn(N, 32, 16, 32, generator=g), torch.randn(B, 32, 16, 32, generator=g))]
+    net.options.chain_form = "banded"
+    try:
+        got = eng.incremental_cost_volume(*dev, want_features=True)
+        torch.cuda.synchronize()
+        assert eng.chain_status() == 0
+        eng.lib.mvsn_debug_set_band_flags(4)
+        try:
+            ref = eng.incremental_cost_volume(*dev, want_features=True)
+            torch.cuda.synchronize()
+            assert eng.chain_status() == 0
+        finally:
+            eng.lib.mvsn_debug_set_band_flags(0)
+        for name, a, b in zip(("cost", "mask", "features"), got, ref):
+            assert torch.equal(a, b), (name, int((a != b).sum()))
+        assert bool(torch.isfinite(got[0]).all())
+    finally:
+        net.options.chain_form = "auto"
+
+
 @pytest.mark.parametrize("form", ["winograd", "banded"])
 @pytest.mark.parametrize("case,D", [("long", 128), ("long", 256), ("steps", 48), ("offset", 24)])
 def test_chain_groupnorm_single_pass_stays_accurate(case, D, form):

@@ -20,7 +20,15 @@ for N in [int(a) for a in sys.argv[1:]] or [2, 256]:
     Hinc = torch.eye(3).repeat(N, D, 1, 1); Hinc[:, 1:, 0, 2] = 12.0 / (D - 1)
     F0 = torch.randn(N, 32, rows, cols, generator=g).cuda(); FL = torch.randn(B, 32, rows, cols, generator=g).cuda()
     H, Hinc = H.cuda(), Hinc.cuda()
-    for form in ("direct", "winograd", "stepwise", "banded"):
+    for form in ("direct", "winograd", "stepwise", "banded", "banded4"):
+        if form == "banded4":         # 16x32: the 4-band plan pinned (debug flag 4) against the 8-band half-split plan
+            if (rows, cols) != (16, 32) or N > 32:
+                continue
+            eng.lib.mvsn_debug_set_band_flags(4)
+            form, tag = "banded", "banded4"
+        else:
+            eng.lib.mvsn_debug_set_band_flags(0)
+            tag = form
         if form == "winograd" and (rows, cols) != (16, 32):
             continue
         if form == "stepwise" and (rows, cols) == (16, 32):
@@ -38,5 +46,7 @@ for N in [int(a) for a in sys.argv[1:]] or [2, 256]:
         ms = a.elapsed_time(b) / reps
         flops = N * (D - 1) * 2.0 * 9 * 32 * 99 * P
         nbytes = N * (4.0 * 67 * P + 128.0 * D * P + D * P)
-        print(f"N={N:4d} {form:8s}: {ms:7.3f} ms/launch  {ms * 1e3 / (D - 1):6.1f} us/step  "
-              f"{flops / ms / 1e9:6.1f} direct-form TFLOP/s  {nbytes / ms / 1e6:7.1f} GB/s algorithmic  status {eng.chain_status()}")
+        status = eng.chain_status()
+        eng.lib.mvsn_debug_set_band_flags(0)
+        print(f"N={N:4d} {tag:8s}: {ms:7.3f} ms/launch  {ms * 1e3 / (D - 1):6.1f} us/step  "
+              f"{flops / ms / 1e9:6.1f} direct-form TFLOP/s  {nbytes / ms / 1e6:7.1f} GB/s algorithmic  status {status}")
