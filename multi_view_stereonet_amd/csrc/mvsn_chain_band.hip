@@ -61,9 +61,11 @@ template <int ROWS, int COLS, int BR_, int W_, int CSA_, bool HS_ = false>
 struct BandGeo {
   static constexpr int rows = ROWS, cols = COLS, BR = BR_, W = W_, G = ROWS / BR_, P = ROWS * COLS, RS = COLS + 2;
   // HS ("half split"): a band of ONE patch tile; the waves that would own the second tile take the second
-  // transform-row half of every layer instead (wave = (half h, cout tile ct)), the halves are added through LDS
+  // transform-row half of every layer instead (wave = (half h, cout tile ct)); the two waves of a pair hand each other
+  // their half's outputs through LDS (both end up with the sum) and share the rest of the step by pixel row: wave h
+  // gathers, publishes, normalises and emits row h of every 2x2 patch (the GroupNorm sums stay with h = 0: same order)
   static constexpr bool HS = HS_;
-  static constexpr int COMB = HS_ ? 2 * 64 * 16 : 0;              // [cout tile][r][lane][e]: half 1's outputs
+  static constexpr int COMB = HS_ ? 2 * 2 * 64 * 16 : 0;          // [half][cout tile][r][lane][e]
   static constexpr int PCOLS = COLS / 2, PROWS = BR_ / 2, NPATCH = PROWS * PCOLS;
   static constexpr int AROWS = BR_ + 2, CSA = CSA_;             // layer input planes: rows, channel stride
   static constexpr int WSLOTS = BR_ + 2 * W_ + 1, CSW = WSLOTS * RS + 2;   // gather window: row slots, channel stride
@@ -314,7 +316,11 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
   const int k = lane >> 4;
   const int q = pt * 16 + (lane & 15);
   const bool qvalid = q < GEO::NPATCH;
-  const bool pvalid = qvalid && (!HS || hsel == 0);     // owner of the patch's outputs (gather, statistics, epilogue)
+  const bool pvalid = qvalid;
+  const bool sum_owner = qvalid && (!HS || hsel == 0);  // whose GroupNorm partial sums count (one wave per patch tile)
+  // pixel rows of a 2x2 patch this wave gathers / publishes / normalises / emits (wave-uniform): both, or row hsel
+  const bool row0 = !HS || hsel == 0, row1 = !HS || hsel == 1;
+  auto mine = [&](int e) { return (e >> 1) ? row1 : row0; };
   const int qq = qvalid ? q : 0;
   const int prow = qq / GEO::PCOLS, pc = qq - prow * GEO::PCOLS;
   const bool tile_live = HS || pt * 16 < GEO::NPATCH;    // wave-uniform
@@ -323,8 +329,8 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
   const int cbase = ct * 16 + k * 4;                  // this lane's couts: cbase + r
   const int gown = ct * 2 + (k >> 1);                 // their GroupNorm group
   const int py0 = lo + 2 * prow, px0 = 2 * pc;
-  const bool top_pub = pvalid && prow == 0 && m > 0;                  // this patch's first pixel row faces band m - 1
-  const bool bot_pub = pvalid && prow == GEO::PROWS - 1 && m < G - 1;   // its second pixel row faces band m + 1
+  const bool top_pub = pvalid && row0 && prow == 0 && m > 0;                  // this patch's first pixel row faces band m - 1
+  const bool bot_pub = pvalid && row1 && prow == GEO::PROWS - 1 && m < G - 1;   // its second pixel row faces band m + 1
   const float inv_n = 1.0f / (8.0f * (float)P);
   // halo role: item i = tid + 256 it -> (side hs: 0 = row lo-1, 1 = row hi+1; channels 8 hcg .. + 7; column hx)
   int hs[HI], hx[HI], hcg[HI], hoff[HI];
@@ -371,17 +377,19 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         gu64 *g = Fg + (size_t)(cbase + r) * P + py0 * cols + px0;
-        cb_publish2(g, d + 1, f[r][0], f[r][1]);
-        cb_publish2(g + cols, d + 1, f[r][2], f[r][3]);
+        if (row0) cb_publish2(g, d + 1, f[r][0], f[r][1]);
+        if (row1) cb_publish2(g + cols, d + 1, f[r][2], f[r][3]);
       }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float *dst = win + (cbase + r) * CSW + (W + 2 * prow) * RS + px0 + 1;
-      dst[0] = f[r][0], dst[1] = f[r][1], dst[RS] = f[r][2], dst[RS + 1] = f[r][3];
+      if (row0) dst[0] = f[r][0], dst[1] = f[r][1];
+      if (row1) dst[RS] = f[r][2], dst[RS + 1] = f[r][3];
       float *cdst = cd + (r * D) * P + slice_off;
 #pragma unroll
       for (int a2 = 0; a2 < 2; ++a2) {
+        if (!(a2 ? row1 : row0)) continue;
         float2v c2;
         c2.x = out[a2 * 2] ? 0.0f : fabsf(fl[r][a2].x - f[r][a2 * 2]);
         c2.y = out[a2 * 2 + 1] ? 0.0f : fabsf(fl[r][a2].y - f[r][a2 * 2 + 1]);
@@ -391,6 +399,7 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
         float *fdst = fd + (r * D) * P + slice_off;
 #pragma unroll
         for (int a2 = 0; a2 < 2; ++a2) {
+          if (!(a2 ? row1 : row0)) continue;
           float2v f2;
           f2.x = out[a2 * 2] ? 0.0f : f[r][a2 * 2];
           f2.y = out[a2 * 2 + 1] ? 0.0f : f[r][a2 * 2 + 1];
@@ -403,7 +412,8 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int a2 = 0; a2 < 2; ++a2) fl[r][a2] = *reinterpret_cast<const float2 *>(fl_lane + (size_t)r * P + a2 * cols);
+      for (int a2 = 0; a2 < 2; ++a2)
+        if (a2 ? row1 : row0) fl[r][a2] = *reinterpret_cast<const float2 *>(fl_lane + (size_t)r * P + a2 * cols);
   };
 
   // ---- plane 0: mask from the plane's homography, features from the extractor ---------------------
@@ -419,7 +429,7 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
   {
     const float *f0 = a.f0 + (size_t)n * 32 * P + (size_t)cbase * P + py0 * cols + px0;
     float f[4][4];
-    float2 fl[4][2];
+    float2 fl[4][2] = {};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float2 t0 = *reinterpret_cast<const float2 *>(f0 + (size_t)r * P);
@@ -491,7 +501,7 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
     const int need_lo = range[par * 2], need_hi = range[par * 2 + 1];
     const bool fast = !(flags & 1) && need_lo >= wlo && need_hi <= wlo + GEO::WSLOTS - 1;   // workgroup-uniform
 
-    float fp[4][4], hv[HI][8];
+    float fp[4][4] = {}, hv[HI][8];   // (half split: only the wave's own pixel row is gathered, the rest stays zero)
     float tw[4 + HI][4];
     int to[4 + HI], tdy[4 + HI];
     auto footprints = [&]() {   // this thread's pixels: own 2x2 patch (ext rows 1 + 2 prow + a) and its halo pixels
@@ -555,14 +565,14 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
       cb_barrier();   // B2: window complete
       // A2 gather.  The +1 column tap is read unclamped: where the clamp would act its weight is exactly zero and the
       // slot read is the zero halo column; the +1 row tap re-reads row y0 there (weight exactly zero as well).
-      if (!HS || hsel == 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < 4; ++e) {
+        if (!mine(e)) continue;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float *fc = win + (cbase + r) * CSW + (to[e] - wlo * RS);
-            fp[r][e] = fc[0] * tw[e][0] + fc[1] * tw[e][1] + fc[tdy[e]] * tw[e][2] + fc[tdy[e] + 1] * tw[e][3];
-          }
+        for (int r = 0; r < 4; ++r) {
+          const float *fc = win + (cbase + r) * CSW + (to[e] - wlo * RS);
+          fp[r][e] = fc[0] * tw[e][0] + fc[1] * tw[e][1] + fc[tdy[e]] * tw[e][2] + fc[tdy[e] + 1] * tw[e][3];
+        }
       }
 #pragma unroll
       for (int it = 0; it < HI; ++it) {
@@ -583,6 +593,7 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
       footprints();
 #pragma unroll
       for (int e = 0; e < 4 + HI; ++e) {
+        if (e < 4 && !mine(e)) continue;   // (wave-uniform: the other wave of the pair gathers that pixel row)
         const int it = e < 4 ? 0 : e - 4;
         const bool act_e = e < 4 ? pvalid : hvalid[it];
         const int y0 = to[e] / RS, x0 = to[e] - y0 * RS - 1;
@@ -618,7 +629,8 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float *dst = act + (3 + cbase + r) * CSA + ob;
-        dst[0] = fp[r][0], dst[1] = fp[r][1], dst[RS] = fp[r][2], dst[RS + 1] = fp[r][3];
+        if (row0) dst[0] = fp[r][0], dst[1] = fp[r][1];
+        if (row1) dst[RS] = fp[r][2], dst[RS + 1] = fp[r][3];
       }
     }
 #pragma unroll
@@ -648,24 +660,21 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
       constexpr int NC = decltype(nc)::value;
       if constexpr (HS) {
         if (hsel == 0) band_layer<NC, CSA, RS, 0>(act, U, ct, wb, lane, y);
-        else {
-          band_layer<NC, CSA, RS, 1>(act, U, ct, wb, lane, y);
+        else band_layer<NC, CSA, RS, 1>(act, U, ct, wb, lane, y);
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            *reinterpret_cast<floatx4 *>(comb + ((ct * 4 + r) * 64 + lane) * 4) = floatx4{y[r][0], y[r][1], y[r][2], y[r][3]};
-        }
+        for (int r = 0; r < 4; ++r)
+          *reinterpret_cast<floatx4 *>(comb + (((hsel * 2 + ct) * 4 + r) * 64 + lane) * 4) =
+              floatx4{y[r][0], y[r][1], y[r][2], y[r][3]};
       } else {
         if (tile_live) band_layer<NC, CSA, RS>(act, U, ct, wb, lane, y);
       }
     };
     auto combine = [&]() {
-      if constexpr (HS) {
-        if (hsel == 0) {
+      if constexpr (HS) {   // (a + b == b + a bit for bit: both waves of the pair hold half 0's outputs + half 1's)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const floatx4 o = *reinterpret_cast<const floatx4 *>(comb + ((ct * 4 + r) * 64 + lane) * 4);
-            y[r][0] += o[0], y[r][1] += o[1], y[r][2] += o[2], y[r][3] += o[3];
-          }
+        for (int r = 0; r < 4; ++r) {
+          const floatx4 o = *reinterpret_cast<const floatx4 *>(comb + ((((hsel ^ 1) * 2 + ct) * 4 + r) * 64 + lane) * 4);
+          y[r][0] += o[0], y[r][1] += o[1], y[r][2] += o[2], y[r][3] += o[3];
         }
       }
     };
@@ -696,7 +705,7 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
           s[1] += dv * dv;
         }
       }
-      if (!pvalid) s[0] = s[1] = 0.f;
+      if (!sum_owner) s[0] = s[1] = 0.f;
       cb_half_wave_sums(s);
       gu64 *Sl = Sg + (size_t)layer * (G * CB_WAVES * 4);
       if ((lane & 31) == 16) {
@@ -823,11 +832,11 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
           const float sft = beta[c] - mean * scl;
           float *dst = act + c * CSA + ob;
           if (residual) {
-            dst[0] += lrelu02(y[r][0] * scl + sft), dst[1] += lrelu02(y[r][1] * scl + sft);
-            dst[RS] += lrelu02(y[r][2] * scl + sft), dst[RS + 1] += lrelu02(y[r][3] * scl + sft);
+            if (row0) dst[0] += lrelu02(y[r][0] * scl + sft), dst[1] += lrelu02(y[r][1] * scl + sft);
+            if (row1) dst[RS] += lrelu02(y[r][2] * scl + sft), dst[RS + 1] += lrelu02(y[r][3] * scl + sft);
           } else {
-            dst[0] = lrelu02(y[r][0] * scl + sft), dst[1] = lrelu02(y[r][1] * scl + sft);
-            dst[RS] = lrelu02(y[r][2] * scl + sft), dst[RS + 1] = lrelu02(y[r][3] * scl + sft);
+            if (row0) dst[0] = lrelu02(y[r][0] * scl + sft), dst[1] = lrelu02(y[r][1] * scl + sft);
+            if (row1) dst[RS] = lrelu02(y[r][2] * scl + sft), dst[RS + 1] = lrelu02(y[r][3] * scl + sft);
           }
         }
       }
@@ -866,7 +875,7 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
     CB_STAMP(10);
 
     layer(std::integral_constant<int, 8>{});
-    float2 fl[4][2];
+    float2 fl[4][2] = {};
     load_left(fl);
     CB_STAMP(11);
     cb_barrier();   // B11
@@ -892,7 +901,7 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
   // wrong numbers behind.  Besides the status word, make that impossible to miss without a host round trip: one NaN in
   // the cost slice turns the regulariser's GroupNorm statistics -- and with them the whole depth map -- into NaN.
   // (written by the thread that owns the element: program order puts it behind the last step's own store)
-  if (__syncthreads_or(dead) && pvalid) costg[(size_t)(D - 1) * P + slice_off] = __builtin_nanf("");
+  if (__syncthreads_or(dead) && pvalid && row0) costg[(size_t)(D - 1) * P + slice_off] = __builtin_nanf("");
 }
 
 // Zero fill of the hand-off workspace (granules + status word) as a plain kernel: inside a captured graph a
