@@ -98,8 +98,10 @@ int mvsn_homography_warp(const float *image, const float *H, int batch, int chan
                                  GroupNorm statistics of the producing launch, the residual pass, the cost slice):
                                  for coarse grids whose planes do not fit one CU (30x40, 32x64), any number of chains
                                  (cols % 4 == 0); AUTO's choice there once the banded form would need three passes */
-#define MVSN_CHAIN_BANDED 4   /* one chain on SEVERAL workgroups: the coarse plane cut into bands of pixel rows (16x32: 4
-                                 bands of 4 rows; 30x40: 15 of 2; 32x64: 16 of 2), Winograd arithmetic of
+#define MVSN_CHAIN_BANDED 4   /* one chain on SEVERAL workgroups: the coarse plane cut into bands of pixel rows (16x32: 8
+                                 bands of 2 rows up to CUs / 8 chains -- every layer split by transform-row half across a
+                                 band's waves -- and 4 bands of 4 rows beyond, bit-identical; 30x40: 15 of 2; 32x64: 16 of
+                                 2), Winograd arithmetic of
                                  MVSN_CHAIN_WINOGRAD; per step the bands hand each other the new feature rows their
                                  gathers reach into, their GroupNorm sums and one halo row per layer as tagged 8-byte
                                  write-through granules -- no fence, no placement assumption.  For few chains in flight
@@ -444,10 +446,11 @@ int mvsn_copy_many(void *const *dst, const void *const *src, const size_t *nbyte
 int mvsn_gather_focal(const float *const *K_pyr, int levels, int batch, float *fx, mvsn_stream_t stream);
 int mvsn_gather_strided(const float *src, int count, long stride, float *dst, mvsn_stream_t stream);
 
-/* Test hook for the banded chain's failure path (process-wide, 0 = off): bit 1 = the last band of every chain never
- * runs (what a shared device can do to a launch whose workgroups must be co-resident); bits 8.. = log2 of the spin
- * limit of a hand-off (default 2^21).  With it the other bands time out: the status word is set, the cost slice carries
- * a NaN (so the depth maps of that forward are NaN), nothing hangs. */
+/* Test hook for the banded chain (process-wide, 0 = off): bit 1 = the last band of every chain never runs (what a
+ * shared device can do to a launch whose workgroups must be co-resident); bits 8.. = log2 of the spin limit of a
+ * hand-off (default 2^21).  With it the other bands time out: the status word is set, the cost slice carries a NaN (so
+ * the depth maps of that forward are NaN), nothing hangs.  Bit 2 (value 4) pins the 4-band plan on 16x32 (the 8-band
+ * half-split plan is compared with it bit for bit); set it before asking for the workspace size. */
 int mvsn_debug_set_band_flags(int flags);
 
 /* Device self-test of the MFMA fragment mapping the conv kernels rely on (A = 16x4, B = 4x16
