@@ -10,8 +10,8 @@ mkdir -p $OUT
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1 | tee $OUT/smoke.txt
 timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
 timeout 300 python bench.py --steps 300 --warmup 5 --no-cpu-baseline --no-tiers --sustain 24 > $OUT/bench_sustain.json 2> /dev/null
-timeout 1200 python tools/soak.py 3000 > $OUT/soak.json 2> $OUT/soak.err
-timeout 600 python tools/soak.py 1000 graphed > $OUT/soak_graphed.json 2>> $OUT/soak.err
+timeout 1200 python tools/soak.py ${SOAK:-3000} > $OUT/soak.json 2> $OUT/soak.err
+timeout 600 python tools/soak.py ${SOAKG:-1000} graphed > $OUT/soak_graphed.json 2>> $OUT/soak.err
 TAG=$TAG timeout 900 bash tools/prof_round.sh > $OUT/prof_round.log 2>&1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o b1 -- python tools/b1_trace.py 1 > $OUT/b1_trace.log 2>&1
