@@ -19,7 +19,9 @@
 // features are re-gathered by both neighbours instead of exchanged).
 //
 // Geometries (template BandGeo<ROWS, COLS, BR, W>; a band holds at most 32 patches of 2x2 pixels = two MFMA tiles):
-//   16x32 (512x256 frames):   4 bands of 4 rows, gather window +-3 rows
+//   16x32 (512x256 frames):   8 bands of 2 rows, "half split" (below), while 8 workgroups per chain fit the chip in one
+//                             pass (<= CUs / 8 chains); 4 bands of 4 rows beyond; gather window +-3 rows.  The two
+//                             plans give the same bits (same arithmetic per output, same GroupNorm records and order)
 //   30x40 (640x480 frames):  15 bands of 2 rows (20 patches: the second tile is a quarter full), window +-3 rows
 //   32x64 (1024x512 frames): 16 bands of 2 rows, window +-1 row (what fits next to one layer of transformed weights)
 //
@@ -37,6 +39,9 @@
 // Work split inside a workgroup: 256 threads = 4 waves, ONE per SIMD (512 registers each); wave (pt, ct) owns patch
 // tile pt of the band (16 consecutive patches, row-major) and cout tile ct.  Per k-step and transform-row half: 8
 // multiplies against the plane-resident kernel's 16 -- the input transform is repeated by the two cout-tile waves.
+// Half split (a band of ONE patch tile): wave (h, ct) runs transform-row half h of every layer for the band's only
+// tile; the pair exchanges its halves' outputs through LDS behind the barrier that follows the layer (both hold
+// half 0 + half 1, the one-wave sum) and shares the rest of the step by pixel row (wave h: row h of every patch).
 //
 // LDS (floats):  U 18432 (one layer's transformed weights, LDS-DMA'd per layer exactly as in chain_wino_kernel)
 //                sparams 224 | red 16 G (every band's, every wave's GroupNorm records of a hand-off) | gstat 32
