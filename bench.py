@@ -38,10 +38,12 @@ GOLDEN_SEED = 7
 # BASELINE.json's configs (config 1 is the CPU plumbing case).  `--config` selects the workload of the timed region;
 # the default line (headline = the configuration the metric is quoted on) also carries the others as `other_configs`.
 # `batch` = reference images per GPU per step; config 3 is stated as batch 8 over 8 GPUs = ONE image per rank.
+# Headline: 256 images = 512 chains = two rounds of one chain per CU, 35 GB of the 288 (measured 128 / 256 / 384 / 512
+# images: 3400-3428 / 3459-3493 / 3528 / 3491-3530 depthmaps/s; the persistent kernels' prologues and tails amortise).
 # Every config has a reference-generated fixture whose input is image 0 of rank 0 (seed = the fixture's).
 CONFIGS = {
     "headline": dict(rows=256, cols=512, D=64, S=2, weights="gta_sfm_150epochs", golden="g2_gta_512x256_d64_s2.npz",
-                     batch=128, what="GTA-SfM-shaped 512x256, D=64 hypotheses, 2 source views, cost-volume filter + 5 refiners"),
+                     batch=256, what="GTA-SfM-shaped 512x256, D=64 hypotheses, 2 source views, cost-volume filter + 5 refiners"),
     "config2": dict(rows=256, cols=512, D=64, S=1, weights="gta_sfm_150epochs", golden="gc2_gta_512x256_d64_s1.npz",
                     batch=128, what="BASELINE config 2: GTA-SfM 2-view, 512x256, D=64, 1 source view"),
     "config3": dict(rows=256, cols=512, D=64, S=5, weights="gta_sfm_150epochs", golden="gc3_gta_512x256_d64_s5.npz",
@@ -377,7 +379,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("MVSN_BENCH_BATCH", "0")),
-                    help="reference images per GPU per step (default: the config's own, 128 for the headline)")
+                    help="reference images per GPU per step (default: the config's own, 256 for the headline)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="headline",
                     help="which BASELINE.json configuration the timed region runs (default: the one the metric is "
                          "quoted on); config3 = 5 source views, one image per GPU")
