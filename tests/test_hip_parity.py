@@ -841,6 +841,39 @@ def test_banded_chain_gather_paths_vs_oracle(kind, N, D, grid):
     assert torch.equal(got["banded"][1], got[other][1])
 
 
+@pytest.mark.parametrize("D", [1, 2, 3])
+@pytest.mark.parametrize("grid", [(16, 32), (30, 40), (32, 64)])
+def test_chain_with_one_to_three_planes_all_forms(grid, D):
+    """Edge of the recurrence (multi_view_stereonet.py:279-290 runs D - 1 steps): D = 1 is plane 0 alone (no step, no
+    hand-off, the cost slice straight from the extractor's features), D = 2 one step, D = 3 the first step whose
+    gather reads a plane this launch produced.  Every form the grid has a plan for, against the oracle."""
+    w = load_weights("gta_sfm_150epochs")
+    net = net_for("gta_sfm_150epochs")
+    eng = net.engine()
+    r4, c4 = grid
+    N = 3
+    g = torch.Generator().manual_seed(41)
+    H, Hinc = _motion_family(N, D, "mixed", seed=12)
+    src4 = torch.rand(N, 3, r4, c4, generator=g) * 2 - 1
+    F0, FL = torch.randn(N, 32, r4, c4, generator=g), torch.randn(N, 32, r4, c4, generator=g)
+    fvol_ref, cost_ref, mask_ref = _oracle_chain(w, src4, H, Hinc, F0, FL)
+    dev = [x.to(DEV) for x in (src4, H, Hinc, F0, FL)]
+    forms = ["direct", "banded"] + (["winograd"] if grid == (16, 32) else ["stepwise"])
+    try:
+        for form in forms:
+            net.options.chain_form = form
+            cost, mask, fvol = eng.incremental_cost_volume(*dev, want_features=True)
+            torch.cuda.synchronize()
+            assert eng.chain_status() == 0, form
+            assert cost.shape == (N, 32, D, r4, c4) and mask.shape == (N, D, r4, c4)
+            assert int((mask.cpu() != mask_ref).sum()) == 0, form
+            for name, a, b in (("features", fvol.cpu(), fvol_ref), ("cost", cost.cpu(), cost_ref)):
+                mean_rel, max_rel = rel_err(a, b)
+                assert mean_rel < 1e-5 and max_rel < 1e-4, (form, D, name, mean_rel, max_rel)
+    finally:
+        net.options.chain_form = "auto"
+
+
 @pytest.mark.parametrize("kind,N,D", [("small", 1, 64), ("mixed", 5, 20), ("vertical", 2, 9), ("small", 32, 6), ("mixed", 17, 7)])
 def test_banded_chain_half_split_is_bit_identical_to_four_bands(kind, N, D):
     """16x32 has two banded plans: up to CUs / 8 chains run on 8 bands of 2 rows whose waves split every layer by
