@@ -706,7 +706,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   int step = 0, mm_stage = 0;   // mm_stage: U ring slot of `step` (VOL)
   for (int round = 0; round < my_items; ++round) {
 #ifdef MVSN_WN_STAMPS
-    dbg_on = round >= 3;   // steady state: skip the first tiles
+    dbg_on = round >= 3 || my_items < 4;   // steady state: skip the first tiles (few tiles: the launch's whole life)
 #endif
     const int flat = g.rev ? total - 1 - (round * G + slot) : round * G + slot;
     const int n = flat / ptiles;
