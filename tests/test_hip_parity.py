@@ -1017,7 +1017,9 @@ def test_banded_chain_in_passes(grid, N, D):
         net.options.chain_form = "auto"
 
 
-@pytest.mark.parametrize("grid,N,D", [((16, 32), 5, 64), ((30, 40), 3, 24), ((32, 64), 4, 20)])
+@pytest.mark.parametrize("grid,N,D", [((16, 32), 5, 64), ((30, 40), 3, 24), ((32, 64), 4, 20),
+                                      ((16, 32), 32, 12),    # 8 bands x 32 chains: every CU of the chip takes part
+                                      ((16, 32), 64, 8)])    # 4 bands x 64 chains: the same
 def test_banded_chain_hand_offs_under_uneven_load(grid, N, D):
     """The inter-workgroup hand-offs (tagged granules) must not depend on timing or placement: the same launch
     repeated while a second stream keeps part of the chip busy with streaming copies of varying size must return
