@@ -976,7 +976,9 @@ def test_chain_groupnorm_single_pass_stays_accurate(case, D, form):
 def test_banded_chain_in_passes(grid, N, D):
     """More chains than fit the chip at one workgroup per band: the banded call runs consecutive passes over one
     workspace (17 / 16 / 64 chains per pass on an MI355X).  Every chain must come out exactly as when it runs in a call
-    of its own (chains are independent: `torch.equal`), agree with another form of the library, and leave status 0;
+    of its own (chains are independent: `torch.equal` -- on 16x32 that call of 6 chains runs the 8-band half-split plan
+    while the 70-chain call runs 4 bands: the two plans must agree bit for bit), agree with another form of the library,
+    and leave status 0;
     AUTO picks the banded form for up to two passes where no plane-resident plan exists."""
     net = net_for("gta_sfm_150epochs")
     eng = net.engine()
