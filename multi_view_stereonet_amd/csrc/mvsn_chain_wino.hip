@@ -364,7 +364,8 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a, MVS
   // pixels) outputs as 8-byte pieces (L2 hits: 64 KB per reference image, shared by its S chains; the cost stores
   // are streaming and do not evict them) ahead of the barrier that ends the last layer
   write_cost_slice(0);
-  const float *fl_lane = flp + (size_t)cbase * P + (2 * pr) * cols + 2 * pc;
+  // (qq = 0 for lanes without a patch: always a valid address, the loads below are unconditional)
+  int fl_off = cbase * P + (2 * pr) * cols + 2 * pc;   // (an offset, not a pointer: an opaque pointer loses its address space)
   int slice_off = (cbase * D) * P + (2 * pr) * cols + 2 * pc;   // this lane's origin inside a chain's cost volume
 
   // ---- the recurrence ------------------------------------------------------------------------
@@ -379,7 +380,13 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a, MVS
   for (int d = 1; d < D; ++d) {
     // per-thread index arithmetic of the pixel / slice loops is recomputed every step from an opaque copy of the
     // thread id: hoisted out of the loop it would occupy dozens of VGPRs across the convolutions (and spill)
-    asm volatile("" : "+v"(tid), "+v"(lane16), "+v"(slice_off));
+    // ... and the left-feature pointer: the sixteen 64-bit addresses derived from it (offsets beyond the immediate
+    // range) were hoisted and spilled, and every reload in front of a load is an s_waitcnt vmcnt(0) -- the sixteen
+    // loads ran one round trip after the other (9 k cycles per step); likewise the lane id the GroupNorm's LDS
+    // addresses derive from (their reloads waited for the next layer's U to land)
+    asm volatile("" : "+v"(tid), "+v"(lane16), "+v"(slice_off), "+v"(fl_off));
+    const int lane_s = tid & 63;
+    const float *fl_lane = flp + fl_off;
     CW_STAMP(0);
 
     // A1: image plane d and its mask (global gathers; the 6 KB source image stays in L1/L2)
@@ -473,7 +480,7 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a, MVS
     CW_WSTAMP(6);
     CW_STAMP(5);
 
-    wino_groupnorm_lrelu(y, pvalid && tile_live, inv_n, shift0, bias0, gn0w, gn0b, red, lane, wave);
+    wino_groupnorm_lrelu(y, pvalid && tile_live, inv_n, shift0, bias0, gn0w, gn0b, red, lane_s, wave);
     if (pvalid) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
@@ -496,7 +503,7 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a, MVS
     dma_u(upk + CW_U0_FLOATS + CW_U1_FLOATS, 8);
     CW_STAMP(8);
 
-    wino_groupnorm_lrelu(y, pvalid && tile_live, inv_n, shift1, bias1, gn1w, gn1b, red + CW_RED_FLOATS / 2, lane, wave);
+    wino_groupnorm_lrelu(y, pvalid && tile_live, inv_n, shift1, bias1, gn1w, gn1b, red + CW_RED_FLOATS / 2, lane_s, wave);
     if (pvalid) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
@@ -518,8 +525,7 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a, MVS
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int a2 = 0; a2 < 2; ++a2)
-          fl[ct][r][a2] = pvalid ? *reinterpret_cast<const float2 *>(fl_lane + (size_t)(ct * 16 + r) * P + a2 * cols)
-                                 : float2{0.f, 0.f};
+          fl[ct][r][a2] = *reinterpret_cast<const float2 *>(fl_lane + (size_t)(ct * 16 + r) * P + a2 * cols);
     CW_STAMP(10);
     cw_barrier();  // B11
     dma_u(upk, 9);    // conv0 of the next step
