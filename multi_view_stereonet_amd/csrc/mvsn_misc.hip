@@ -499,7 +499,12 @@ constexpr int T3_LDS_FLOATS = 27 * T3_SLOTS;          // 77,760 bytes: two workg
 
 // XF: the input is a raw convolution output whose LeakyReLU(GroupNorm(.)) is applied on load (two VALU per
 // element behind an HBM-bound stream) -- the regulariser's last normalise/activate pass never touches HBM.
-template <bool XF>
+// WHOLE: the plane IS the tile (16 x 32, the headline's coarse grid): the 208 halo slots of the 720 lie outside the
+// volume for every plane -- their rows of P are zeroed once and never written, the products cover the 512 real slots
+// only (two full 64-slot groups per wave instead of three partly idle ones: a third fewer multiplies -- at 22 flop per
+// input byte the tap GEMM needs most of the fp32 matrix pipe at the HBM rate -- and every lane of every load carries
+// data), and a plane's two groups are requested while the previous plane is gathered.
+template <bool XF, bool WHOLE>
 __global__ __launch_bounds__(256, 2) void conv_to1_3d_mfma_kernel(const float *__restrict__ in, const float *__restrict__ w,
                                                                   const float *__restrict__ bias,
                                                                   const float *__restrict__ in_stats,
@@ -539,14 +544,25 @@ __global__ __launch_bounds__(256, 2) void conv_to1_3d_mfma_kernel(const float *_
   }
 
   // this lane's slots: group g = wave + 4 u, slots 64 g + 4 (lane&15) .. + 3
-  constexpr int GPW = T3_GROUPS / 4;   // 3
-  int goff[GPW];
+  constexpr int GPW = WHOLE ? 2 : T3_GROUPS / 4;   // 3 (WHOLE: 8 groups of 64 REAL slots, 2 per wave)
+  int goff[GPW];   // global offset of the lane's four slots inside a plane (-1: outside the volume)
+  int lslot[GPW];  // their first slot in P (-1: beyond the tile)
 #pragma unroll
   for (int u = 0; u < GPW; ++u) {
     const int s0 = (wave + 4 * u) * 64 + 4 * (lane & 15);
-    const int row = s0 / T3_XS, col = s0 - row * T3_XS;
-    const int gy = y0 - 1 + row, gx = x0 - 4 + col;
-    goff[u] = (s0 < T3_SLOTS && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
+    if constexpr (WHOLE) {   // H == 16, W == 32, one tile: pixel index == plane offset
+      goff[u] = s0;
+      lslot[u] = ((s0 >> 5) + 1) * T3_XS + (s0 & 31) + 4;
+    } else {
+      const int row = s0 / T3_XS, col = s0 - row * T3_XS;
+      const int gy = y0 - 1 + row, gx = x0 - 4 + col;
+      goff[u] = (s0 < T3_SLOTS && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
+      lslot[u] = s0 < T3_SLOTS ? s0 : -1;
+    }
+  }
+  if constexpr (WHOLE) {   // halo slots of every tap row: zero, once
+    for (int i = tid * 4; i < T3_LDS_FLOATS; i += 1024) *reinterpret_cast<floatx4 *>(P + i) = floatx4{0.f, 0.f, 0.f, 0.f};
+    t3_barrier();
   }
 
   // gather side: this thread's two output pixels (xx even)
@@ -579,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void conv_to1_3d_mfma_kernel(const float *_
       }
     }
   };
-  static_assert(GPW == 3, "the plane pipeline below is written for three slot groups per wave");
+  static_assert(GPW == (WHOLE ? 2 : 3), "the plane pipeline below is written for three (WHOLE: two) slot groups per wave");
   const int zfirst = zb - 1 < 0 ? 0 : zb - 1, zlast = ze < D ? ze : D - 1;   // input planes inside the volume
   if (zfirst <= zlast) {
     load_group(zfirst, 0, bfr[0]);
@@ -588,8 +604,10 @@ __global__ __launch_bounds__(256, 2) void conv_to1_3d_mfma_kernel(const float *_
   auto plane_products = [&](int z) {
 #pragma unroll
     for (int u = 0; u < GPW; ++u) {
-      if (u == 0) load_group(z, 2, bfr[2]);
-      else if (z + 1 <= zlast) load_group(z + 1, u - 1, bfr[u - 1]);   // next plane: in flight across the barriers below
+      if constexpr (!WHOLE) {
+        if (u == 0) load_group(z, 2, bfr[2]);
+        else if (z + 1 <= zlast) load_group(z + 1, u - 1, bfr[u - 1]);   // next plane: in flight across the barriers below
+      }
       activate(u, bfr[u]);
       floatx4 d[2][4];
 #pragma unroll
@@ -603,9 +621,14 @@ __global__ __launch_bounds__(256, 2) void conv_to1_3d_mfma_kernel(const float *_
           d[0][p] = mfma16x16x4(a[0][ks], bfr[u][ks][p], d[0][p]);
           d[1][p] = mfma16x16x4(a[1][ks], bfr[u][ks][p], d[1][p]);
         }
+      // WHOLE: the group's registers are free again -- the same group of the next plane travels during the rest of this
+      // plane (the other group's multiplies, the gather and both barriers)
+      if constexpr (WHOLE) {
+        if (z + 1 <= zlast) load_group(z + 1, u, bfr[u]);
+      }
       // lane holds taps 16 t + 4 (lane>>4) + r of slots s0 .. s0 + 3
-      const int s0 = (wave + 4 * u) * 64 + 4 * (lane & 15);
-      if (s0 < T3_SLOTS) {
+      const int s0 = lslot[u];
+      if (s0 >= 0) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -791,18 +814,24 @@ static int conv_to1_volume(const float *in, const float *weight, const float *bi
   const int nz = (depth + zslab - 1) / zslab;
   MVSN_REQUIRE(n <= 65535 && nz <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_to1: grid");
   const size_t lds = (size_t)T3_LDS_FLOATS * sizeof(float);
+  const bool whole = rows == T3_TY && cols == T3_TX;   // the plane is the tile
+#define MVSN_TO1_3D_LAUNCH(XF_, WHOLE_)                                                                                \
+  do {                                                                                                                 \
+    static LdsOptIn opt;                                                                                               \
+    if (int rc = ensure_lds(opt, (const void *)conv_to1_3d_mfma_kernel<XF_, WHOLE_>, lds, "mvsn_conv_to1")) return rc; \
+    hipLaunchKernelGGL((conv_to1_3d_mfma_kernel<XF_, WHOLE_>), dim3(nty * ntx, nz, n), dim3(256), lds,                 \
+                       (hipStream_t)stream, in, weight, bias, in_stats, in_gamma, in_beta, depth, rows, cols, ntx,     \
+                       zslab, out);                                                                                    \
+  } while (0)
   if (in_stats) {
-    static LdsOptIn opt;
-    if (int rc = ensure_lds(opt, (const void *)conv_to1_3d_mfma_kernel<true>, lds, "mvsn_conv_to1")) return rc;
-    hipLaunchKernelGGL(conv_to1_3d_mfma_kernel<true>, dim3(nty * ntx, nz, n), dim3(256), lds, (hipStream_t)stream, in,
-                       weight, bias, in_stats, in_gamma, in_beta, depth, rows, cols, ntx, zslab, out);
+    if (whole) MVSN_TO1_3D_LAUNCH(true, true);
+    else MVSN_TO1_3D_LAUNCH(true, false);
   } else {
-    static LdsOptIn opt;
-    if (int rc = ensure_lds(opt, (const void *)conv_to1_3d_mfma_kernel<false>, lds, "mvsn_conv_to1")) return rc;
-    hipLaunchKernelGGL(conv_to1_3d_mfma_kernel<false>, dim3(nty * ntx, nz, n), dim3(256), lds, (hipStream_t)stream, in,
-                       weight, bias, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, depth,
-                       rows, cols, ntx, zslab, out);
+    in_gamma = in_beta = nullptr;
+    if (whole) MVSN_TO1_3D_LAUNCH(false, true);
+    else MVSN_TO1_3D_LAUNCH(false, false);
   }
+#undef MVSN_TO1_3D_LAUNCH
   return mvsn::check_launch("mvsn_conv_to1(volume)");
 }
 
