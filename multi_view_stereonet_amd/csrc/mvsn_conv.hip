@@ -766,8 +766,9 @@ __global__ __launch_bounds__(CV_THREADS, MODE <= 1 ? 4 : 2) void conv_dma_kernel
 constexpr int HD_TY = 8, HD_TX = 32, HD_ROWS = 2 * HD_TY + 3, HD_XS = 2 * HD_TX + 8;   // 19 rows of 72 floats
 constexpr int HD_CST = HD_ROWS * HD_XS + 4;                                           // channel stride (floats)
 constexpr int HD_KSTEPS = 19;
+static_assert(3 * HD_CST < 65536, "k-step offsets are packed as 16-bit values");
 
-__global__ __launch_bounds__(256) void conv5x5s2_head_kernel(const float *__restrict__ in, const float *__restrict__ wpk,
+__global__ __launch_bounds__(256, 4) void conv5x5s2_head_kernel(const float *__restrict__ in, const float *__restrict__ wpk,
                                                              const float *__restrict__ bias, int H, int W, int Ho,
                                                              int Wo, int ntx, int tiles, float *__restrict__ out) {
   __shared__ __attribute__((aligned(16))) float tile[3 * HD_CST];
@@ -782,7 +783,7 @@ __global__ __launch_bounds__(256) void conv5x5s2_head_kernel(const float *__rest
   // the LDS offset of this lane's k inside the tile
   const int kk = lane >> 4, cl = lane & 15;
   float wf[HD_KSTEPS][2];
-  int koff[HD_KSTEPS];
+  unsigned kpk[(HD_KSTEPS + 1) / 2] = {};   // tile offsets of the k-steps, two 16-bit values per register
 #pragma unroll
   for (int ks = 0; ks < HD_KSTEPS; ++ks) {
     const int k = 4 * ks + kk;
@@ -790,7 +791,8 @@ __global__ __launch_bounds__(256) void conv5x5s2_head_kernel(const float *__rest
     const int ch = live ? k / 25 : 0, tap = live ? k - ch * 25 : 0;
     wf[ks][0] = live ? wpk[tap * 128 + ch * 16 + cl] : 0.0f;
     wf[ks][1] = live ? wpk[tap * 128 + 64 + ch * 16 + cl] : 0.0f;
-    koff[ks] = ch * HD_CST + (tap / 5) * HD_XS + (tap % 5) + 2;   // input column of tap tx: 2 xx + tx - 2 -> tile column + 2
+    const unsigned ko = ch * HD_CST + (tap / 5) * HD_XS + (tap % 5) + 2;   // input column of tap tx: 2 xx + tx - 2 -> tile column + 2
+    kpk[ks >> 1] |= (ks & 1) ? ko << 16 : ko;
   }
   float *outn = out + (size_t)n * 32 * Ho * Wo;
 
@@ -824,9 +826,10 @@ __global__ __launch_bounds__(256) void conv5x5s2_head_kernel(const float *__rest
   }
 #pragma unroll
   for (int ks = 0; ks < HD_KSTEPS; ++ks) {
+    const int ko = (ks & 1) ? (int)(kpk[ks >> 1] >> 16) : (int)(kpk[ks >> 1] & 0xffffu);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float a = tile[pbase[j] + koff[ks]];
+      const float a = tile[pbase[j] + ko];
       acc[j][0] = mfma16x16x4(a, wf[ks][0], acc[j][0]);
       acc[j][1] = mfma16x16x4(a, wf[ks][1], acc[j][1]);
     }
@@ -1079,6 +1082,8 @@ extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, co
     MVSN_REQUIRE(desc->n <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_forward: batch too large for one launch");
     const int Ho = (desc->rows - 1) / 2 + 1, Wo = (desc->cols - 1) / 2 + 1;
     const int nty = (Ho + HD_TY - 1) / HD_TY, ntx = (Wo + HD_TX - 1) / HD_TX, tiles = nty * ntx;
+    // (__launch_bounds__(256, 4): 128 VGPRs -- the k-step offsets packed two per register -- so that FOUR of these
+    // workgroups share a CU, 156 VGPRs allowed three: 2.10 -> 1.83 ms on the bench's 768 frames)
     // one tile per workgroup: measured 0.84 ms for the 384-frame batch against 1.02 ms with ~8 persistent
     // workgroups per CU walking 21 tiles each (four short-lived workgroups per CU overlap each other's staging,
     // multiplies and stores; a persistent one serialises them behind its barrier)
