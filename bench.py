@@ -72,14 +72,32 @@ def config_inputs(cfg, batch, rank, device):
     return merged, snu.multi_view_unpack_batch(merged, device, 5), torch.from_numpy(fix["idepth_0"])
 
 
-def l1_against(ref0, got0, golden):
+def per_pixel_rel(ref0, got0):
+    """The contract's reading of "within 1e-3 relative on the final depthmap": |a - ref| / max(|ref|, 1e-3 * mean|ref|)
+    per pixel over ref > 0 (the refiner's final relu clamps the rest to exactly 0); (max, p99.9)."""
+    ref, got = ref0.double().reshape(-1), got0.double().reshape(-1)
+    sel = ref > 0
+    if not bool(sel.any()):
+        return 0.0, 0.0
+    e = ((got - ref).abs() / ref.abs().clamp_min(1e-3 * float(ref.abs().mean())))[sel].sort().values
+    return float(e[-1]), float(e[int(0.999 * (e.numel() - 1))])
+
+
+def l1_against(ref0, got0, golden=None):
     l1 = float((got0 - ref0).abs().mean())
-    return {"l1": l1, "mean_rel": l1 / float(ref0.abs().mean()),
-            "max_rel": float((got0 - ref0).abs().max() / ref0.abs().max()),
-            "reference": f"tests/golden/{golden} (reference PyTorch-CPU forward)"}
+    mx, p999 = per_pixel_rel(ref0, got0)
+    res = {"l1": l1, "mean_rel": l1 / float(ref0.abs().mean()),
+           "max_rel": float((got0 - ref0).abs().max() / ref0.abs().max()),
+           "max_rel_per_pixel": mx, "p999_rel_per_pixel": p999,
+           "rel_definitions": "mean_rel = mean|a-b| / mean|ref|; max_rel = max|a-b| / max|ref|; *_per_pixel = "
+                              "|a-b| / max(|ref|, 1e-3 mean|ref|) over ref > 0 (contract: < 1e-3)"}
+    if golden:
+        res["reference"] = f"tests/golden/{golden} (reference PyTorch-CPU forward)"
+    return res
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 dense peak
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC_FILE = "r03_pmc_traffic.json"   # the latest committed FETCH_SIZE / WRITE_SIZE pass (tools/prof_pmc.sh)
+PMC_TRAFFIC_FILE = "r04_pmc_traffic.json"   # FETCH_SIZE / WRITE_SIZE passes of the bench command (tools/prof_round.sh)
+LEVEL_PMC_FILE = "r04_level_pmc.json"       # ... of the refiner towers level by level (tools/level_profile.py)
 
 
 def make_inputs(batch, first_seed, device):
@@ -151,12 +169,74 @@ def kernel_breakdown(net, inp, d=D):
     return agg
 
 
+def host_cpu_info():
+    """(model name, logical cpus, physical cores) from /proc/cpuinfo (physical = distinct (physical id, core id) pairs)."""
+    model, cores, phys, cur = "unknown", os.cpu_count() or 1, set(), {}
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ":" not in ln:
+                    if cur:
+                        phys.add((cur.get("physical id", "0"), cur.get("core id", str(len(phys)))))
+                    cur = {}
+                    continue
+                k, v = (x.strip() for x in ln.split(":", 1))
+                cur[k] = v
+                if k == "model name":
+                    model = v
+        if cur:
+            phys.add((cur.get("physical id", "0"), cur.get("core id", str(len(phys)))))
+    except OSError:
+        pass
+    return model, cores, (len(phys) or cores)
+
+
+def roofline_by_kernel(agg, total_ms, top=14):
+    """Every arithmetic kernel of the step (refiner launches by LEVEL and dilation, ` L<level>` in the name) against both
+    roofs: launch time from this run's device events; executed flops (Winograd forms: 4/9 of the direct count) against
+    the fp32 MFMA peak; ALGORITHMIC bytes (each tensor of the launch -- and of the pass it carries -- once) against the
+    HBM peak; `binds` = the roof the launch sits closer to.  Counter-measured bytes of the same launches, where a PMC
+    pass of THIS library is committed: profiles/<round>_level_pmc.json (tools/level_profile.py), keyed alike."""
+    pmc = load_profile_json(LEVEL_PMC_FILE) or {}
+    rows = {}
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+        if v["flops"] <= 0 or len(rows) >= top:
+            continue
+        sec = v["ms"] * 1e-3
+        ex = v["flops"] * (4.0 / 9.0 if " wino" in k else 1.0) / sec / 1e12
+        gbs = v["bytes"] / sec / 1e9
+        row = {"launches": v["launches"], "ms_per_step": round(v["ms"], 3), "ms_per_launch": round(v["ms"] / v["launches"], 4),
+               "share_of_step": round(v["ms"] / total_ms, 4), "executed_TFLOPs": round(ex, 1),
+               "frac_of_fp32_mfma_peak": round(ex / PEAK_FP32_MFMA_TFLOPS, 3), "algorithmic_GBps": round(gbs, 0),
+               "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 3)}
+        row["binds"] = "mfma" if row["frac_of_fp32_mfma_peak"] >= row["frac_of_hbm_peak"] else "hbm"
+        t = pmc.get(k)
+        if t:
+            row["pmc"] = t
+        rows[k] = row
+    return rows
+
+
+def load_profile_json(name):
+    """A committed counter file under profiles/ -- only if it was taken with THIS library (its `_library_digest` equals
+    multi_view_stereonet_amd/libmvsn_hip.so.sources); a stale file is refused, never scaled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            data = json.load(f)
+        with open(os.path.join(ROOT, "multi_view_stereonet_amd", "libmvsn_hip.so.sources")) as f:
+            digest = f.read().strip()
+    except (OSError, ValueError):
+        return None
+    return data if data.get("_library_digest") == digest else None
+
+
 def cpu_baseline(cfg, budget_s=15.0):
-    """The oracle (CPU restatement of the reference forward) on the host cores, B=1, same workload."""
+    """The oracle (CPU restatement of the reference forward) on the host cores, B=1, same workload (one
+    thread, all physical cores, and the best thread count of a short sweep -- the latter is `value`)."""
     from oracle import mvsn_oracle as oracle
     w = load_weights(cfg["weights"])
     _, inp, _ = config_inputs(cfg, 1, 0, torch.device("cpu"))
-    cores = os.cpu_count() or 1
+    model, cores, physical = host_cpu_info()
 
     def once():
         t0 = time.time()
@@ -164,6 +244,14 @@ def cpu_baseline(cfg, budget_s=15.0):
                              cfg["D"])
         return time.time() - t0, out
 
+    def at(threads, reps):
+        torch.set_num_threads(threads)
+        once()
+        ts = [once()[0] for _ in range(reps)]
+        return {"threads": threads, "forwards": reps, "mean_ms": round(sum(ts) / reps * 1e3, 1),
+                "depthmaps_per_s": round(reps / sum(ts), 3)}
+
+    one = at(1, 2)
     # torch's intra-op scaling on this small per-image problem peaks well below the core count; take the
     # best of a short sweep and report the thread count actually used
     best, threads = None, 1
@@ -173,6 +261,7 @@ def cpu_baseline(cfg, budget_s=15.0):
         dt = min(once()[0] for _ in range(2))
         if best is None or dt < best:
             best, threads = dt, cand
+    allp = at(physical, 2) if physical not in (1, threads) else None
     torch.set_num_threads(threads)
     once()  # warm-up
     times, t_start = [], time.time()
@@ -180,9 +269,12 @@ def cpu_baseline(cfg, budget_s=15.0):
         dt, out = once()
         times.append(dt)
     mean = sum(times) / len(times)
-    return {"value": 1.0 / mean, "unit": "depthmaps/s", "cores": threads, "kind": "port",
-            "sample": f"{len(times)} forwards of 1 image ({cfg['cols']}x{cfg['rows']}, D={cfg['D']}, S={cfg['S']}, fp32, "
-                      f"torch CPU, {threads} threads of {cores} host cpus), mean {mean * 1e3:.1f} ms"}, out
+    res = {"value": 1.0 / mean, "unit": "depthmaps/s", "cores": threads, "kind": "port",
+           "sample": f"{len(times)} forwards of 1 image ({cfg['cols']}x{cfg['rows']}, D={cfg['D']}, S={cfg['S']}, fp32, "
+                     f"torch CPU, {threads} threads of {cores} host cpus), mean {mean * 1e3:.1f} ms",
+           "cpu_model": model, "logical_cpus": cores, "physical_cores": physical, "one_thread": one,
+           "all_physical_cores": allp if allp is not None else {"threads": physical, "note": "same as `cores`"}}
+    return res, out
 
 
 def self_launch(n):
@@ -493,17 +585,18 @@ def main():
         got0 = idepth[:1].cpu()
         line["l1_vs_ref"] = l1_against(ref0, got0, cfg["golden"])
         traffic, traffic_source = None, None
-        try:   # HBM bytes per launch from the committed PMC passes (profiles/), scaled to this batch
-            with open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)) as f:
-                pmc = json.load(f)
-            t = pmc.get(name)
-            if t:
-                traffic = (t["fetch_bytes_per_chain"] + t["write_bytes_per_chain"]) * B * Sn
-                traffic_source = (f"profiles/{PMC_TRAFFIC_FILE}: FETCH_SIZE + WRITE_SIZE of a separate rocprofv3 --pmc pass "
-                                  f"of this kernel ({pmc.get('_round', 'an earlier round')}), per chain, scaled to this "
-                                  "batch -- a pointer to that pass, NOT a counter read during this run")
-        except OSError:
-            pass
+        # HBM bytes per launch from the committed PMC passes of THIS library (refused when the digest differs)
+        pmc = load_profile_json(PMC_TRAFFIC_FILE)
+        t = (pmc or {}).get(name)
+        if t:
+            traffic = (t["fetch_bytes_per_chain"] + t["write_bytes_per_chain"]) * B * Sn
+            traffic_source = (f"profiles/{PMC_TRAFFIC_FILE}: FETCH_SIZE (x2: gfx950 half-count of 16-byte streaming reads) + "
+                              f"WRITE_SIZE of separate rocprofv3 --pmc passes of the bench command with this library "
+                              f"(digest {pmc['_library_digest'][:12]}, {pmc.get('_chains_per_launch', '?')} chains per launch), "
+                              "per chain x this batch -- a committed pass, NOT a counter read during this run")
+        elif pmc is None:
+            traffic_source = (f"profiles/{PMC_TRAFFIC_FILE} is missing or was taken with another build of the library "
+                              "(digest mismatch): refused")
         line["roofline"] = {"kernel": name, "bound": "mfma", "achieved": tfl, "peak": PEAK_FP32_MFMA_TFLOPS,
                             "unit": "TFLOP/s", "frac": min(fracs), "frac_per_rank": fracs, "traffic": traffic,
                             "traffic_source": traffic_source,
@@ -537,20 +630,17 @@ def main():
                                     "executed_TFLOPs": exec_tfl,
                                     "executed_frac_of_fp32_mfma_peak": exec_tfl / PEAK_FP32_MFMA_TFLOPS,
                                     "share_of_step": ch["ms"] / total_ms}
-            try:
-                with open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)) as f:
-                    t = json.load(f).get("mvsn_incremental_cost_volume")
-                if t and form == "winograd":
-                    line["chain_kernel"]["hbm_traffic_bytes_per_chain"] = {
-                        "fetched": t["fetch_bytes_per_chain"], "written": t["write_bytes_per_chain"],
-                        "algorithmic": t["algorithmic_bytes_per_chain"],
-                        "ratio": (t["fetch_bytes_per_chain"] + t["write_bytes_per_chain"]) /
-                        t["algorithmic_bytes_per_chain"], "source": f"profiles/{PMC_TRAFFIC_FILE} (separate PMC pass)"}
-            except OSError:
-                pass
+            t = (pmc or {}).get("mvsn_incremental_cost_volume")
+            if t and form == "winograd":
+                line["chain_kernel"]["hbm_traffic_bytes_per_chain"] = {
+                    "fetched": t["fetch_bytes_per_chain"], "written": t["write_bytes_per_chain"],
+                    "algorithmic": t["algorithmic_bytes_per_chain"],
+                    "ratio": (t["fetch_bytes_per_chain"] + t["write_bytes_per_chain"]) /
+                    t["algorithmic_bytes_per_chain"], "source": f"profiles/{PMC_TRAFFIC_FILE} (separate PMC pass, this library)"}
         line["kernel_ms_per_step"] = {k: round(v["ms"], 3) for k, v in
-                                      sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]}
+                                      sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:16]}
         line["launches_per_forward"] = int(sum(v["launches"] for v in agg.values()))
+        line["roofline_by_kernel"] = roofline_by_kernel(agg, total_ms)
         if world == 1 and args.sustain > 0:
             windows, t_end = [], time.perf_counter() + args.sustain
             while time.perf_counter() < t_end:
@@ -598,14 +688,12 @@ def main():
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t1
                 got_t = out_t["left_idepthmap_pyr"][0][:1].cpu()
-                l1_t = float((got_t - ref0).abs().mean())
                 agg_t = kernel_breakdown(net, inp, Dn)
                 name_t, dom_t = max(agg_t.items(), key=lambda kv: kv[1]["ms"])
                 line[key] = {
                     "value": B * args.steps / dt, "unit": "depthmaps/s", "ms_per_step": dt / args.steps * 1e3,
                     "dtype": dtype,
-                    "l1_vs_ref": {"l1": l1_t, "mean_rel": l1_t / float(ref0.abs().mean()),
-                                  "max_rel": float((got_t - ref0).abs().max() / ref0.abs().max())},
+                    "l1_vs_ref": {k: v for k, v in l1_against(ref0, got_t).items() if k != "rel_definitions"},
                     "dominant_kernel": name_t, "dominant_kernel_ms": round(dom_t["ms"], 3),
                     "kernel_ms_per_step": {k: round(v["ms"], 3) for k, v in
                                            sorted(agg_t.items(), key=lambda kv: -kv[1]["ms"])[:6]}}

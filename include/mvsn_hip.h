@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVSN_ABI_VERSION 2
+#define MVSN_ABI_VERSION 3
 
 #define MVSN_E_BADARG (-1)      /* null pointer, non-positive size, unsupported channel count */
 #define MVSN_E_TOOLARGE (-2)    /* shape exceeds what the kernel's LDS/global plan supports */
@@ -134,6 +134,26 @@ int mvsn_incremental_cost_volume(const float *src_image_lvl4, const float *H_lvl
                                  int num_idepth_samples, int rows, int cols, float *cost_volume,
                                  uint8_t *mask_volume, float *feature_volume, void *workspace,
                                  size_t workspace_bytes, int form, mvsn_stream_t stream);
+/* The same call with the small-batch default made safe on a SHARED device (ABI 3).  When `form` resolves to
+ * MVSN_CHAIN_BANDED, a second launch follows the banded one(s) on the stream: the single-launch form of the grid (plane-
+ * resident Winograd on 16x32, the direct kernel elsewhere) GATED on the banded status word -- its workgroups read the word
+ * and return at once when it is 0 (a few microseconds), and recompute cost_volume / mask_volume / feature_volume
+ * completely when a hand-off timed out (the banded workgroups were not co-resident).  No host round trip, graph-capturable;
+ * the outputs are valid either way.  `repair_workspace`: mvsn_incremental_cost_volume_repair_workspace_bytes() bytes (0 on
+ * 16x32).  `sticky_status`: optional two 32-bit words in device-VISIBLE memory (device or pinned host memory; plain
+ * system-scope loads / stores by one thread of the repair launch): [0] |= the status of every repaired call, [1] += 1
+ * per repair -- never cleared by the library, so a host that looks at it later (or never synchronises per call) still
+ * learns that the banded form does not fit this device's load.
+ * Other forms: identical to mvsn_incremental_cost_volume.
+ * Replaces: the reference's chain loop as above (multi_view_stereonet.py:279-290) -- which has no failure mode to repair. */
+size_t mvsn_incremental_cost_volume_repair_workspace_bytes(int n_chains, int rows, int cols);
+int mvsn_incremental_cost_volume_guarded(const float *src_image_lvl4, const float *H_lvl4, const float *H_inc,
+                                         const float *plane0_features, const float *left_features,
+                                         const float *refiner_packed, int n_chains, int batch,
+                                         int num_idepth_samples, int rows, int cols, float *cost_volume,
+                                         uint8_t *mask_volume, float *feature_volume, void *workspace,
+                                         size_t workspace_bytes, int form, void *repair_workspace,
+                                         size_t repair_workspace_bytes, unsigned *sticky_status, mvsn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Direct convolution on fp32 MFMA (implicit GEMM, weights = A, activations = B), 2-D or 3-D,

@@ -38,7 +38,7 @@ class TowerDesc(Structure):
 
 CONV_FP32, CONV_BF16X3, CONV_FP32_WINO, CONV_BF16 = 0, 1, 2, 3
 CHAIN_AUTO, CHAIN_DIRECT, CHAIN_WINOGRAD, CHAIN_STEPWISE, CHAIN_BANDED = 0, 1, 2, 3, 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 # name -> (restype, argtypes); mirrors include/mvsn_hip.h one to one
@@ -57,6 +57,9 @@ SIGNATURES = {
     "mvsn_incremental_cost_volume_workspace_bytes_for": (c_size_t, [c_int] * 5),
     "mvsn_incremental_cost_volume_status_offset": (c_size_t, [c_int] * 3),
     "mvsn_incremental_cost_volume": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 4 + [c_size_t, c_int, c_void_p]),
+    "mvsn_incremental_cost_volume_repair_workspace_bytes": (c_size_t, [c_int] * 3),
+    "mvsn_incremental_cost_volume_guarded": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 4 +
+                                             [c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "mvsn_conv_bf16x3_supported": (c_int, [POINTER(ConvDesc)]),
     "mvsn_conv_winograd_supported": (c_int, [POINTER(ConvDesc)]),
     "mvsn_conv_packed_floats": (c_size_t, [POINTER(ConvDesc)]),
@@ -116,12 +119,14 @@ def load():
             "(run `python -m multi_view_stereonet_amd.build` or __graft_entry__.build()). "
             "There is no CPU fallback for the plane-sweep path.")
     lib = ctypes.CDLL(_LIB_PATH)
+    lib.mvsn_abi_version.restype, lib.mvsn_abi_version.argtypes = c_int, []
+    if lib.mvsn_abi_version() != ABI_VERSION:     # (checked first: a stale binary lacks the newer symbols)
+        raise RuntimeError(f"libmvsn_hip.so is ABI version {lib.mvsn_abi_version()}, this package needs {ABI_VERSION}: "
+                           "rebuild it (python -m multi_view_stereonet_amd.build --force)")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the header and the binary disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.mvsn_abi_version() != ABI_VERSION:
-        raise RuntimeError("libmvsn_hip.so ABI version mismatch")
     _lib = lib
     return lib
 

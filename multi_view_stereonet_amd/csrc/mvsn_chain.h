@@ -37,13 +37,44 @@ struct ChainArgs {
   int chain0;            // banded form, launched in passes: global index of this pass's first chain (0 otherwise)
   int ws_chains;         // ... and the number of chains its workspace holds (the status word sits behind them)
   unsigned long long *dbg;  // optional: s_memtime stamps of block 0 / lane 0 at phase boundaries (tuning only)
+  // Repair launch (mvsn_incremental_cost_volume_guarded): `gate` = the status word the banded launch ahead of this one
+  // left behind; the launch runs only if it is non-zero (a hand-off timed out) and then recomputes every output.
+  // `sticky` (optional, device-visible -- e.g. pinned host memory): [0] |= status, [1] += 1 per repair that ran
+  // (one writer per launch; not atomic across concurrent streams -- a lost count still leaves a changed word).
+  const unsigned *gate;
+  unsigned *sticky;
 };
+
+// First statement of a kernel that may be launched as a repair: true = nothing to repair, the workgroup returns.
+// (The status word is read past L1 -- the launch boundary published it, a stale line of an earlier forward must not
+// answer; every thread reads the same word, so the answer is workgroup-uniform.)
+__device__ __forceinline__ bool chain_gate_closed(const ChainArgs &a) {
+  if (a.gate == nullptr) return false;
+  const unsigned st = __hip_atomic_load(a.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (st == 0) return true;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.sticky != nullptr) {
+    // one writer per launch, launches of a stream in order: plain system-scope loads / stores (a read-modify-write
+    // atomic on pinned HOST memory would need PCIe atomics end to end)
+    const unsigned seen = __hip_atomic_load(a.sticky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned count = __hip_atomic_load(a.sticky + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(a.sticky, seen | st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(a.sticky + 1, count + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  return false;
+}
 
 // the chain's buffers as plain pointer arguments behind the struct (MVSN_VIS10, mvsn_common.h)
 #define CHAIN_VISIBLE(a)                                                                                              \
   (const void *)(a).src, (const void *)(a).H, (const void *)(a).Hinc, (const void *)(a).f0, (const void *)(a).fl,     \
       (const void *)(a).packed, (const void *)(a).cost, (const void *)(a).mask, (const void *)(a).fvol,               \
       (const void *)(a).workspace
+
+// ... of a launch that may be a repair: the gate word (inside the banded launch's workspace) takes the slot of this
+// launch's own workspace, which is scratch within the launch and orders nothing between kernels
+#define CHAIN_VISIBLE_G(a)                                                                                            \
+  (const void *)(a).src, (const void *)(a).H, (const void *)(a).Hinc, (const void *)(a).f0, (const void *)(a).fl,     \
+      (const void *)(a).packed, (const void *)(a).cost, (const void *)(a).mask, (const void *)(a).fvol,               \
+      ((a).gate ? (const void *)(a).gate : (const void *)(a).workspace)
 
 // Winograd form: does this coarse grid have a plan (even rows / cols, <= 128 patches, LDS fits)?
 bool chain_wino_supported(int rows, int cols);

@@ -272,6 +272,7 @@ __device__ __forceinline__ void store_weights_to_lds(float *wbuf, const floatx4 
 template <int TP, bool LDS_ACT>
 __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a, MVSN_VIS10) {   // (MVSN_VIS10: mvsn_common.h)
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (chain_gate_closed(a)) return;   // repair launch with nothing to repair (mvsn_chain.h)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = blockIdx.x;
   const int rows = a.rows, cols = a.cols, P = rows * cols, RS = cols + 1, G = RS + 1, CS = a.CS, D = a.D;
@@ -632,12 +633,12 @@ extern "C" int mvsn_debug_set_chain_stamps(void *buf) {
 }
 #endif
 
-extern "C" int mvsn_incremental_cost_volume(const float *src_image_lvl4, const float *H_lvl4, const float *H_inc,
-                                            const float *plane0_features, const float *left_features,
-                                            const float *refiner_packed, int n_chains, int batch,
-                                            int num_idepth_samples, int rows, int cols, float *cost_volume,
-                                            uint8_t *mask_volume, float *feature_volume, void *workspace,
-                                            size_t workspace_bytes, int form, mvsn_stream_t stream) {
+// The chain in `form` (resolved), optionally as a gated repair launch (gate != null: one of the single-launch forms).
+static int chain_run(const float *src_image_lvl4, const float *H_lvl4, const float *H_inc, const float *plane0_features,
+                     const float *left_features, const float *refiner_packed, int n_chains, int batch,
+                     int num_idepth_samples, int rows, int cols, float *cost_volume, uint8_t *mask_volume,
+                     float *feature_volume, void *workspace, size_t workspace_bytes, int form, const unsigned *gate,
+                     unsigned *sticky, mvsn_stream_t stream) {
   using namespace mvsn;
   MVSN_REQUIRE(src_image_lvl4 && H_lvl4 && H_inc && plane0_features && left_features && refiner_packed &&
                    cost_volume && mask_volume,
@@ -656,9 +657,13 @@ extern "C" int mvsn_incremental_cost_volume(const float *src_image_lvl4, const f
                "mvsn_incremental_cost_volume: the banded form has no plan for a %dx%d coarse grid (16x32, 30x40, 32x64)", rows, cols);
   MVSN_REQUIRE(wino || form == MVSN_CHAIN_STEPWISE || form == MVSN_CHAIN_BANDED || TP <= 8, MVSN_E_TOOLARGE,
                "mvsn_incremental_cost_volume: %dx%d coarse grid (%d px) exceeds the 2048 px plan", rows, cols, P);
+  MVSN_REQUIRE(gate == nullptr || wino || form == MVSN_CHAIN_DIRECT, MVSN_E_BADARG,
+               "mvsn_incremental_cost_volume: a repair launch runs the Winograd or the direct form");
   ChainArgs a;
   a.chain0 = 0;
   a.ws_chains = 0;
+  a.gate = gate;
+  a.sticky = sticky;
   a.src = src_image_lvl4;
   a.H = H_lvl4;
   a.Hinc = H_inc;
@@ -702,7 +707,7 @@ extern "C" int mvsn_incremental_cost_volume(const float *src_image_lvl4, const f
     auto kern = chain_kernel<TPV, LDSV>;                                                                       \
     static LdsOptIn opt;                                                                                       \
     if (int rc = ensure_lds(opt, (const void *)kern, lds, "mvsn_incremental_cost_volume")) return rc;          \
-    hipLaunchKernelGGL(kern, dim3(n_chains), dim3(CH_THREADS), lds, (hipStream_t)stream, a, CHAIN_VISIBLE(a));    \
+    hipLaunchKernelGGL(kern, dim3(n_chains), dim3(CH_THREADS), lds, (hipStream_t)stream, a, CHAIN_VISIBLE_G(a));    \
   } while (0)
 
   MVSN_REQUIRE(!lds_act || TP <= 3, MVSN_E_TOOLARGE, "mvsn_incremental_cost_volume: internal plan error");
@@ -726,4 +731,52 @@ extern "C" int mvsn_incremental_cost_volume(const float *src_image_lvl4, const f
   }
 #undef MVSN_CHAIN_LAUNCH
   return check_launch("mvsn_incremental_cost_volume");
+}
+
+extern "C" int mvsn_incremental_cost_volume(const float *src_image_lvl4, const float *H_lvl4, const float *H_inc,
+                                            const float *plane0_features, const float *left_features,
+                                            const float *refiner_packed, int n_chains, int batch,
+                                            int num_idepth_samples, int rows, int cols, float *cost_volume,
+                                            uint8_t *mask_volume, float *feature_volume, void *workspace,
+                                            size_t workspace_bytes, int form, mvsn_stream_t stream) {
+  return chain_run(src_image_lvl4, H_lvl4, H_inc, plane0_features, left_features, refiner_packed, n_chains, batch,
+                   num_idepth_samples, rows, cols, cost_volume, mask_volume, feature_volume, workspace, workspace_bytes,
+                   form, nullptr, nullptr, stream);
+}
+
+// The single-launch form a banded call is repaired with: the plane-resident Winograd kernel where the grid has that plan
+// (16x32), the direct kernel (planes in a global workspace) elsewhere.
+static int chain_repair_form(int rows, int cols) {
+  return mvsn::chain_wino_supported(rows, cols) ? MVSN_CHAIN_WINOGRAD : MVSN_CHAIN_DIRECT;
+}
+
+extern "C" size_t mvsn_incremental_cost_volume_repair_workspace_bytes(int n_chains, int rows, int cols) {
+  if (n_chains <= 0 || rows <= 0 || cols <= 0) return 0;
+  if (chain_repair_form(rows, cols) == MVSN_CHAIN_WINOGRAD) return 0;
+  return mvsn_incremental_cost_volume_workspace_bytes(n_chains, rows, cols);
+}
+
+extern "C" int mvsn_incremental_cost_volume_guarded(const float *src_image_lvl4, const float *H_lvl4, const float *H_inc,
+                                                    const float *plane0_features, const float *left_features,
+                                                    const float *refiner_packed, int n_chains, int batch,
+                                                    int num_idepth_samples, int rows, int cols, float *cost_volume,
+                                                    uint8_t *mask_volume, float *feature_volume, void *workspace,
+                                                    size_t workspace_bytes, int form, void *repair_workspace,
+                                                    size_t repair_workspace_bytes, unsigned *sticky_status,
+                                                    mvsn_stream_t stream) {
+  using namespace mvsn;
+  if (form == MVSN_CHAIN_AUTO && n_chains > 0 && rows > 0 && cols > 0) form = chain_auto_form(n_chains, rows, cols);
+  if (int rc = chain_run(src_image_lvl4, H_lvl4, H_inc, plane0_features, left_features, refiner_packed, n_chains, batch,
+                         num_idepth_samples, rows, cols, cost_volume, mask_volume, feature_volume, workspace,
+                         workspace_bytes, form, nullptr, nullptr, stream))
+    return rc;
+  if (form != MVSN_CHAIN_BANDED) return 0;   // the other forms have no inter-workgroup hand-offs to time out
+  const size_t need = mvsn_incremental_cost_volume_repair_workspace_bytes(n_chains, rows, cols);
+  MVSN_REQUIRE(need == 0 || (repair_workspace && repair_workspace_bytes >= need), MVSN_E_WORKSPACE,
+               "mvsn_incremental_cost_volume_guarded: repair workspace of %zu bytes required", need);
+  const unsigned *gate = reinterpret_cast<const unsigned *>(static_cast<const char *>(workspace) +
+                                                            chain_band_status_offset(n_chains, rows, cols));
+  return chain_run(src_image_lvl4, H_lvl4, H_inc, plane0_features, left_features, refiner_packed, n_chains, batch,
+                   num_idepth_samples, rows, cols, cost_volume, mask_volume, feature_volume, repair_workspace,
+                   repair_workspace_bytes, chain_repair_form(rows, cols), gate, sticky_status, stream);
 }

@@ -250,6 +250,7 @@ __device__ __forceinline__ void wino_groupnorm_lrelu(float (&y)[2][4][4], bool p
 template <int ROWS, int COLS>
 __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a, MVSN_VIS10) {   // (MVSN_VIS10: mvsn_common.h)
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (chain_gate_closed(a)) return;   // repair launch with nothing to repair (mvsn_chain.h)
   const int tid0 = threadIdx.x, lane = tid0 & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int n = blockIdx.x;
@@ -586,7 +587,7 @@ int chain_wino_launch(const ChainArgs &a, int n_chains, hipStream_t stream) {
     static LdsOptIn opt;                                                                                             \
     if (int rc = ensure_lds(opt, (const void *)chain_wino_kernel<R, C>, lds, "mvsn_incremental_cost_volume(winograd)")) \
       return rc;                                                                                                     \
-    hipLaunchKernelGGL((chain_wino_kernel<R, C>), dim3(n_chains), dim3(CW_THREADS), lds, stream, a, CHAIN_VISIBLE(a)); \
+    hipLaunchKernelGGL((chain_wino_kernel<R, C>), dim3(n_chains), dim3(CW_THREADS), lds, stream, a, CHAIN_VISIBLE_G(a)); \
   } while (0)
   if (a.rows == 16 && a.cols == 32) CW_LAUNCH(16, 32);   // 512x256 frames (BASELINE configs 2, 3 and the headline)
   else CW_LAUNCH(0, 0);

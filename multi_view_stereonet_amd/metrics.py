@@ -165,7 +165,7 @@ def evaluate(stereo_network, batches: Iterable[dict], params: dict, split: str, 
     if checks and not bool(torch.stack([c.reshape(()) for c in checks]).all()):
         raise AssertionError("baseline to the first source view must be positive")
     if on_gpu and hasattr(stereo_network, "check_device_status"):
-        stereo_network.check_device_status()
+        stereo_network.check_device_status(synchronize=False)
     rows_all = torch.cat(row_parts, 0) if row_parts else torch.zeros((0, 9), dtype=torch.float64, device=device)
     idx_all = torch.cat(idx_parts, 0) if idx_parts else torch.zeros((0,), dtype=torch.int64)
     # per-image runtime = batch time / batch size (the reference writes the BATCH time per file, test.py:271; both

@@ -23,6 +23,8 @@ Execution plan of one forward (B reference images, S sources each, N = S*B chain
   7. levels 3..0: mvsn_upsample_bilinear / mvsn_upsample_mask + refiner                 (a12, a11)
 """
 import ctypes
+import threading
+import warnings
 from typing import Dict, List, Optional
 
 import torch
@@ -63,7 +65,8 @@ class _Conv:
             _native.check(lib.mvsn_conv_pack_weights(ctypes.byref(dbx), _native.ptr(w), _native.ptr(self.packed_bx),
                                                      _native.stream()), "mvsn_conv_pack_weights(bf16x3)")
 
-        # third packing: Winograd F(2x2,3x3) coefficients for the 2-D 3x3 stride-1 dilation-1 layers
+        # third packing: Winograd F(2x2,3x3) coefficients for the 3x3 stride-1 layers that have that form (2-D with
+        # dilation 1, 2, 4, 8 and the 3x3x3 volume layers; also what the plane-resident towers are packed from)
         self.packed_wino = None
         dwn = self.desc(1, 1, 8, 32, _native.CONV_FP32_WINO)
         if lib.mvsn_conv_winograd_supported(ctypes.byref(dwn)):
@@ -137,8 +140,14 @@ class EngineOptions:
         self.plan_max_chains = 16
         self.plan_graph = True     # ... and from the second replay on the call list is launched as one hipGraph
         self.plan_max_bytes = 8 << 30   # intermediates all recorded plans together may keep alive
+        # The banded chain's workgroups wait for each other: on a device SHARED with other work a hand-off can time out.
+        # With this switch every banded call is followed, on the stream, by the single-launch form of the grid gated on
+        # the banded status word (mvsn_incremental_cost_volume_guarded): a few microseconds when nothing happened, a full
+        # recomputation when a hand-off timed out -- the forward's outputs are valid either way, without a host round
+        # trip.  The module then stops choosing the banded form (see MultiViewStereoNet.check_device_status).
+        self.banded_repair = True
 
-    NAMES = ("towers", "plan_max_chains", "plan_graph", "plan_max_bytes", "carry_passes", "carry_min_bytes", "carry_volume_passes", "carry_alternate", "chain_form", "fold_residual_blocks", "conv_precision", "winograd", "winograd_with_input_transform",
+    NAMES = ("banded_repair", "towers", "plan_max_chains", "plan_graph", "plan_max_bytes", "carry_passes", "carry_min_bytes", "carry_volume_passes", "carry_alternate", "chain_form", "fold_residual_blocks", "conv_precision", "winograd", "winograd_with_input_transform",
              "winograd_volume", "volume_materialise", "trim_tower_ends", "cat_free_heads", "lazy_stats_max_samples",
              "lazy_stats_max_records")
 
@@ -170,6 +179,43 @@ class _Job:
             eng.gn_lrelu_add2(r, stats, norm, residual, r_stats, r_norm, out=r)
         else:
             eng.gn_lrelu(r, stats, norm, residual=residual, out=r)
+
+
+class _SharedState:
+    """What must outlive a PlaneSweepEngine (it is rebuilt on .to() / load_state_dict): the two status words the repair
+    launches of the banded chain write (pinned host memory the device can reach: the host reads them WITHOUT
+    synchronising), how many repairs have been noticed, and the latch that keeps AUTO off the banded form afterwards."""
+
+    def __init__(self):
+        self.words = None              # int32[4]: [0] |= status, [1] += 1 per repair (mvsn_chain.h: chain_gate_closed)
+        self.words_np = None
+        self.seen = 0
+        self.banded_latched = False
+        self.warned = False
+
+    def status_ptr(self) -> int:
+        if self.words is None:
+            self.words = torch.zeros(4, dtype=torch.int32).pin_memory()
+            self.words_np = self.words.numpy()
+        return self.words.data_ptr()
+
+    def poll(self) -> int:
+        """Repairs since the last poll (no synchronisation: what the device has written so far)."""
+        if self.words_np is None:
+            return 0
+        count = int(self.words_np[1])
+        fresh, self.seen = count - self.seen, count
+        if fresh:
+            self.banded_latched = True
+            if not self.warned:
+                self.warned = True
+                warnings.warn(
+                    "mvsn_incremental_cost_volume(banded): an inter-workgroup hand-off timed out (status %d) -- the chain's "
+                    "workgroups were not co-resident: the device is shared with other work.  That forward's chain was "
+                    "recomputed in-stream by the single-launch form (its outputs are valid); this module no longer "
+                    "chooses the banded form (net.reset_device_status() re-enables it)." % int(self.words_np[0]),
+                    RuntimeWarning, stacklevel=3)
+        return fresh
 
 
 class ForwardPlan:
@@ -224,6 +270,7 @@ class PlaneSweepEngine:
         # The banded chain form spins on its sibling workgroups: every workgroup of a launch must be resident, so two
         # such launches must not share the device (MultiViewStereoNet._forward_lanes clears this for its lanes).
         self.banded_ok = True
+        self.net_state = net.__dict__.setdefault("_shared_state", _SharedState())   # survives rebuilds of this object
         self.last_chain_form, self.last_chain_workspace, self.last_chain_shape = None, None, None
         self.recording: Optional["ForwardPlan"] = None    # the plan a forward is being recorded into
         self.plans: Dict[tuple, Optional[ForwardPlan]] = {}   # shape key -> plan (None: that shape runs eagerly)
@@ -235,6 +282,7 @@ class PlaneSweepEngine:
         # When set to a list, every library call is bracketed by device events on the current
         # stream and appended as (kernel, start, end, algorithmic_flops, algorithmic_bytes).
         self.timeline: Optional[list] = None
+        self.level_tag = ""            # timeline names of the refiner levels' launches carry " L<level>" (bench attribution)
         fe = net.left_feature_extractor
         self.fe_down = [_Conv(lib, getattr(fe, f"conv{i}").weight, None, stride=2) for i in range(4)]
         self.fe_res = [(_Conv(lib, getattr(fe, f"res{i}").conv1.weight, None), _Norm(getattr(fe, f"res{i}").bn1))
@@ -420,6 +468,9 @@ class PlaneSweepEngine:
                    _native.ptr(out), _native.stream())
         return out
 
+    def _lvl(self) -> str:
+        return f"[{self.level_tag.strip()}]" if self.level_tag else ""
+
     def _call(self, kernel: str, fn, *args, flops: float = 0.0, nbytes: float = 0.0):
         if self.timeline is None:
             _native.check(fn(*args), kernel)
@@ -495,7 +546,7 @@ class PlaneSweepEngine:
                (f"d{c.dilation}" if c.dilation > 1 else "") + f" {c.cin}->{c.cout}" +
                (" bf16x3" if d.precision == _native.CONV_BF16X3 else "") +
                (" bf16" if d.precision == _native.CONV_BF16 else "") +
-               (" wino" if d.precision == _native.CONV_FP32_WINO else ""))
+               (" wino" if d.precision == _native.CONV_FP32_WINO else "") + self.level_tag)
         nbytes = 4.0 * (x.numel() * (2 if in_residual is not None else 1) + out.numel() +
                         (staged.numel() if staged is not None else 0))
         if carry is not None:
@@ -556,7 +607,7 @@ class PlaneSweepEngine:
         ptrs = (ctypes.c_void_p * len(blocks))(*[b.data_ptr() for b in blocks])
         chans = (ctypes.c_int * len(blocks))(*[b.shape[1] for b in blocks])
         self._keep(blocks)
-        self._call(f"mvsn_conv_forward_blocks[conv2d k3 {c.cin}->{c.cout} wino]", lib.mvsn_conv_forward_blocks,
+        self._call(f"mvsn_conv_forward_blocks[conv2d k3 {c.cin}->{c.cout} wino{self.level_tag}]", lib.mvsn_conv_forward_blocks,
                    ctypes.byref(d), ptrs, chans, len(blocks), _native.ptr(c.packed_wino), _native.ptr(c.bias),
                    _native.ptr(out), _native.ptr(partials), _native.stream(),
                    flops=2.0 * c.cin * 9 * c.cout * out[:, 0].numel(),
@@ -691,13 +742,13 @@ class PlaneSweepEngine:
             out = self.empty((n, 1, rows, cols), dtype=torch.float32, device=r.device)
         assert tuple(out.shape) == (n, 1, rows, cols) and out.is_contiguous()
         if isinstance(st, _Records):
-            self._call("mvsn_conv_to1_block", self.lib.mvsn_conv_to1_block_records, _native.ptr(r),
+            self._call("mvsn_conv_to1_block" + self._lvl(), self.lib.mvsn_conv_to1_block_records, _native.ptr(r),
                        _native.ptr(st.partials), st.tiles, _native.ptr(norm.gamma), _native.ptr(norm.beta),
                        _native.ptr(x), _native.ptr(c.weight), _native.ptr(c.bias), _native.ptr(prior), _native.ptr(fx),
                        n, rows, cols, _native.ptr(out), _native.stream(), flops=2.0 * 32 * 9 * out.numel(),
                        nbytes=4.0 * (2 * r.numel() + out.numel()))
             return out
-        self._call("mvsn_conv_to1_block", self.lib.mvsn_conv_to1_block, _native.ptr(r), _native.ptr(st),
+        self._call("mvsn_conv_to1_block" + self._lvl(), self.lib.mvsn_conv_to1_block, _native.ptr(r), _native.ptr(st),
                    _native.ptr(norm.gamma), _native.ptr(norm.beta), _native.ptr(x), _native.ptr(c.weight),
                    _native.ptr(c.bias), _native.ptr(prior), _native.ptr(fx), n, rows, cols, _native.ptr(out),
                    _native.stream(), flops=2.0 * 32 * 9 * out.numel(), nbytes=4.0 * (2 * r.numel() + out.numel()))
@@ -735,16 +786,23 @@ class PlaneSweepEngine:
         spatial = r[0, 0].numel()
         out = self.empty(r.shape, r.dtype, r.device) if out is None else out
         if isinstance(stats, _Records):
-            self._call("mvsn_groupnorm_lrelu_apply", self.lib.mvsn_groupnorm_lrelu_apply_records, _native.ptr(r),
+            self._call("mvsn_groupnorm_lrelu_apply" + self._lvl(), self.lib.mvsn_groupnorm_lrelu_apply_records, _native.ptr(r),
                        _native.ptr(stats.partials), stats.tiles, _native.ptr(norm.gamma), _native.ptr(norm.beta),
                        _native.ptr(residual), None, None, None, n, spatial, _native.ptr(out), _native.stream(),
                        nbytes=4.0 * r.numel() * (3 if residual is not None else 2))
             return out
-        self._call("mvsn_groupnorm_lrelu_apply", self.lib.mvsn_groupnorm_lrelu_apply, _native.ptr(r),
+        self._call("mvsn_groupnorm_lrelu_apply" + self._lvl(), self.lib.mvsn_groupnorm_lrelu_apply, _native.ptr(r),
                    _native.ptr(stats), _native.ptr(norm.gamma), _native.ptr(norm.beta), _native.ptr(residual), n,
                    spatial, _native.ptr(out), _native.stream(),
                    nbytes=4.0 * r.numel() * (3 if residual is not None else 2))
         return out
+
+    def use_towers(self) -> bool:
+        """The plane-resident towers are fp32 Winograd kernels: `winograd = False` (direct-form numerics end to end) and
+        `fold_residual_blocks` switch them off with the layers they replace.  They do NOT follow `conv_precision` (the
+        bf16 tiers keep these two small stages in fp32 -- more exact, and faster than 15-21 bf16 launches) nor
+        `trim_tower_ends` (there is no stand-alone pass inside them to trim)."""
+        return bool(self.towers and self.winograd and not self.fold_residual_blocks)
 
     def feature_network(self, image: torch.Tensor) -> List[torch.Tensor]:
         pyr = [image]
@@ -753,7 +811,7 @@ class PlaneSweepEngine:
             x, _ = self.conv(self.fe_down[i], x)
             pyr.append(x)
         x, _ = self.conv(self.fe_down[3], x)
-        if self.towers and not self.fold_residual_blocks:
+        if self.use_towers():
             feats = self.tower_extractor_tail(x)
             if feats is not None:
                 pyr.append(feats)
@@ -825,6 +883,14 @@ class PlaneSweepEngine:
         """`guide` is a tensor or a list of channel blocks (image, features): the refiner input
         [guide..., prior * fx] is assembled with ONE concatenation.  `scaled` = prior * fx when the caller already
         has it (upsample_prior forms it in the upsampling pass)."""
+        self.level_tag = f" L{level}"
+        try:
+            return self._idepth_refiner(level, guide, prior, fx, scaled)
+        finally:
+            self.level_tag = ""
+
+    def _idepth_refiner(self, level: int, guide, prior: torch.Tensor, fx: torch.Tensor,
+                        scaled: Optional[torch.Tensor] = None) -> torch.Tensor:
         p = self.refiners[level]
         prior, fx = self.dense(prior), self.dense(fx)
         n, pixels = prior.shape[0], prior[0].numel()
@@ -930,7 +996,7 @@ class PlaneSweepEngine:
                 "stepwise": _native.CHAIN_STEPWISE, "banded": _native.CHAIN_BANDED}[self.chain_form]
         if form == _native.CHAIN_AUTO:
             form = self.lib.mvsn_incremental_cost_volume_form_for(N, rows, cols)
-            if form == _native.CHAIN_BANDED and not self.banded_ok:
+            if form == _native.CHAIN_BANDED and not (self.banded_ok and not self.net_state.banded_latched):
                 # lanes on several streams (see forward): what AUTO picks once the banded form is out of reach
                 form = self.lib.mvsn_incremental_cost_volume_form_for(1 << 20, rows, cols)
         if form == _native.CHAIN_WINOGRAD and self.lib.mvsn_incremental_cost_volume_form(rows, cols) != form:
@@ -941,12 +1007,20 @@ class PlaneSweepEngine:
         ws = self.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
         self.last_chain_form, self.last_chain_workspace, self.last_chain_shape = form, ws, (N, rows, cols)
         P = rows * cols
-        self._call("mvsn_incremental_cost_volume", self.lib.mvsn_incremental_cost_volume,
-                   _native.ptr(src4), _native.ptr(H4), _native.ptr(Hinc), _native.ptr(plane0), _native.ptr(left_feats),
-                   _native.ptr(self.refiner_packed), N, B, D, rows, cols, _native.ptr(cost), _native.ptr(mask),
-                   _native.ptr(fvol), _native.ptr(ws), ws_bytes, form, _native.stream(),
-                   flops=N * (D - 1) * 2.0 * 9 * 32 * (35 + 32 + 32) * P,
-                   nbytes=N * (4.0 * 67 * P + 128.0 * D * P + D * P))  # Kernel A algorithmic bytes
+        common = (_native.ptr(src4), _native.ptr(H4), _native.ptr(Hinc), _native.ptr(plane0), _native.ptr(left_feats),
+                  _native.ptr(self.refiner_packed), N, B, D, rows, cols, _native.ptr(cost), _native.ptr(mask),
+                  _native.ptr(fvol), _native.ptr(ws), ws_bytes, form)
+        acct = dict(flops=N * (D - 1) * 2.0 * 9 * 32 * (35 + 32 + 32) * P,
+                    nbytes=N * (4.0 * 67 * P + 128.0 * D * P + D * P))  # Kernel A algorithmic bytes
+        if form == _native.CHAIN_BANDED and self.banded_repair:
+            # followed by the gated single-launch form: valid outputs even if a hand-off times out (EngineOptions)
+            rws_bytes = self.lib.mvsn_incremental_cost_volume_repair_workspace_bytes(N, rows, cols)
+            rws = self.empty(rws_bytes, dtype=torch.uint8, device=dev) if rws_bytes else None
+            self._call("mvsn_incremental_cost_volume", self.lib.mvsn_incremental_cost_volume_guarded, *common,
+                       _native.ptr(rws), rws_bytes, self.net_state.status_ptr(), _native.stream(), **acct)
+        else:
+            self._call("mvsn_incremental_cost_volume", self.lib.mvsn_incremental_cost_volume, *common,
+                       _native.stream(), **acct)
         return cost, mask, fvol
 
     def chain_status(self) -> int:
@@ -1044,7 +1118,7 @@ class PlaneSweepEngine:
         # 6. level-4 refinement per chain, then fuse the sources
         if do_refiners[4]:
             refined = None
-            if self.towers and not self.fold_residual_blocks:
+            if self.use_towers():
                 refined = self.tower_refiner4(self.f32c(left_image_pyr[-1]), left_feats[-1], raw, fx_all[-1])
             if refined is None:
                 # per chain: the guide blocks of its reference image (device copies, no concatenated tensor)
@@ -1104,6 +1178,8 @@ class MultiViewStereoNet(nn.Module):
         state = self.__dict__.copy()
         state["_engine"], state["_engine_key"], state["_lane_streams"] = None, None, []
         state.pop("_plist", None)
+        state.pop("_shared_state", None)
+        state.pop("_lock", None)
         return state
 
     def __deepcopy__(self, memo):
@@ -1138,19 +1214,36 @@ class MultiViewStereoNet(nn.Module):
         """Drop the packed weight copies now (after replacing Parameter objects by hand)."""
         self._invalidate()
 
-    def check_device_status(self):
-        """Raise if the last forward's banded chain (one chain on several workgroups, small batches) reported a
-        hand-off that timed out -- its workgroups were not co-resident, i.e. the device was shared with other work.
-        Synchronises; the wrappers call it where they synchronise anyway (multi_view_forward's timer, evaluate's
-        final sync).  Independently of this check such a forward returns NaN depth maps (the kernel poisons its cost
-        slice), never plausible-looking wrong ones."""
+    def check_device_status(self, synchronize: bool = True) -> int:
+        """Where the wrappers synchronise anyway (multi_view_forward's timer, evaluate's final sync): has a banded chain
+        (one chain on several workgroups, the small-batch default) run into a hand-off that timed out -- its workgroups
+        were not co-resident, i.e. the device is shared with other work?
+
+        With `options.banded_repair` (default) such a forward was recomputed in-stream by the single-launch form: its
+        outputs are VALID; this call returns the number of repaired forwards since the last call, warns once and latches
+        the module off the banded form (every later forward polls the same words without synchronising, so callers that
+        never come here -- `net(...)` through torch.jit.load -- are latched one forward later).  Without the repair launch
+        (`banded_repair = False`) a timed-out forward's outputs are NaN and this call raises."""
         eng = self._engine
-        status = eng.chain_status() if eng is not None else 0
-        if status:
-            raise RuntimeError(
-                "mvsn_incremental_cost_volume(banded): inter-workgroup hand-off %d timed out -- the chain's workgroups "
-                "were not co-resident (is the device shared with other work?).  The outputs of that forward are "
-                "NaN; set net.options.chain_form = 'winograd' (one workgroup per chain) to run without hand-offs." % status)
+        if eng is None:
+            return 0
+        if synchronize:                # (callers that have just synchronised pass False: two host reads remain)
+            torch.cuda.synchronize()
+        fresh = eng.net_state.poll()
+        if not self.options.banded_repair:
+            status = eng.chain_status()
+            if status:
+                raise RuntimeError(
+                    "mvsn_incremental_cost_volume(banded): inter-workgroup hand-off %d timed out -- the chain's workgroups "
+                    "were not co-resident (is the device shared with other work?).  The outputs of that forward are "
+                    "NaN; set net.options.banded_repair = True (the default) or net.options.chain_form = 'winograd'." % status)
+        return fresh
+
+    def reset_device_status(self):
+        """Re-enable the banded chain form after check_device_status / a forward latched it off."""
+        st = self.__dict__.get("_shared_state")
+        if st is not None:
+            st.banded_latched, st.warned = False, False
 
     def engine(self) -> PlaneSweepEngine:
         # The packed copies go stale when a parameter is rebound (.to(), load_state_dict: both invalidate above) or
@@ -1191,8 +1284,14 @@ class MultiViewStereoNet(nn.Module):
                                "its inputs to 'cuda'; there is no CPU implementation of the plane-sweep path")
         if next(self.parameters()).device != left_image_pyr[0].device:
             raise RuntimeError("module parameters and inputs are on different devices")
-        with torch.cuda.device(left_image_pyr[0].device):
+        lock = self.__dict__.get("_lock")
+        if lock is None:
+            lock = self.__dict__.setdefault("_lock", threading.RLock())
+        with torch.cuda.device(left_image_pyr[0].device), lock:
+            # (the lock: a forward's launches -- and a recorded plan's copy-in / replay / copy-out -- are enqueued as a
+            # unit; two threads sharing this module interleave whole forwards, never launches)
             eng = self.engine()
+            eng.net_state.poll()       # a repaired banded chain since the last forward latches AUTO off that form
             args = (int(num_idepth_samples), bool(do_cost_volume_filter), list(do_refiners))
             B = left_image_pyr[0].shape[0]
             lanes = min(self.stream_lanes, B) if capture is None else 1
@@ -1208,7 +1307,11 @@ class MultiViewStereoNet(nn.Module):
         S, L = len(T_right_in_lefts), len(left_image_pyr)
         flat = list(left_image_pyr) + list(K_pyr) + list(T_right_in_lefts) + [x for p in right_image_pyrs for x in p]
         opts = tuple(getattr(self.options, k) for k in EngineOptions.NAMES)
-        key = (tuple((tuple(t.shape), t.dtype) for t in flat), S, args[0], args[1], tuple(args[2]), opts, eng.banded_ok)
+        # A plan owns its buffers (static inputs, intermediates, chain workspace) and its hipGraph: forwards of one shape
+        # on DIFFERENT streams would race on them, so the stream is part of the key (each stream records its own plan);
+        # forwards on one stream are ordered by the stream, and their enqueueing by the engine's lock.
+        key = (tuple((tuple(t.shape), t.dtype) for t in flat), S, args[0], args[1], tuple(args[2]), opts, eng.banded_ok,
+               eng.net_state.banded_latched, torch.cuda.current_stream().cuda_stream)
         plan = eng.plans.get(key, False)
 
         def unflatten(ts):
@@ -1281,17 +1384,19 @@ class MultiViewStereoNet(nn.Module):
             self._lane_streams = [torch.cuda.Stream() for _ in range(lanes)]
         bounds = [(B * i) // lanes for i in range(lanes + 1)]
         parts = []
-        for i in range(lanes):
-            lo, hi = bounds[i], bounds[i + 1]
-            st = self._lane_streams[i]
-            st.wait_stream(main)
-            eng.banded_ok = False       # concurrent lanes: the banded chain needs the device to itself
-            with torch.cuda.stream(st):
-                parts.append(eng.forward([x[lo:hi] for x in left_image_pyr], [k[lo:hi] for k in K_pyr],
-                                         [t[lo:hi] for t in T_right_in_lefts],
-                                         [[x[lo:hi] for x in p] for p in right_image_pyrs], *args, None))
+        eng.banded_ok = False           # concurrent lanes: the banded chain needs the device to itself
+        try:
+            for i in range(lanes):
+                lo, hi = bounds[i], bounds[i + 1]
+                st = self._lane_streams[i]
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    parts.append(eng.forward([x[lo:hi] for x in left_image_pyr], [k[lo:hi] for k in K_pyr],
+                                             [t[lo:hi] for t in T_right_in_lefts],
+                                             [[x[lo:hi] for x in p] for p in right_image_pyrs], *args, None))
+        finally:
+            eng.banded_ok = True        # (also when a lane's forward raised)
         out = {}
-        eng.banded_ok = True
         for st in self._lane_streams[:lanes]:
             main.wait_stream(st)
         for key in parts[0]:

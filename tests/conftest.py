@@ -50,3 +50,17 @@ def rel_err(a, b):
     b = torch.as_tensor(b, dtype=torch.float64)
     denom = b.abs().mean().clamp_min(1e-12)
     return float((a - b).abs().mean() / denom), float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def rel_err_per_pixel(a, ref):
+    """The contract's own reading of "within 1e-3 relative on the final depthmap": per-pixel |a - ref| / max(|ref|, floor)
+    with floor = 1e-3 * mean|ref|, over the pixels where ref > 0 (the refiner's final relu clamps the others to exactly
+    0, multi_view_stereonet.py:482).  Returns (max, p99.9)."""
+    a = torch.as_tensor(a, dtype=torch.float64).reshape(-1)
+    ref = torch.as_tensor(ref, dtype=torch.float64).reshape(-1)
+    floor = 1e-3 * ref.abs().mean().clamp_min(1e-12)
+    sel = ref > 0
+    if not bool(sel.any()):
+        return 0.0, 0.0
+    e = ((a - ref).abs() / ref.abs().clamp_min(floor))[sel]
+    return float(e.max()), float(torch.quantile(e, 0.999)) if e.numel() <= (1 << 24) else float(e.sort().values[int(0.999 * (e.numel() - 1))])

@@ -50,7 +50,7 @@ for name, b in cases:
     net.options.plan_max_chains = keep
     for k, v in late.items():
         setattr(net.options, k, int(v) if v.lstrip("-").isdigit() else v)
-    bad, worst = 0, 0.0
+    bad, worst, repaired = 0, 0.0, 0
     run = lambda x: bench.run_forward(net, x, cfg["D"])
     if graphed:
         x0 = inps[0]
@@ -67,11 +67,11 @@ for name, b in cases:
             bad += 1
             worst = max(worst, max(float((a.float() - r.float()).abs().max()) for a, r in zip(got, refs[j])))
         if i % 50 == 49 or not same:
-            net.check_device_status()                      # synchronises; raises on a timed-out hand-off
+            repaired += net.check_device_status()          # synchronises; counts forwards whose banded chain was repaired
     torch.cuda.synchronize()
-    net.check_device_status()
+    repaired += net.check_device_status()
     eng = net.engine()
-    res.append({"config": name, "batch": b, "chains": b * cfg["S"], "chain_form": FORMS.get(eng.last_chain_form),
+    res.append({"repaired_forwards": repaired, "config": name, "batch": b, "chains": b * cfg["S"], "chain_form": FORMS.get(eng.last_chain_form),
                 "forwards": n_rep, "graph_replays": eng.replays, "wrong_forwards": bad, "worst_abs_diff": worst,
                 "ms_per_forward": round((time.perf_counter() - t0) / n_rep * 1e3, 3)})
     del net, inps, refs
