@@ -191,7 +191,7 @@ def host_cpu_info():
     return model, cores, (len(phys) or cores)
 
 
-def roofline_by_kernel(agg, total_ms, top=14):
+def roofline_by_kernel(agg, total_ms, top=14, wino_names=()):
     """Every arithmetic kernel of the step (refiner launches by LEVEL and dilation, ` L<level>` in the name) against both
     roofs: launch time from this run's device events; executed flops (Winograd forms: 4/9 of the direct count) against
     the fp32 MFMA peak; ALGORITHMIC bytes (each tensor of the launch -- and of the pass it carries -- once) against the
@@ -203,7 +203,7 @@ def roofline_by_kernel(agg, total_ms, top=14):
         if v["flops"] <= 0 or len(rows) >= top:
             continue
         sec = v["ms"] * 1e-3
-        ex = v["flops"] * (4.0 / 9.0 if " wino" in k else 1.0) / sec / 1e12
+        ex = v["flops"] * (4.0 / 9.0 if (" wino" in k or k in wino_names) else 1.0) / sec / 1e12
         gbs = v["bytes"] / sec / 1e9
         row = {"launches": v["launches"], "ms_per_step": round(v["ms"], 3), "ms_per_launch": round(v["ms"] / v["launches"], 4),
                "share_of_step": round(v["ms"] / total_ms, 4), "executed_TFLOPs": round(ex, 1),
@@ -640,7 +640,9 @@ def main():
         line["kernel_ms_per_step"] = {k: round(v["ms"], 3) for k, v in
                                       sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:16]}
         line["launches_per_forward"] = int(sum(v["launches"] for v in agg.values()))
-        line["roofline_by_kernel"] = roofline_by_kernel(agg, total_ms)
+        wino_chain_now = net.engine().last_chain_form in (2, 3, 4)      # every chain form but the direct one
+        line["roofline_by_kernel"] = roofline_by_kernel(
+            agg, total_ms, wino_names=("mvsn_incremental_cost_volume",) if wino_chain_now else ())
         if world == 1 and args.sustain > 0:
             windows, t_end = [], time.perf_counter() + args.sustain
             while time.perf_counter() < t_end:

@@ -18,8 +18,8 @@
 //   * Transformed weights: 72 / 64 / 64 KB per layer -- one layer fits next to the activation planes.  The U of the
 //     NEXT layer is fetched by LDS-DMA (global_load_lds, 1 KB per instruction, from L2) right after the barrier that
 //     ends the current layer's multiplies, and lands behind the GroupNorm / layout phase that follows.
-//   * GroupNorm: per-wave two-pass moments (count, mean, M2) by DPP reductions, combined across the 8 waves with
-//     Chan's formula behind ONE barrier.
+//   * GroupNorm: per-wave shifted sums by DPP reductions, written ahead of the barrier that ends the layer's multiplies
+//     and combined across the 8 waves behind it (no barrier of its own).
 //
 // LDS plan (floats), RS = cols + 2, CS = (rows + 1) * RS:
 //   U       [9 * 2048]      transformed weights of the current layer, [k-step][cout tile][xi quad][lane][4 xi]
@@ -186,16 +186,17 @@ __device__ __forceinline__ void half_wave_sums(float (&s)[4]) {
     s[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s[k]), 0x142, 0xA, 0xF, false));
 }
 
-// y (+bias) -> LeakyReLU(GroupNorm(.)) in place, statistics over the whole workgroup with ONE barrier.
+// y (+bias) -> LeakyReLU(GroupNorm(.)) in place, statistics over the whole workgroup, in two parts around the barrier
+// that ends the layer's multiplies anyway (B3 / B7: no barrier of its own).
 // Shifted single pass: every lane accumulates sum(x - c) and sum((x - c)^2) with c = the group's mean of the
 // previous step (`shift`, identical in all lanes of the group; 0 at the first step), the per-wave sums are combined
 // behind the barrier, and var = E[(x-c)^2] - (E[x-c])^2.  The recurrence moves slowly from plane to plane, so c sits
 // within a fraction of a standard deviation of the mean and the subtraction cancels nothing of significance
 // (with c = 0 it is the plain one-pass formula, still accurate here: |mean| is of the order of the deviation).
-__device__ __forceinline__ void wino_groupnorm_lrelu(float (&y)[2][4][4], bool pvalid, float inv_n, float (&shift)[2],
-                                                     const float *__restrict__ bias, const float *__restrict__ gamma,
-                                                     const float *__restrict__ beta, float *red_slab, int lane,
-                                                     int wave) {
+// Part 1 (before the barrier): bias, this wave's sums -> its record.  A wave that leaves the multiplies early does
+// this while its SIMD partner still multiplies; the record slab of a GroupNorm is rewritten one whole step later.
+__device__ __forceinline__ void wino_groupnorm_sums(float (&y)[2][4][4], bool pvalid, const float (&shift)[2],
+                                                    const float *__restrict__ bias, float *red_slab, int lane, int wave) {
   const int cbase = (lane >> 4) * 4;
   float s[4] = {0.f, 0.f, 0.f, 0.f};   // [ct][sum, sum of squares]
 #pragma unroll
@@ -218,7 +219,13 @@ __device__ __forceinline__ void wino_groupnorm_lrelu(float (&y)[2][4][4], bool p
     rec[0] = s[0], rec[1] = s[1];
     rec[4] = s[2], rec[5] = s[3];
   }
-  cw_barrier();
+}
+
+// Part 2 (behind the barrier): combine the eight records, normalise, activate.
+__device__ __forceinline__ void wino_groupnorm_apply(float (&y)[2][4][4], float inv_n, float (&shift)[2],
+                                                     const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                     const float *red_slab, int lane) {
+  const int cbase = (lane >> 4) * 4;
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
     const int g = ct * 2 + (lane >> 5);
@@ -253,7 +260,20 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a, MVS
   if (chain_gate_closed(a)) return;   // repair launch with nothing to repair (mvsn_chain.h)
   const int tid0 = threadIdx.x, lane = tid0 & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-  const int n = blockIdx.x;
+  // Chain of this workgroup.  The S chains of a reference image read the same 64 KB of left features at every step:
+  // they take neighbouring slots of ONE XCD's range (workgroup b is observed on XCD b % 8), so they run at the same
+  // time next to one copy in that L2 -- with n = blockIdx.x they sat on the same XCD a whole round apart, and the copy
+  // was evicted and re-fetched in between.  A permutation of the chains: placement only, results identical.
+  int n = blockIdx.x;
+#ifndef MVSN_CW_NO_XCD_PAIRS
+  {
+    const int S = (int)gridDim.x / a.B;
+    if (S > 1 && S * a.B == (int)gridDim.x) {
+      const int t = xcd_tile_index(blockIdx.x, gridDim.x);
+      n = (t % S) * a.B + t / S;
+    }
+  }
+#endif
   const int rows = ROWS ? ROWS : a.rows, cols = COLS ? COLS : a.cols;
   const int P = rows * cols, RS = cols + 2, CS = (rows + 1) * RS, D = a.D;
   int tid = tid0;
@@ -473,15 +493,16 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a, MVS
     float y[2][4][4] = {};
     CW_WSTAMP(0);
     if (tile_live) wino_layer<9>(act, U, CS, RS, wb, lane, y);
+    wino_groupnorm_sums(y, pvalid && tile_live, shift0, bias0, red, lane_s, wave);
     CW_STAMP(4);
     CW_WSTAMP(1);
-    cw_barrier();  // B3: act and U free
+    cw_barrier();  // B3: act and U free, GroupNorm records published
     CW_WSTAMP(2);
     dma_u(upk + CW_U0_FLOATS, 8);
     CW_WSTAMP(6);
     CW_STAMP(5);
 
-    wino_groupnorm_lrelu(y, pvalid && tile_live, inv_n, shift0, bias0, gn0w, gn0b, red, lane_s, wave);
+    wino_groupnorm_apply(y, inv_n, shift0, gn0w, gn0b, red, lane_s);
     if (pvalid) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
@@ -499,12 +520,13 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a, MVS
     CW_STAMP(6);
 
     if (tile_live) wino_layer<8>(act, U, CS, RS, wb, lane, y);
+    wino_groupnorm_sums(y, pvalid && tile_live, shift1, bias1, red + CW_RED_FLOATS / 2, lane_s, wave);
     CW_STAMP(7);
-    cw_barrier();  // B7
+    cw_barrier();  // B7 (+ records)
     dma_u(upk + CW_U0_FLOATS + CW_U1_FLOATS, 8);
     CW_STAMP(8);
 
-    wino_groupnorm_lrelu(y, pvalid && tile_live, inv_n, shift1, bias1, gn1w, gn1b, red + CW_RED_FLOATS / 2, lane_s, wave);
+    wino_groupnorm_apply(y, inv_n, shift1, gn1w, gn1b, red + CW_RED_FLOATS / 2, lane_s);
     if (pvalid) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
