@@ -50,9 +50,11 @@ CONFIGS = {
                     batch=1, what="BASELINE config 3: GTA-SfM 5-cmp, 512x256, D=64, 5 source views, ONE image per GPU "
                                   "(batch 8 over 8 GPUs)"),
     "config4": dict(rows=480, cols=640, D=96, S=1, weights="demon_45epochs", golden="g3_demon_640x480_d96_s1.npz",
-                    batch=32, what="BASELINE config 4: DeMoN 640x480, D=96, 1 source view, demon_45epochs weights"),
+                    batch=32, more_batches=(128,),
+                    what="BASELINE config 4: DeMoN 640x480, D=96, 1 source view, demon_45epochs weights"),
     "config5": dict(rows=512, cols=1024, D=128, S=4, weights="gta_sfm_150epochs", golden="gc5_gta_1024x512_d128_s4.npz",
-                    batch=8, what="BASELINE config 5 geometry: 1024x512, D=128, 4 source views (fp32 throughout; the bf16 "
+                    batch=8, more_batches=(32,),
+                    what="BASELINE config 5 geometry: 1024x512, D=128, 4 source views (fp32 throughout; the bf16 "
                                   "tiers are reported by the headline line)"),
 }
 
@@ -127,7 +129,7 @@ def other_configs(dev, skip):
         net.load_state_dict(load_weights(cfg["weights"]), strict=True)
         net = net.to(dev).eval()
         entry = {"workload": cfg["what"]}
-        for b in sorted({1, cfg["batch"]}):
+        for b in sorted({1, cfg["batch"]} | set(cfg.get("more_batches", ()))):
             _, inp, ref0 = config_inputs(cfg, b, 0, dev)
             for _ in range(5):      # (record, list replay, graph instantiation of a planned forward; allocator pools)
                 out = run_forward(net, inp, cfg["D"])
@@ -142,7 +144,9 @@ def other_configs(dev, skip):
                 torch.cuda.synchronize()
                 blocks.append((time.perf_counter() - t0) / reps * 1e3)
             ms = sorted(blocks)[2]
-            entry[f"B={b}"] = {"ms_per_forward": round(ms, 3), "depthmaps_per_s": round(b / ms * 1e3, 1)}
+            entry[f"B={b}"] = {"ms_per_forward": round(ms, 3), "depthmaps_per_s": round(b / ms * 1e3, 1),
+                               "chain_form": {1: "direct", 2: "winograd", 3: "stepwise", 4: "banded"}.get(
+                                   net.engine().last_chain_form, "?")}
             if b == 1:
                 entry["l1_vs_ref"] = l1_against(ref0, out["left_idepthmap_pyr"][0][:1].cpu(), cfg["golden"])
             del inp, out

@@ -118,7 +118,9 @@ int mvsn_pack_feature_refiner(const float *conv0_w, const float *conv0_b, const 
                               const float *bn0_b, const float *res0_w, const float *res0_b,
                               const float *res0_bn_w, const float *res0_bn_b, const float *final_w,
                               const float *final_b, float *packed, mvsn_stream_t stream);
-size_t mvsn_incremental_cost_volume_workspace_bytes(int n_chains, int rows, int cols);   /* the fused forms only */
+size_t mvsn_incremental_cost_volume_workspace_bytes(int n_chains, int rows, int cols);   /* MVSN_CHAIN_DIRECT: the step's moved
+                                                                                             features (always, since ABI 3) + the
+                                                                                             activation planes that do not fit LDS */
 int mvsn_incremental_cost_volume_form(int rows, int cols);   /* the fused form of this grid: WINOGRAD or DIRECT */
 /* what MVSN_CHAIN_AUTO resolves to for this many chains on this grid (BANDED, WINOGRAD, STEPWISE or DIRECT), and the
  * workspace `form` (AUTO allowed) needs for num_idepth_samples planes */

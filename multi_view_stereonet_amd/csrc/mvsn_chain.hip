@@ -160,7 +160,7 @@ __device__ __forceinline__ void conv3x3_mfma_slab(const float *__restrict__ act,
   for (int c4 = 0; c4 < NC; ++c4) {
     if (c4 + 1 < NC) fetch(c4 + 1);
     const float *sb = slab + (c4 & 1) * slab_floats + G + (lane >> 4) * CS;
-#pragma unroll
+#pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
       const int off = (tap / 3 - 1) * RS + (tap % 3 - 1);
       const float *wt = wbuf + (tap * NC + c4) * 128 + lane;
@@ -273,7 +273,8 @@ template <int TP, bool LDS_ACT>
 __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a, MVSN_VIS10) {   // (MVSN_VIS10: mvsn_common.h)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (chain_gate_closed(a)) return;   // repair launch with nothing to repair (mvsn_chain.h)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int tid = threadIdx.x;              // (made opaque at the top of every step, see the step loop)
+  const int lane = tid & 63, wave = tid >> 6;
   const int n = blockIdx.x;
   const int rows = a.rows, cols = a.cols, P = rows * cols, RS = cols + 1, G = RS + 1, CS = a.CS, D = a.D;
   constexpr int IMG_IT = (TP * 256 + CH_THREADS - 1) / CH_THREADS;
@@ -286,10 +287,16 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a, MVSN_VIS
   float *act;
   float *slab = nullptr;
   const int act_floats = G + 36 * CS;
+  // moved features of the step (the epilogue adds the refiner's output to them): 32 x P floats per chain in the global
+  // workspace, written and read back by the same thread -- held in registers across the three convolutions they cost
+  // 8 VGPRs per tile, which a 1024-thread workgroup (128 registers per lane) does not have
+  float *mv;
   if constexpr (LDS_ACT) {
     act = maskb + Ppad + G;
+    mv = a.workspace + (size_t)n * 32 * P;
   } else {
-    act = a.workspace + (size_t)n * act_floats + G;
+    act = a.workspace + (size_t)n * (act_floats + 32 * P) + G;
+    mv = a.workspace + (size_t)n * (act_floats + 32 * P) + act_floats;
     slab = maskb + Ppad;   // 2 x (G + 4*CS) floats
   }
 
@@ -301,14 +308,19 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a, MVSN_VIS
 
   int pb[TP], qb[TP];
   bool valid[TP];
+  int cbase;   // this lane's channels: t*16 + cbase + r
+  auto tile_indices = [&](int t_) {   // this thread's pixels of its wave's TP tiles (recomputed per step, see the loop)
+    const int lane_ = t_ & 63, wave_ = t_ >> 6;
 #pragma unroll
-  for (int j = 0; j < TP; ++j) {
-    const int p = (wave * TP + j) * 16 + (lane & 15);
-    valid[j] = p < P;
-    pb[j] = valid[j] ? p : 0;
-    qb[j] = (pb[j] / cols) * RS + (pb[j] % cols);
-  }
-  const int cbase = (lane >> 4) * 4;  // this lane's channels: t*16 + cbase + r
+    for (int j = 0; j < TP; ++j) {
+      const int p = (wave_ * TP + j) * 16 + (lane_ & 15);
+      valid[j] = p < P;
+      pb[j] = valid[j] ? p : 0;
+      qb[j] = (pb[j] / cols) * RS + (pb[j] % cols);
+    }
+    cbase = (lane_ >> 4) * 4;
+  };
+  tile_indices(tid);
   __syncthreads();
 
   const float *f0 = a.f0 + (size_t)n * 32 * P;
@@ -383,6 +395,12 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a, MVSN_VIS
     if (a.dbg && blockIdx.x == 0 && tid == 0 && d <= 4) a.dbg[(d - 1) * 16 + (i)] = __builtin_readcyclecounter(); \
   } while (0)
   for (int d = 1; d < D; ++d) {
+    // Per-thread addresses are recomputed every step from an opaque copy of the thread id: hoisted out of the loop
+    // (72 of them in the smallest instantiation) they do not fit the 128 registers of a 1024-thread workgroup and go
+    // to scratch -- and every reload in front of a load is an s_waitcnt vmcnt(0) (HISTORY 11.9, same disease).
+    asm volatile("" : "+v"(tid));
+    tile_indices(tid);
+    const int lane = tid & 63, wave = tid >> 6;
     MVSN_STAMP(0);
     floatx4 wreg[3];
     load_weights_to_regs<W0_FLOATS>(a.packed, wreg, tid);
@@ -414,8 +432,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a, MVSN_VIS
       }
     }
 
-    // A2: previous plane's features moved by the incremental homography (gather from LDS)
-    floatx4 fp[TP][2];
+    // A2: previous plane's features moved by the incremental homography (gather from the activation planes) -> mv
     {
       float Hl[9];
 #pragma unroll
@@ -431,8 +448,10 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a, MVSN_VIS
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float *fc = act + (3 + t * 16 + cbase + r) * CS;
-            fp[j][t][r] = keep * (fc[o00] * b.w00 + fc[o01] * b.w01 + fc[o10] * b.w10 + fc[o11] * b.w11);
+            const float v = keep * (fc[o00] * b.w00 + fc[o01] * b.w01 + fc[o10] * b.w10 + fc[o11] * b.w11);
+            if (valid[j]) mv[(size_t)(t * 16 + cbase + r) * P + pb[j]] = v;
           }
+        __builtin_amdgcn_sched_barrier(0);   // one tile's 32 taps in flight at a time
       }
     }
     MVSN_STAMP(1);
@@ -446,7 +465,8 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a, MVSN_VIS
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) act[(3 + t * 16 + cbase + r) * CS + qb[j]] = fp[j][t][r];
+          for (int r = 0; r < 4; ++r)
+            act[(3 + t * 16 + cbase + r) * CS + qb[j]] = mv[(size_t)(t * 16 + cbase + r) * P + pb[j]];
       }
 #pragma unroll
     for (int it = 0; it < IMG_IT; ++it) {
@@ -523,7 +543,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a, MVSN_VIS
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int c = t * 16 + cbase + r;
-          act[(3 + c) * CS + qb[j]] = fp[j][t][r] + (acc[j][t][r] + bias2[c]);
+          act[(3 + c) * CS + qb[j]] = mv[(size_t)c * P + pb[j]] + (acc[j][t][r] + bias2[c]);
         }
     }
     MVSN_STAMP(12);
@@ -579,8 +599,10 @@ extern "C" size_t mvsn_incremental_cost_volume_workspace_bytes(int n_chains, int
   if (n_chains <= 0 || rows <= 0 || cols <= 0) return 0;
   const int CS = mvsn::chain_cs(rows, cols);
   const int act_floats = (cols + 2) + 36 * CS;
-  if (mvsn::chain_lds_bytes(rows * cols, act_floats, true) <= 160 * 1024) return 0;
-  return (size_t)n_chains * act_floats * sizeof(float);
+  // per chain: the step's moved features (32 x P, always) + the activation planes where they do not fit LDS
+  const size_t mv_floats = (size_t)32 * rows * cols;
+  if (mvsn::chain_lds_bytes(rows * cols, act_floats, true) <= 160 * 1024) return (size_t)n_chains * mv_floats * sizeof(float);
+  return (size_t)n_chains * (act_floats + mv_floats) * sizeof(float);
 }
 
 // What MVSN_CHAIN_AUTO resolves to for this many chains on this coarse grid.
@@ -693,10 +715,10 @@ static int chain_run(const float *src_image_lvl4, const float *H_lvl4, const flo
   }
   const int act_floats = (cols + 2) + 36 * a.CS;
   const bool lds_act = chain_lds_bytes(P, act_floats, true) <= 160 * 1024;
-  const size_t need = lds_act ? 0 : (size_t)n_chains * act_floats * sizeof(float);
-  MVSN_REQUIRE(lds_act || (workspace && workspace_bytes >= need), MVSN_E_WORKSPACE,
+  const size_t need = mvsn_incremental_cost_volume_workspace_bytes(n_chains, rows, cols);
+  MVSN_REQUIRE(workspace && workspace_bytes >= need, MVSN_E_WORKSPACE,
                "mvsn_incremental_cost_volume: workspace of %zu bytes required", need);
-  a.workspace = lds_act ? nullptr : (float *)workspace;
+  a.workspace = (float *)workspace;
   const int slab_floats = (cols + 2) + 4 * a.CS;
   MVSN_REQUIRE(lds_act || slab_floats <= 9 * CH_THREADS, MVSN_E_TOOLARGE,
                "mvsn_incremental_cost_volume: coarse grid too large for the slab staging plan");

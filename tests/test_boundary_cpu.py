@@ -82,8 +82,12 @@ def test_conv_planning_is_host_side_and_validates():
     # argument validation happens before any device work
     rc = lib.mvsn_soft_argmin(None, None, 1, 4, 16, None, None)
     assert rc == -1 and b"null" in lib.mvsn_last_error()
-    assert lib.mvsn_incremental_cost_volume_workspace_bytes(4, 16, 32) == 0       # LDS-resident plan
-    assert lib.mvsn_incremental_cost_volume_workspace_bytes(4, 30, 40) > 0        # global planes
+    # direct form: the step's moved features always travel through the workspace (32 x P floats per chain, ABI 3) ...
+    assert lib.mvsn_incremental_cost_volume_workspace_bytes(4, 16, 32) == 4 * 32 * 512 * 4      # ... alone (planes in LDS)
+    assert lib.mvsn_incremental_cost_volume_workspace_bytes(4, 30, 40) > 4 * 32 * 1200 * 4      # ... + global planes
+    assert lib.mvsn_incremental_cost_volume_repair_workspace_bytes(4, 16, 32) == 0   # the repair form there is Winograd
+    assert lib.mvsn_incremental_cost_volume_repair_workspace_bytes(4, 30, 40) == \
+        lib.mvsn_incremental_cost_volume_workspace_bytes(4, 30, 40)
     assert lib.mvsn_incremental_cost_volume_workspace_bytes(1, 32, 64) > 0        # config 5 grid
 
 

@@ -1370,6 +1370,12 @@ def test_forward_baseline_configs_golden(name, what, precision):
     _check_mask4(name, out, fix)
 
 
+# BASELINE config 5's speed tier (bf16 operands, fp32 accumulate on the 32 -> 32 3x3[x3] layers) is outside the 1e-3
+# contract by construction; its OWN error budget against the reference's depth maps, asserted here
+# and quoted by bench.py's `bf16_operand_tier`:
+BF16_TIER_BUDGET = {"mean_rel": 5e-3, "p999_rel_per_pixel": 2e-2, "max_rel_per_pixel": 5e-2}
+
+
 def test_forward_config5_bf16_operand_tier_reported():
     """BASELINE config 5 names a bf16 speed tier.  Plain bf16 operands on the 32->32 3x3[x3] layers are outside
     the 1e-3 contract (SURVEY section 7 measured it), so the error against the reference is REPORTED here and only
@@ -1383,8 +1389,11 @@ def test_forward_config5_bf16_operand_tier_reported():
     finally:
         net.options.conv_precision = "fp32"
     mean_rel, max_rel = rel_err(out["left_idepthmap_pyr"][0].cpu(), fix["idepth_0"])
-    print(f"config 5 [bf16 operands] level 0: mean-rel {mean_rel:.3e} max-rel {max_rel:.3e} (contract 1e-3: outside)")
-    assert mean_rel < 3e-2 and max_rel < 0.2
+    mx, p999 = rel_err_per_pixel(out["left_idepthmap_pyr"][0].cpu(), fix["idepth_0"])
+    print(f"config 5 [bf16 operands] level 0: mean-rel {mean_rel:.3e} max-rel {max_rel:.3e} per-pixel max {mx:.3e} "
+          f"p99.9 {p999:.3e} (contract 1e-3: outside; the tier's own budget: {BF16_TIER_BUDGET})")
+    assert mean_rel < BF16_TIER_BUDGET["mean_rel"] and p999 < BF16_TIER_BUDGET["p999_rel_per_pixel"] and \
+        mx < BF16_TIER_BUDGET["max_rel_per_pixel"], (mean_rel, p999, mx)
     _check_mask4(name, out, fix)
 
 
