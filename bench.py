@@ -527,6 +527,10 @@ def main():
     net.stream_lanes = args.lanes
     net.options.fold_residual_blocks = args.fold
     net.options.conv_precision = args.precision
+    for item in filter(None, os.environ.get("MVSN_BENCH_OPTIONS", "").split(",")):   # A/B aid: engine switches, "name=value,..."
+        key, val = item.split("=")
+        cur = getattr(net.options, key)
+        setattr(net.options, key, type(cur)(int(val)) if isinstance(cur, (bool, int)) else type(cur)(val))
     if args.single_device_selftest:
         net.options.chain_form = "winograd"    # (the banded chain form needs the device to itself: one process per GPU)
     B = args.batch if args.batch > 0 else cfg["batch"]
@@ -580,6 +584,8 @@ def main():
                            "global_batch": B * world, "parallelism": f"dp{world} (independent images, "
                                                                       "all-gather of metric rows)"},
                 "mean_idepth": float(mdist.average_rows(all_rows)[0])}
+        if os.environ.get("MVSN_BENCH_OPTIONS"):
+            line["engine_options_override"] = os.environ["MVSN_BENCH_OPTIONS"]       # (an A/B run, not the default line)
         if args.single_device_selftest:
             line["selftest"] = ("every rank ran on cuda:0 (gloo): the ranks time-share ONE GPU -- the multi-rank plumbing and "
                                 "the per-N quality fields are what this line shows, its rate is not a scaling measurement")
