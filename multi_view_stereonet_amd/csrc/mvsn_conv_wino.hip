@@ -68,6 +68,12 @@ __device__ floatx4 g_wn_zero16 = {0.f, 0.f, 0.f, 0.f};
 #ifndef MVSN_WN_SHIFT
 #define MVSN_WN_SHIFT 1
 #endif
+#ifndef MVSN_WN_XF        // placement of the next step's input transform, see conv_wino_kernel's multiply()
+#define MVSN_WN_XF 0
+#endif
+#ifndef MVSN_WN_STAGGER   // tuning aid: waves 4-7 sleep this many 64-cycle units behind every step barrier
+#define MVSN_WN_STAGGER 0
+#endif
 
 #ifdef MVSN_WN_STAMPS   // tuning aid (tools/wino_phases.py): s_memtime stamps of one mid-launch wave
 __device__ unsigned long long *g_wn_stamps = nullptr;
@@ -215,6 +221,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   constexpr int UST = KS * WN_UFLOATS;               // U of one step (floats)
   static_assert(!VOL || (KS == 2 && DIL == 1), "volume form: 32 channels in steps of 8, dilation 1");
   const int nsteps = (g.nchunks + KS - 1) / KS;      // steps per tile
+  const int uchunks = nsteps * KS;                   // chunks of U in LDS: whole steps (an odd count gets a zero chunk)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
 #ifdef MVSN_WN_STAMPS
   unsigned long long *dbg = (blockIdx.x == gridDim.x / 3 && tid == 0) ? g_wn_stamps : nullptr;
   unsigned long long *dbg_lds = reinterpret_cast<unsigned long long *>(
-      U + (VOL ? NSTAGE * UST : g.nchunks * WN_UFLOATS) + 32 + (RIDE > 0 ? WN_WAVES * RIDE * 256 : 0));
+      U + (VOL ? NSTAGE * UST : uchunks * WN_UFLOATS) + 32 + (RIDE > 0 ? WN_WAVES * RIDE * 256 : 0));
   int dbg_i = 0;
   bool dbg_on = true;
 #endif
@@ -238,11 +245,13 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     const int runs = g.nchunks * (WN_UFLOATS / 256);
     for (int run = wave; run < runs; run += WN_WAVES)
       wn_dma16<ASM_DMA>(upk + (size_t)run * 256 + lane * 4, U + run * 256);
+    if (uchunks != g.nchunks)   // (uniform) the zero chunk: 2048 floats, one 16-byte store per thread
+      *reinterpret_cast<floatx4 *>(U + g.nchunks * WN_UFLOATS + tid * 4) = floatx4{0.f, 0.f, 0.f, 0.f};
   }
 
   // the bias is read from LDS in the tile epilogue: as a global load its s_waitcnt vmcnt(0) would drain the DMA ring
   // (which runs ahead into the next tile) once per tile
-  float *bias_lds = U + (VOL ? NSTAGE * UST : g.nchunks * WN_UFLOATS);
+  float *bias_lds = U + (VOL ? NSTAGE * UST : uchunks * WN_UFLOATS);
   if (tid < 32) bias_lds[tid] = bias ? bias[tid] : 0.0f;   // published by the first barrier
 
   // ---- prefetcher state: DMA of (item, chunk) steps runs two steps ahead of the multiplies
@@ -273,9 +282,13 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     const int tyi = wdiv(tile, g.fd_ntx), txi = tile - tyi * g.ntx;
     const int y0 = tyi * WN_TY, x0 = txi * WN_TX;
     pf_n = n;
+    // (the pieces' rows / columns are re-derived per tile from an opaque copy of the lane id: hoisted out of the tile
+    // loop they occupy six registers for the whole launch -- spilled, and reloaded per step, in the carrying kernels)
+    int lo = lane;
+    asm volatile("" : "+v"(lo));
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int e = (dp0 + i) * 64 + lane;
+      const int e = (dp0 + i) * 64 + lo;
       const int row = e / DQ, q = e - row * DQ;
       const int gy = y0 - DIL + row, gx = x0 - PA + 4 * q;
       pf_goff[i] = (i < dpn && e < GROUPS && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) ? gy * g.W + gx : -1;
@@ -394,9 +407,11 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         const int tyi = wdiv(tile, g.fd_ntx), txi = tile - tyi * g.ntx;
         const int y0 = tyi * WN_TY, x0 = txi * WN_TX;
         xf_mask = 0;
+        int lo = lane;
+        asm volatile("" : "+v"(lo));
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-          const int e = (dp0 + i) * 64 + lane;
+          const int e = (dp0 + i) * 64 + lo;
           const int row = e / DQ, q = e - row * DQ;
           const int gy = y0 - DIL + row, gx = x0 - PA + 4 * q;
           if (i < dpn && e < GROUPS && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) xf_mask |= 1u << i;
@@ -456,9 +471,10 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   //   otherwise: slots (0, 1) = columns (0, 2), slots (2, 3) = columns (1, 3) -- the register pairs two
   //   ds_read2_b32 produce, consumed in place (no re-interleaving moves).
   auto dslot = [](int j) { return SHIFT ? j : (j & 1) * 2 + (j >> 1); };
-  auto tr_load = [&](float (&d)[KS][4][4]) {
+  auto tr_load = [&](float (&d)[KS][4][4], int h0 = 0, int h1 = KS) {
 #pragma unroll
     for (int h = 0; h < KS; ++h) {
+      if (h < h0 || h >= h1) continue;
       const float *raw = smem + tr_stage * STAGE + (h * 4 + kc) * RCST + ya * XS + xa + (PA - DIL) + SHIFT + CSHIFT * (kc & 1);
       if constexpr (SHIFT) {
         const float2 *r2 = reinterpret_cast<const float2 *>(raw);
@@ -530,7 +546,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   float rd_sc = 0.f, rd_sh = 0.f, rd_rsc = 0.f, rd_rsh = 0.f;   // wave-uniform
   int rd_u = 0;                                                 // first unit in flight
   bool rd_ok = false;                                           // ... is one of the job's
-  float *rds = U + (VOL ? NSTAGE * UST : g.nchunks * WN_UFLOATS) + 32 + wave * (RN * 256);
+  float *rds = U + (VOL ? NSTAGE * UST : uchunks * WN_UFLOATS) + 32 + wave * (RN * 256);
   auto rd_issue = [&](int flat, int chunk) {   // flat < 0: nothing to fetch (the set-up's and the last step's)
     if constexpr (RIDE > 0) {
       const int u = ((flat * nsteps + chunk) * WN_WAVES + wave) * RN;
@@ -558,7 +574,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       }
     }
   };
-  auto rd_consume = [&]() {
+  auto rd_consume = [&](int ln) {
     if constexpr (RIDE > 0) {
       // all arithmetic first, then the stores: a store in flight next to a load still awaited makes the compiler
       // drain the queue (it treats mixed loads / stores as unordered) -- the store's whole latency, every step
@@ -570,7 +586,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
 #pragma unroll
         for (int k = 0; k < 4; ++k) o[j][k] = lrelu02(rd_v[j][k] * rd_sc + rd_sh);
         if (rd.res) {
-          const floatx4 r = *reinterpret_cast<const floatx4 *>(rds + j * 256 + lane * 4);
+          const floatx4 r = *reinterpret_cast<const floatx4 *>(rds + j * 256 + ln * 4);
           if (rd.r_stats) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[j][k] += lrelu02(r[k] * rd_rsc + rd_rsh);
@@ -583,7 +599,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       if (rd_ok && !(MVSN_RD_ABLATE & 2)) {   // uniform
 #pragma unroll
         for (int j = 0; j < RN; ++j)
-          __builtin_nontemporal_store(o[j], reinterpret_cast<floatx4 *>(rd.out + (size_t)rd_u * 256 + j * 256 + lane * 4));
+          __builtin_nontemporal_store(o[j], reinterpret_cast<floatx4 *>(rd.out + (size_t)rd_u * 256 + j * 256 + ln * 4));
       }
     }
   };
@@ -609,7 +625,13 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     // lane: cout t*16 + (lane&15); patches p = 4*(lane>>4) + r of patch row `wave`: output rows ya, ya + DIL and
     // columns xa(p), xa(p) + DIL.  Whatever the dilation, the eight columns of a lane's four patches form two
     // aligned groups of four consecutive columns: element (r, second) goes to slot k of group h.
-    const int cl = lane & 15, gq = lane >> 4;
+    // The lane id is re-derived here (two instructions the optimiser cannot hoist): everything the epilogue forms
+    // from it -- output and record addresses, 64-bit per lane -- would otherwise be computed once in front of the tile
+    // loop and carried through it; in the carrying instantiations those values (and `lane` itself) were SPILLED, and a
+    // reload in the epilogue comes with s_waitcnt vmcnt(0): a drain of the tile's output stores and of the DMA ring.
+    int lq;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lq));
+    const int cl = lq & 15, gq = lq >> 4;
     constexpr int PSH = DIL <= 2 ? 1 : 0;   // DIL 1, 2: h = r >> 1; DIL 4, 8: h = second
     auto slot_h = [](int r, int sec) { return PSH ? (r >> 1) : sec; };
     auto slot_k = [](int r, int sec) { return DIL == 1 ? 2 * (r & 1) + sec : (DIL == 2 ? (r & 1) + 2 * sec : r); };
@@ -667,7 +689,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         v += dpp_mov<0x141>(v);   // row_half_mirror
         return v;
       };
-      const int hi = (lane >> 3) & 1;
+      const int hi = (lq >> 3) & 1;
       const float npos = 8.0f * (float)cnt;
       const float rn = cnt == 16 ? 0.0078125f : (cnt == 8 ? 0.015625f : (cnt == 4 ? 0.03125f : 0.0f));   // 1 / npos, exact
       float m[2], qv[2] = {0.f, 0.f};
@@ -691,14 +713,14 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
             }
 #pragma unroll
       for (int t = 0; t < 2; ++t) qv[t] = sum8(qv[t]);
-      if ((lane & 7) == 0) {   // lanes 0 and 8 of every row
-        float *rec = out_partials +
-                     ((((size_t)n * ptiles + (size_t)z * g.tiles + tile_id) * WN_WAVES + wave) * 4 + gq) * 12;
+      if ((lq & 7) == 0) {   // lanes 0 and 8 of every row
+        float *rec = out_partials + (((size_t)n * ptiles + (size_t)z * g.tiles + tile_id) * WN_WAVES + wave) * 48;   // uniform
+        rec += gq * 12 + hi * 3;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          rec[(t * 2 + hi) * 3 + 0] = npos;
-          rec[(t * 2 + hi) * 3 + 1] = m[t];
-          rec[(t * 2 + hi) * 3 + 2] = qv[t];
+          rec[t * 6 + 0] = npos;
+          rec[t * 6 + 1] = m[t];
+          rec[t * 6 + 2] = qv[t];
         }
       }
     }
@@ -737,7 +759,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         else if (rd_young == PER) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
         else if (VOL && rd_young == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        rd_consume();
+        rd_consume(lane);
         waited = true;
       }
       if (has_next) {
@@ -746,13 +768,19 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         xf_apply();        // step + 1
         WN_STAMP();   // landed
         if (!(MVSN_WN_ABLATE & 8)) wn_barrier<LDS_BARRIER>();   // ... for everyone; everyone has read the raw tile of `step`
+        if (MVSN_WN_STAGGER > 0 && wave >= 4) __builtin_amdgcn_s_sleep(MVSN_WN_STAGGER);
         WN_STAMP();   // barrier
         xf_prepare();      // step + 2: its scalar loads travel behind this step's multiplies
       }
       rd_issue(flat, chunk);
       // multiplies of `step` with the transform of `step + 1` slotted between them
+      // (a half that runs as a burst fetches its own patch right in front of its multiplies and consumes it right
+      // behind them: the two halves' patches share their 16 registers)
       float dn[KS][4][4];
-      if (has_next && !(MVSN_WN_ABLATE & 32)) tr_load(dn);
+      if (has_next && !(MVSN_WN_ABLATE & 32)) {
+        if (MVSN_WN_XF == 1) tr_load(dn);
+        else if (MVSN_WN_XF == 0) tr_load(dn, 0, 1);
+      }
       auto multiply = [&](auto first, auto hc) {   // one k-step: 16 coefficient GEMMs x 2 cout tiles
         constexpr bool FIRST = decltype(first)::value;
         constexpr int h = decltype(hc)::value;
@@ -767,11 +795,20 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
           const float d0 = dn[h][0][dslot(j)], d1 = dn[h][1][dslot(j)], d2 = dn[h][2][dslot(j)], d3 = dn[h][3][dslot(j)];
           return i == 0 ? d0 - d2 : (i == 1 ? d1 + d2 : (i == 2 ? d2 - d1 : d1 - d3));
         };
-        float tc[4] = {tcol(0, 0), tcol(0, 1), tcol(0, 2), tcol(0, 3)}, tn[4];
+        // INTER: which k-step halves carry that interleave; the others run their 32 MFMAs as one burst and transform
+        // behind it (MVSN_WN_XF: 0 = first half interleaved, second as a burst; 1 = both interleaved; 2 = both bursts)
+        constexpr bool INTER = MVSN_WN_XF == 1 || (MVSN_WN_XF == 0 && h == 0);
+        float tc[4], tn[4];
+        if constexpr (INTER) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) tc[j] = tcol(0, j);
+        } else {
+          if (has_next && !(MVSN_WN_ABLATE & 32)) tr_load(dn, h, h + 1);
+        }
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {   // next coefficient's U fragments in flight behind this one's MFMAs
           const int cur = xi & 1, ti = xi >> 2, tj = xi & 3;
-          if (ti < 3) tn[tj] = tcol(ti + 1, tj);
+          if (INTER && ti < 3) tn[tj] = tcol(ti + 1, tj);
           if (xi + 1 < 16 && !(MVSN_WN_ABLATE & 2)) {
             fb[cur ^ 1][0] = ub[(xi + 1) * 128];
             fb[cur ^ 1][1] = ub[(xi + 1) * 128 + 64];
@@ -787,22 +824,29 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
             pf_issue();   // raw tile of step + NSTAGE into the stage `step` released
             uq_issue();   // VOL: U of step + NSTAGE - 1 into the slot step - 1 released
           }
-          if (!(MVSN_WN_ABLATE & 1))   // (without a next step dn is undefined and v is never read again)
-            v[h][xi] = tj == 0 ? tc[0] - tc[2] : (tj == 1 ? tc[1] + tc[2] : (tj == 2 ? tc[2] - tc[1] : tc[1] - tc[3]));
-          if (tj == 3) {
+          if constexpr (INTER) {
+            if (!(MVSN_WN_ABLATE & 1))   // (without a next step dn is undefined and v is never read again)
+              v[h][xi] = tj == 0 ? tc[0] - tc[2] : (tj == 1 ? tc[1] + tc[2] : (tj == 2 ? tc[2] - tc[1] : tc[1] - tc[3]));
+            if (tj == 3) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) tc[k] = tn[k];
+              for (int k = 0; k < 4; ++k) tc[k] = tn[k];
+            }
           }
           __builtin_amdgcn_sched_barrier(0);   // keep the interleaving as written (and the live ranges short)
         }
+        if constexpr (!INTER) {
+          if (!(MVSN_WN_ABLATE & 1)) tr_finish(dn, v, h, h + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       };
       multiply(firstc, std::integral_constant<int, 0>{});
-      if constexpr (KS == 2) {
-        if (chunk * KS + 1 < g.nchunks)   // uniform: odd chunk count, nothing in the second half
-          multiply(std::false_type{}, std::integral_constant<int, 1>{});
-        else
-          tr_finish(dn, v, 1, 2);
-      }
+      // Odd chunk counts (the 36-channel heads): the second half of the last step multiplies zero tiles (channels past
+      // cin are fetched from the zero line) with the zero chunk the prologue put behind U.  As an if / else -- "nothing in
+      // the second half: only finish the transform" -- the compiler hoisted / sank the coefficient arithmetic the two arms
+      // had in common out of EVERY instantiation's second half: its 32 VALU instructions (+ 16 register copies) ran
+      // behind the MFMA burst, on both waves of a SIMD at once, with the matrix pipe idle -- ~1 k of the 6 k cycles of
+      // a step (s_memtime stamps, round 4).
+      if constexpr (KS == 2) multiply(std::false_type{}, std::integral_constant<int, 1>{});
       tr_advance();
       if constexpr (VOL) mm_stage = mm_stage + 1 == NSTAGE ? 0 : mm_stage + 1;
       WN_STAMP();   // MFMAs issued + next transform
@@ -815,7 +859,9 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   if constexpr (RIDE > 0) {
     if (total_steps > 0) {   // the last step's units
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      rd_consume();
+      int ln;   // (re-derived: `lane` kept alive across the tile loop for this one use was spilled around it)
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+      rd_consume(ln);
     }
   }
 #ifdef MVSN_WN_STAMPS
@@ -923,7 +969,7 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   // (a carrying launch waits with one step of DMA in flight, see RideArgs: a fourth stage would never be used)
   const int nstage = head ? 6 : ((g.dil == 1 && g.nchunks <= 8 && !job) ? 4 : 3);
   size_t lds = ((size_t)nstage * ks * 4 * wn_rcst(g.dil) +
-                (g.vol ? (size_t)nstage * ks : (size_t)g.nchunks) * WN_UFLOATS) * sizeof(float);
+                (g.vol ? (size_t)nstage * ks : (size_t)((g.nchunks + ks - 1) / ks * ks)) * WN_UFLOATS) * sizeof(float);
   lds += 32 * sizeof(float);                                      // bias
   if (job && !g.vol) lds += (size_t)WN_WAVES * wino_ride_units(g) * 1024;   // the carried job's residual slots
 #ifdef MVSN_WN_STAMPS
