@@ -57,7 +57,7 @@ __device__ floatx4 g_wn_zero16 = {0.f, 0.f, 0.f, 0.f};
 #define WN_GPTR(p) ((const __attribute__((address_space(1))) void *)(p))
 #define WN_LPTR(p) ((__attribute__((address_space(3))) void *)(p))
 
-#ifndef MVSN_WN_ABLATE   // tuning aid: bit 0 no input transform, 1 no U fragment reads, 2 no DMA in the loop, 3 no barrier, 4 no epilogue, 5 no raw reads
+#ifndef MVSN_WN_ABLATE   // tuning aid: bit 0 no input transform, 1 no U fragment reads, 2 no DMA in the loop, 3 no barrier, 4 no epilogue, 5 no raw reads, 6 no output stores
 #define MVSN_WN_ABLATE 0
 #endif
 
@@ -67,6 +67,12 @@ __device__ floatx4 g_wn_zero16 = {0.f, 0.f, 0.f, 0.f};
 
 #ifndef MVSN_WN_SHIFT
 #define MVSN_WN_SHIFT 1
+#endif
+#ifndef MVSN_WN_NT_STORES   // tuning aid: output tiles by non-temporal stores
+#define MVSN_WN_NT_STORES 0
+#endif
+#ifndef MVSN_WN_TRANSPOSED   // dilation-1 kernels: D = couts x patches (0: the patches x couts form of the dilated layers)
+#define MVSN_WN_TRANSPOSED 1
 #endif
 #ifndef MVSN_WN_XF        // placement of the next step's input transform, see conv_wino_kernel's multiply()
 #define MVSN_WN_XF 0
@@ -219,6 +225,8 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   // odd channels are stored DIL floats further, which moves them to the other half (conflict-free)
   constexpr int CSHIFT = (DIL > 1 && MVSN_WN_SHIFT) ? DIL : 0;
   constexpr int UST = KS * WN_UFLOATS;               // U of one step (floats)
+  // dilation 1: accumulators as couts x patches (transposed MFMA operand order) -- fully coalesced output stores
+  constexpr bool TR = DIL == 1 && MVSN_WN_TRANSPOSED;
   static_assert(!VOL || (KS == 2 && DIL == 1), "volume form: 32 channels in steps of 8, dilation 1");
   const int nsteps = (g.nchunks + KS - 1) / KS;      // steps per tile
   const int uchunks = nsteps * KS;                   // chunks of U in LDS: whole steps (an odd count gets a zero chunk)
@@ -669,8 +677,15 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         for (int h = 0; h < 2; ++h) {
           const bool ok = rok && (h ? q1 : q0);
           if (ok) {
-            *reinterpret_cast<floatx4 *>(oc + (size_t)rr * DIL * g.W + (h ? xg1 : xg0)) =
-                floatx4{y[t][rr][4 * h], y[t][rr][4 * h + 1], y[t][rr][4 * h + 2], y[t][rr][4 * h + 3]};
+            if (!(MVSN_WN_ABLATE & 64) || n < 0) {   // (tuning aid: bit 6 = no output stores)
+              const floatx4 yv = floatx4{y[t][rr][4 * h], y[t][rr][4 * h + 1], y[t][rr][4 * h + 2], y[t][rr][4 * h + 3]};
+              floatx4 *op = reinterpret_cast<floatx4 *>(oc + (size_t)rr * DIL * g.W + (h ? xg1 : xg0));
+#if MVSN_WN_NT_STORES
+              __builtin_nontemporal_store(yv, op);
+#else
+              *op = yv;
+#endif
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) s[t] += y[t][rr][4 * h + k];
           }
@@ -722,6 +737,91 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
           rec[t * 6 + 1] = m[t];
           rec[t * 6 + 2] = qv[t];
         }
+      }
+    }
+  };
+
+  // ---- the same for the transposed accumulators (TR, dilation 1): lane = (patch pcol of patch row `wave`, cout quad gq);
+  // acc[xi][t][r] = M_xi[cout t*16 + 4 gq + r][patch].  A patch's 2 x 2 outputs are two float2 stores (rows 2 wave,
+  // 2 wave + 1; columns 2 pcol, 2 pcol + 1): the 16 lanes of a row write 128 contiguous bytes of one output row of one
+  // cout -- four full lines per instruction.  In the patches x couts form a store instruction scattered 64 sixteen-byte
+  // pieces over 16 couts and relied on L2 to merge eight partial writes per line: the stores were 11 % of a 2-D layer
+  // (ablation, round 4), and as non-temporal stores (no merging) the layer was 10 % SLOWER.
+  // GroupNorm records: the 16 lanes of row gq hold, per cout tile t, 4 couts x 4 outputs of group 2 t + (gq >> 1) for
+  // their 16 patches: one record per (wave, gq) as before, with data for two of its four groups and count 0 for the
+  // others (gn_finalize adds cnt, cnt * mean, M2 + cnt * mean^2: an empty group contributes nothing).
+  auto finish_tile_tr = [&](int n, int z, int tile_id, int y0, int x0) {
+    int lq;   // (re-derived, see finish_tile)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lq));
+    const int pc = lq & 15, gq = lq >> 4;
+    const int oy = y0 + 2 * wave, ox = x0 + 2 * pc;
+    const bool row0 = oy < g.H, row1 = oy + 1 < g.H, cok = ox < g.W;   // W % 4 == 0: a column pair is inside or outside
+    const size_t cstride = VOL ? (size_t)g.D * plane : plane;
+    float *ob = out + (size_t)n * 32 * cstride + (size_t)z * plane + (size_t)oy * g.W + ox;
+    float s[2] = {0.f, 0.f};
+    float y[2][4][4];   // [t][r][2 * row + column]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const floatx4 bv = *reinterpret_cast<const floatx4 *>(bias_lds + t * 16 + 4 * gq);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s0[4], s1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s0[j] = acc[j][t][r] + acc[4 + j][t][r] + acc[8 + j][t][r];
+          s1[j] = acc[4 + j][t][r] - acc[8 + j][t][r] - acc[12 + j][t][r];
+        }
+        y[t][r][0] = s0[0] + s0[1] + s0[2] + bv[r];
+        y[t][r][1] = s0[1] - s0[2] - s0[3] + bv[r];
+        y[t][r][2] = s1[0] + s1[1] + s1[2] + bv[r];
+        y[t][r][3] = s1[1] - s1[2] - s1[3] + bv[r];
+        float *oc = ob + (size_t)(t * 16 + 4 * gq + r) * cstride;
+        if (!(MVSN_WN_ABLATE & 64) || n < 0) {
+          if (row0 && cok) *reinterpret_cast<float2 *>(oc) = make_float2(y[t][r][0], y[t][r][1]);
+          if (row1 && cok) *reinterpret_cast<float2 *>(oc + g.W) = make_float2(y[t][r][2], y[t][r][3]);
+        }
+        if (row0 && cok) s[t] += y[t][r][0] + y[t][r][1];
+        if (row1 && cok) s[t] += y[t][r][2] + y[t][r][3];
+      }
+    }
+    WN_STAMP();   // output transform + stores issued
+    if (out_partials != nullptr) {   // uniform
+      auto sum16 = [](float v) {   // all 16 lanes of a row end up with the row's sum
+        v += dpp_mov<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+        v += dpp_mov<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+        v += dpp_mov<0x141>(v);   // row_half_mirror
+        v += dpp_mov<0x140>(v);   // row_mirror
+        return v;
+      };
+      // valid outputs of the record: 4 couts x rows x 2 columns x the tile's valid patch columns (uniform)
+      const int vp = (g.W - x0) >> 1;
+      const float npos = (float)(8 * ((row0 ? 1 : 0) + (row1 ? 1 : 0)) * (vp > 16 ? 16 : vp));
+      float m[2], qv[2] = {0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        s[t] = sum16(s[t]);
+        m[t] = npos > 0.f ? s[t] / npos : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if ((k < 2 ? row0 : row1) && cok) {
+              const float dv = y[t][r][k] - m[t];
+              qv[t] += dv * dv;
+            }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) qv[t] = sum16(qv[t]);
+      if (pc < 4) {   // lane j of the row writes group j of the record: the row's two groups, zeros for the others
+        float *rec = out_partials + (((size_t)n * ptiles + (size_t)z * g.tiles + tile_id) * WN_WAVES + wave) * 48;   // uniform
+        rec += gq * 12 + pc * 3;
+        const int ga = gq >> 1;
+        const bool a = pc == ga, b = pc == 2 + ga;
+        rec[0] = (a || b) ? npos : 0.f;
+        rec[1] = a ? m[0] : (b ? m[1] : 0.f);
+        rec[2] = a ? qv[0] : (b ? qv[1] : 0.f);
       }
     }
   };
@@ -813,12 +913,17 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
             fb[cur ^ 1][0] = ub[(xi + 1) * 128];
             fb[cur ^ 1][1] = ub[(xi + 1) * 128 + 64];
           }
+          // TR (dilation 1): operands swapped -- D = couts x patches, a lane holds 4 consecutive couts of ONE patch,
+          // so the 16 lanes of a row store 128 contiguous bytes of an output row (see finish_tile_tr).  The fragments
+          // are the same registers either way (A and B of 16x16x4 share their lane layout).
           if constexpr (FIRST) {
-            acc[xi][0] = mfma16x16x4(v[h][xi], fb[cur][0], floatx4{0.f, 0.f, 0.f, 0.f});
-            acc[xi][1] = mfma16x16x4(v[h][xi], fb[cur][1], floatx4{0.f, 0.f, 0.f, 0.f});
+            acc[xi][0] = TR ? mfma16x16x4(fb[cur][0], v[h][xi], floatx4{0.f, 0.f, 0.f, 0.f})
+                            : mfma16x16x4(v[h][xi], fb[cur][0], floatx4{0.f, 0.f, 0.f, 0.f});
+            acc[xi][1] = TR ? mfma16x16x4(fb[cur][1], v[h][xi], floatx4{0.f, 0.f, 0.f, 0.f})
+                            : mfma16x16x4(v[h][xi], fb[cur][1], floatx4{0.f, 0.f, 0.f, 0.f});
           } else {
-            acc[xi][0] = mfma16x16x4(v[h][xi], fb[cur][0], acc[xi][0]);
-            acc[xi][1] = mfma16x16x4(v[h][xi], fb[cur][1], acc[xi][1]);
+            acc[xi][0] = TR ? mfma16x16x4(fb[cur][0], v[h][xi], acc[xi][0]) : mfma16x16x4(v[h][xi], fb[cur][0], acc[xi][0]);
+            acc[xi][1] = TR ? mfma16x16x4(fb[cur][1], v[h][xi], acc[xi][1]) : mfma16x16x4(v[h][xi], fb[cur][1], acc[xi][1]);
           }
           if (h == 0 && xi == 1 && has_next && !(MVSN_WN_ABLATE & 4)) {   // behind the first MFMAs:
             pf_issue();   // raw tile of step + NSTAGE into the stage `step` released
@@ -854,7 +959,10 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     };
     do_step(std::true_type{});
     for (chunk = 1; chunk < nsteps; ++chunk) do_step(std::false_type{});
-    if (!(MVSN_WN_ABLATE & 16) || n < 0) finish_tile(n, z, tile_id, y0, x0);
+    if (!(MVSN_WN_ABLATE & 16) || n < 0) {
+      if constexpr (TR) finish_tile_tr(n, z, tile_id, y0, x0);
+      else finish_tile(n, z, tile_id, y0, x0);
+    }
   }
   if constexpr (RIDE > 0) {
     if (total_steps > 0) {   // the last step's units
