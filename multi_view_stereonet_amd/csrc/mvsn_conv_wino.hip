@@ -74,8 +74,14 @@ __device__ floatx4 g_wn_zero16 = {0.f, 0.f, 0.f, 0.f};
 #ifndef MVSN_WN_TRANSPOSED   // dilation-1 kernels: D = couts x patches (0: the patches x couts form of the dilated layers)
 #define MVSN_WN_TRANSPOSED 1
 #endif
+#ifndef MVSN_WN_BUFDMA    // raw tiles through a buffer descriptor (hardware range check), 0: flat addresses + zero line
+#define MVSN_WN_BUFDMA 1
+#endif
+#ifndef MVSN_WN_PIN       // input-transform results pinned where the source computes them (see multiply())
+#define MVSN_WN_PIN 1
+#endif
 #ifndef MVSN_WN_XF        // placement of the next step's input transform, see conv_wino_kernel's multiply()
-#define MVSN_WN_XF 0
+#define MVSN_WN_XF 2
 #endif
 #ifndef MVSN_WN_STAGGER   // tuning aid: waves 4-7 sleep this many 64-cycle units behind every step barrier
 #define MVSN_WN_STAGGER 0
@@ -116,6 +122,28 @@ __device__ __forceinline__ void wn_dma16(const float *g, const float *l) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(la) : "memory", "m0");
   } else {
     __builtin_amdgcn_global_load_lds(WN_GPTR(g), WN_LPTR(l), 16, 0, 0);
+  }
+}
+// The same piece through a buffer descriptor (base = a channel plane, num_records = its bytes): lanes whose offset lies
+// outside -- the marker 0xFFFFFFFF of pieces outside the image, or every lane when the descriptor is empty (a channel /
+// plane that does not exist) -- get ZEROS written to their LDS slot by the hardware's range check.  The flat form needed
+// a 64-bit address per lane and piece with two selects against a zero line: ~8 VALU instructions per piece and step.
+template <bool ASM>
+__device__ __forceinline__ void wn_dma16_buf(const float *base, unsigned bytes, unsigned voff, const float *l) {
+  if constexpr (ASM) {
+    typedef int wn_srd_t __attribute__((ext_vector_type(4)));
+    const size_t b = (size_t)base;
+    wn_srd_t srd;
+    srd[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    srd[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(b >> 32) & 0xFFFFu));
+    srd[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    srd[3] = 0x00020000;
+    const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)WN_LPTR(l));
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(srd), "s"(la)
+                 : "memory", "m0");
+  } else {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)bytes, 0x00020000),
+                                             WN_LPTR(l), 16, (int)voff, 0, 0, 0);
   }
 }
 #pragma clang diagnostic pop
@@ -292,14 +320,14 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     pf_n = n;
     // (the pieces' rows / columns are re-derived per tile from an opaque copy of the lane id: hoisted out of the tile
     // loop they occupy six registers for the whole launch -- spilled, and reloaded per step, in the carrying kernels)
-    int lo = lane;
-    asm volatile("" : "+v"(lo));
+    int lo;   // (from the hardware, not from `lane`: that one gets spilled around the loops, and a reload here waits vmcnt(0))
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int e = (dp0 + i) * 64 + lo;
       const int row = e / DQ, q = e - row * DQ;
       const int gy = y0 - DIL + row, gx = x0 - PA + 4 * q;
-      pf_goff[i] = (i < dpn && e < GROUPS && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) ? gy * g.W + gx : -1;
+      pf_goff[i] = (i < dpn && e < GROUPS && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) ? (gy * g.W + gx) * (MVSN_WN_BUFDMA ? 4 : 1) : -1;
     }
   };
   auto pf_issue = [&]() {   // issue the DMA of the prefetcher's step and advance it
@@ -320,12 +348,18 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
                    : g.in2 + ((size_t)pf_n * (g.cin - g.cb0 - g.cb1) + c2) * plane;
     }
     float *dst = smem + pf_stage * STAGE + dch * RCST + SHIFT + CSHIFT * (dch & 1);
+    const unsigned pbytes = cok ? (unsigned)plane * 4u : 0u;   // (uniform) an empty descriptor: zeros for every lane
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       if (i < dpn) {   // uniform
-        const float *p = (cok && pf_goff[i] >= 0) ? src + pf_goff[i] : zero;
-        if ((dp0 + i) * 64 + lane < GROUPS)   // lanes past the tile's last 16-byte group stay out of the slot
-          wn_dma16<ASM_DMA>(p, dst + (dp0 + i) * 256);
+        if ((dp0 + i) * 64 + lane < GROUPS) {   // lanes past the tile's last 16-byte group stay out of the slot
+          if constexpr (MVSN_WN_BUFDMA) {
+            wn_dma16_buf<ASM_DMA>(src, pbytes, (unsigned)pf_goff[i], dst + (dp0 + i) * 256);   // byte offset; -1: out of range
+          } else {
+            const float *p = (cok && pf_goff[i] >= 0) ? src + pf_goff[i] : zero;
+            wn_dma16<ASM_DMA>(p, dst + (dp0 + i) * 256);
+          }
+        }
       }
     }
     pf_stage = pf_stage + 1 == NSTAGE ? 0 : pf_stage + 1;
@@ -415,8 +449,8 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         const int tyi = wdiv(tile, g.fd_ntx), txi = tile - tyi * g.ntx;
         const int y0 = tyi * WN_TY, x0 = txi * WN_TX;
         xf_mask = 0;
-        int lo = lane;
-        asm volatile("" : "+v"(lo));
+        int lo;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
           const int e = (dp0 + i) * 64 + lo;
@@ -930,8 +964,12 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
             uq_issue();   // VOL: U of step + NSTAGE - 1 into the slot step - 1 released
           }
           if constexpr (INTER) {
-            if (!(MVSN_WN_ABLATE & 1))   // (without a next step dn is undefined and v is never read again)
+            if (!(MVSN_WN_ABLATE & 1)) {   // (without a next step dn is undefined and v is never read again)
               v[h][xi] = tj == 0 ? tc[0] - tc[2] : (tj == 1 ? tc[1] + tc[2] : (tj == 2 ? tc[2] - tc[1] : tc[1] - tc[3]));
+              // pinned here: the coefficient is only USED a step later, and the compiler's sinking pass otherwise moves
+              // the arithmetic towards that use -- out of this half, across the scheduling barriers (seen twice in round 4)
+              if (MVSN_WN_PIN) asm volatile("" : "+v"(v[h][xi]));
+            }
             if (tj == 3) {
 #pragma unroll
               for (int k = 0; k < 4; ++k) tc[k] = tn[k];
@@ -940,7 +978,12 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
           __builtin_amdgcn_sched_barrier(0);   // keep the interleaving as written (and the live ranges short)
         }
         if constexpr (!INTER) {
-          if (!(MVSN_WN_ABLATE & 1)) tr_finish(dn, v, h, h + 1);
+          if (!(MVSN_WN_ABLATE & 1)) {
+            tr_finish(dn, v, h, h + 1);
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi)
+              if (MVSN_WN_PIN) asm volatile("" : "+v"(v[h][xi]));   // (pinned, as above)
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       };

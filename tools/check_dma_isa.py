@@ -7,7 +7,8 @@ waitcnt pass does not see the DMA, so the count is only right while the compiled
 source assumes.  This script compiles the file to assembly with the library's flags and asserts, per such kernel:
 
   1. every LDS-DMA instruction sits in an intact inline-assembly block `s_mov_b32 m0, sN; s_nop 0; global_load_lds_dwordx4`
-     (no builtin-form DMA mixed in, nothing scheduled into the block);
+     (U, the carried job's residual) or `...; buffer_load_dwordx4 vN, s[..], 0 offen lds` (raw tiles, round 4) --
+     no builtin-form DMA mixed in, nothing scheduled into the block;
   2. M0 is written nowhere else in the kernel (nothing can redirect a piece);
   3. no scratch (a spill is a VMEM instruction the counts do not know);
   4. (reported, not asserted) for every hand-placed counted wait `s_waitcnt vmcnt(N)`, N > 0, every control-flow path
@@ -94,12 +95,14 @@ def check(name, p, body):
         if falls and i + 1 < len(bbs):
             preds[i + 1].add(i)
     stream = [x for _, ins in bbs for x in ins]
-    dma_blocks = {i for i, b in enumerate(blocks) if any(x.startswith("global_load_lds") for x in b)}
+    def is_dma(x):   # flat form (U, the carried job's residual) or descriptor form (raw tiles: hardware range check)
+        return x.startswith("global_load_lds_dwordx4") or (x.startswith("buffer_load_dwordx4") and x.endswith(" lds"))
+    dma_blocks = {i for i, b in enumerate(blocks) if any(is_dma(x) for x in b)}
     # 1. block integrity, no DMA outside blocks
     for i in dma_blocks:
         b = blocks[i]
-        if not (len(b) == 3 and b[0].startswith("s_mov_b32 m0, s") and b[1] == "s_nop 0" and b[2].startswith("global_load_lds_dwordx4")):
-            errs.append(f"DMA block {i} is not [s_mov_b32 m0; s_nop 0; global_load_lds_dwordx4]: {b}")
+        if not (len(b) == 3 and b[0].startswith("s_mov_b32 m0, s") and b[1] == "s_nop 0" and is_dma(b[2])):
+            errs.append(f"DMA block {i} is not [s_mov_b32 m0; s_nop 0; global_load_lds_dwordx4 | buffer_load_dwordx4 .. lds]: {b}")
     for t, bk in stream:
         if "load_lds" in t or (t.startswith("buffer_load") and " lds" in t):
             if bk is None:
