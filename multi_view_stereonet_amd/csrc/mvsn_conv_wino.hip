@@ -148,6 +148,26 @@ __device__ __forceinline__ void wn_dma16_buf(const float *base, unsigned bytes, 
 }
 #pragma clang diagnostic pop
 
+// Output tiles and the carried job go through buffer descriptors too: the base and the per-(cout, row) part of an
+// address are scalar (descriptor + soffset), the lane's part is ONE 32-bit offset formed once per tile, and a lane whose
+// columns lie outside the image carries the offset 0xFFFFFFFF -- the range check drops its store.  The flat form spent
+// ~10 VALU instructions per store on 64-bit address arithmetic, 16 stores per tile and wave, each behind its own
+// exec-mask branch: a quarter of a 2-D tile's VALU instructions.
+typedef unsigned wn_uintx2 __attribute__((ext_vector_type(2)));
+typedef unsigned wn_uintx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wn_rsrc(const void *base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void wn_store2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float a, float b) {
+  wn_uintx2 d;
+  d[0] = __builtin_bit_cast(unsigned, a), d[1] = __builtin_bit_cast(unsigned, b);
+  __builtin_amdgcn_raw_buffer_store_b64(d, r, (int)voff, (int)soff, 0);
+}
+template <int AUX>   // 2 = non-temporal
+__device__ __forceinline__ void wn_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, floatx4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wn_uintx4, v), r, (int)voff, (int)soff, AUX);
+}
+
 struct WinoDiv {
   unsigned mul, shift;
 };
@@ -599,15 +619,17 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       const float rstd = wn_sload(rd.stats, ((size_t)n * 4 + (c >> 3)) * 2 + 1);
       rd_sc = rstd * wn_sload(rd.gamma, c);
       rd_sh = wn_sload(rd.beta, c) - mean * rd_sc;
-      const size_t off = (size_t)rd_u * 256 + lane * 4;
+      // (descriptors on the step's units: scalar base, the lane's offset is its constant 16 bytes)
       rd_young = 0;
+      const __amdgpu_buffer_rsrc_t xs = wn_rsrc(rd.x + (size_t)rd_u * 256, RN * 1024);
 #pragma unroll
       for (int j = 0; j < RN; ++j)
         if (!(MVSN_RD_ABLATE & 1))
-          rd_v[j] = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(rd.x + off + j * 256));
+          rd_v[j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(xs, lane * 16 + j * 1024, 0, 2));
       if (rd.res && !(MVSN_RD_ABLATE & 4)) {
 #pragma unroll
-        for (int j = 0; j < RN; ++j) wn_dma16<ASM_DMA>(rd.res + off + j * 256, rds + j * 256);
+        for (int j = 0; j < RN; ++j)
+          wn_dma16_buf<ASM_DMA>(rd.res + (size_t)rd_u * 256, RN * 1024, (unsigned)(lane * 16 + j * 1024), rds + j * 256);
       }
       if (rd.r_stats) {
         const float rm = wn_sload(rd.r_stats, ((size_t)n * 4 + (c >> 3)) * 2 + 0);
@@ -639,9 +661,9 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         }
       }
       if (rd_ok && !(MVSN_RD_ABLATE & 2)) {   // uniform
+        const __amdgpu_buffer_rsrc_t os = wn_rsrc(rd.out + (size_t)rd_u * 256, RN * 1024);
 #pragma unroll
-        for (int j = 0; j < RN; ++j)
-          __builtin_nontemporal_store(o[j], reinterpret_cast<floatx4 *>(rd.out + (size_t)rd_u * 256 + j * 256 + ln * 4));
+        for (int j = 0; j < RN; ++j) wn_store4<2>(os, (unsigned)(ln * 16 + j * 1024), 0, o[j]);
       }
     }
   };
@@ -683,7 +705,10 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     const bool row0 = oy < g.H, row1 = oy + DIL < g.H;
     const bool q0 = x0 + xg0 < g.W, q1 = x0 + xg1 < g.W;   // W % 4 == 0: each float4 is all inside or all outside
     const size_t cstride = VOL ? (size_t)g.D * plane : plane;   // output channel stride
-    float *outn = out + (size_t)n * 32 * cstride + (size_t)z * plane;
+    // descriptor of this sample's [plane z of the] 32 output channels; lane part: its cout and first column
+    const __amdgpu_buffer_rsrc_t osrd = wn_rsrc(out + (size_t)n * 32 * cstride + (size_t)z * plane, (unsigned)(32 * cstride * 4));
+    const unsigned obase = ((unsigned)cl * (unsigned)cstride + (unsigned)(oy * g.W + x0)) * 4u;
+    const unsigned ovoff0 = q0 ? obase + (unsigned)xg0 * 4u : 0xFFFFFFFFu, ovoff1 = q1 ? obase + (unsigned)xg1 * 4u : 0xFFFFFFFFu;
     const int cnt = ((row0 ? 1 : 0) + (row1 ? 1 : 0)) * ((q0 ? 4 : 0) + (q1 ? 4 : 0));
     float s[2] = {0.f, 0.f};
     float y[2][2][8];   // [t][row][group * 4 + slot]
@@ -703,23 +728,17 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         y[t][1][slot_h(r, 0) * 4 + slot_k(r, 0)] = s1[0] + s1[1] + s1[2] + bv;
         y[t][1][slot_h(r, 1) * 4 + slot_k(r, 1)] = s1[1] - s1[2] - s1[3] + bv;
       }
-      float *oc = outn + (size_t)(t * 16 + cl) * cstride + (size_t)oy * g.W + x0;
 #pragma unroll
       for (int rr = 0; rr < 2; ++rr) {
-        const bool rok = rr ? row1 : row0;
+        const bool rok = rr ? row1 : row0;   // uniform
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const bool ok = rok && (h ? q1 : q0);
+          if (rok && (!(MVSN_WN_ABLATE & 64) || n < 0))   // (tuning aid: bit 6 = no output stores)
+            wn_store4<MVSN_WN_NT_STORES ? 2 : 0>(
+                osrd, h ? ovoff1 : ovoff0, (unsigned)(((size_t)(t * 16) * cstride + (size_t)rr * DIL * g.W) * 4),
+                floatx4{y[t][rr][4 * h], y[t][rr][4 * h + 1], y[t][rr][4 * h + 2], y[t][rr][4 * h + 3]});
           if (ok) {
-            if (!(MVSN_WN_ABLATE & 64) || n < 0) {   // (tuning aid: bit 6 = no output stores)
-              const floatx4 yv = floatx4{y[t][rr][4 * h], y[t][rr][4 * h + 1], y[t][rr][4 * h + 2], y[t][rr][4 * h + 3]};
-              floatx4 *op = reinterpret_cast<floatx4 *>(oc + (size_t)rr * DIL * g.W + (h ? xg1 : xg0));
-#if MVSN_WN_NT_STORES
-              __builtin_nontemporal_store(yv, op);
-#else
-              *op = yv;
-#endif
-            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) s[t] += y[t][rr][4 * h + k];
           }
@@ -791,7 +810,8 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     const int oy = y0 + 2 * wave, ox = x0 + 2 * pc;
     const bool row0 = oy < g.H, row1 = oy + 1 < g.H, cok = ox < g.W;   // W % 4 == 0: a column pair is inside or outside
     const size_t cstride = VOL ? (size_t)g.D * plane : plane;
-    float *ob = out + (size_t)n * 32 * cstride + (size_t)z * plane + (size_t)oy * g.W + ox;
+    const __amdgpu_buffer_rsrc_t osrd = wn_rsrc(out + (size_t)n * 32 * cstride + (size_t)z * plane, (unsigned)(32 * cstride * 4));
+    const unsigned ovoff = cok ? ((unsigned)(4 * gq) * (unsigned)cstride + (unsigned)(oy * g.W + ox)) * 4u : 0xFFFFFFFFu;
     float s[2] = {0.f, 0.f};
     float y[2][4][4];   // [t][r][2 * row + column]
 #pragma unroll
@@ -809,10 +829,10 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         y[t][r][1] = s0[1] - s0[2] - s0[3] + bv[r];
         y[t][r][2] = s1[0] + s1[1] + s1[2] + bv[r];
         y[t][r][3] = s1[1] - s1[2] - s1[3] + bv[r];
-        float *oc = ob + (size_t)(t * 16 + 4 * gq + r) * cstride;
-        if (!(MVSN_WN_ABLATE & 64) || n < 0) {
-          if (row0 && cok) *reinterpret_cast<float2 *>(oc) = make_float2(y[t][r][0], y[t][r][1]);
-          if (row1 && cok) *reinterpret_cast<float2 *>(oc + g.W) = make_float2(y[t][r][2], y[t][r][3]);
+        if (!(MVSN_WN_ABLATE & 64) || n < 0) {   // (rows: uniform; columns outside the image: dropped by the range check)
+          const unsigned so = (unsigned)((size_t)(t * 16 + r) * cstride * 4);
+          if (row0) wn_store2(osrd, ovoff, so, y[t][r][0], y[t][r][1]);
+          if (row1) wn_store2(osrd, ovoff, so + (unsigned)g.W * 4u, y[t][r][2], y[t][r][3]);
         }
         if (row0 && cok) s[t] += y[t][r][0] + y[t][r][1];
         if (row1 && cok) s[t] += y[t][r][2] + y[t][r][3];
