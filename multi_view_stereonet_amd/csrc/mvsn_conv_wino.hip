@@ -80,6 +80,12 @@ __device__ floatx4 g_wn_zero16 = {0.f, 0.f, 0.f, 0.f};
 #ifndef MVSN_WN_PIN       // input-transform results pinned where the source computes them (see multiply())
 #define MVSN_WN_PIN 1
 #endif
+#ifndef MVSN_WN_NT_TR     // tuning aid: the transposed epilogue's (full-line) stores non-temporal
+#define MVSN_WN_NT_TR 0
+#endif
+#ifndef MVSN_WN_NT_RAW    // tuning aid: raw-tile DMA with the nt hint
+#define MVSN_WN_NT_RAW 0
+#endif
 #ifndef MVSN_WN_XF        // placement of the next step's input transform, see conv_wino_kernel's multiply()
 #define MVSN_WN_XF 2
 #endif
@@ -139,11 +145,16 @@ __device__ __forceinline__ void wn_dma16_buf(const float *base, unsigned bytes, 
     srd[2] = __builtin_amdgcn_readfirstlane((int)bytes);
     srd[3] = 0x00020000;
     const unsigned la = __builtin_amdgcn_readfirstlane((unsigned)(size_t)WN_LPTR(l));
+#if MVSN_WN_NT_RAW
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen nt lds" ::"v"(voff), "s"(srd), "s"(la)
+                 : "memory", "m0");
+#else
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(srd), "s"(la)
                  : "memory", "m0");
+#endif
   } else {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)bytes, 0x00020000),
-                                             WN_LPTR(l), 16, (int)voff, 0, 0, 0);
+                                             WN_LPTR(l), 16, (int)voff, 0, 0, MVSN_WN_NT_RAW ? 2 : 0);
   }
 }
 #pragma clang diagnostic pop
@@ -158,10 +169,11 @@ typedef unsigned wn_uintx4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wn_rsrc(const void *base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
 }
+template <int AUX>   // 2 = non-temporal
 __device__ __forceinline__ void wn_store2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float a, float b) {
   wn_uintx2 d;
   d[0] = __builtin_bit_cast(unsigned, a), d[1] = __builtin_bit_cast(unsigned, b);
-  __builtin_amdgcn_raw_buffer_store_b64(d, r, (int)voff, (int)soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(d, r, (int)voff, (int)soff, AUX);
 }
 template <int AUX>   // 2 = non-temporal
 __device__ __forceinline__ void wn_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, floatx4 v) {
@@ -831,8 +843,8 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         y[t][r][3] = s1[1] - s1[2] - s1[3] + bv[r];
         if (!(MVSN_WN_ABLATE & 64) || n < 0) {   // (rows: uniform; columns outside the image: dropped by the range check)
           const unsigned so = (unsigned)((size_t)(t * 16 + r) * cstride * 4);
-          if (row0) wn_store2(osrd, ovoff, so, y[t][r][0], y[t][r][1]);
-          if (row1) wn_store2(osrd, ovoff, so + (unsigned)g.W * 4u, y[t][r][2], y[t][r][3]);
+          if (row0) wn_store2<MVSN_WN_NT_TR ? 2 : 0>(osrd, ovoff, so, y[t][r][0], y[t][r][1]);
+          if (row1) wn_store2<MVSN_WN_NT_TR ? 2 : 0>(osrd, ovoff, so + (unsigned)g.W * 4u, y[t][r][2], y[t][r][3]);
         }
         if (row0 && cok) s[t] += y[t][r][0] + y[t][r][1];
         if (row1 && cok) s[t] += y[t][r][2] + y[t][r][3];
