@@ -1060,6 +1060,8 @@ bool wino_geom(const mvsn_conv_desc *d, WinoGeom *g) {
   if (d->kd == 1 && d->depth != 1) return false;
   if (d->dilation != 1 && d->dilation != 2 && d->dilation != 4 && d->dilation != 8) return false;
   if (d->cols % 4 != 0) return false;
+  // tiles travel through buffer descriptors with 32-bit byte offsets: a sample's 32 channels must stay below 4 GB
+  if ((unsigned long long)d->depth * d->rows * d->cols * 32ull * 4ull >= (1ull << 32)) return false;
   g->n = d->n, g->cin = d->c_in, g->H = d->rows, g->W = d->cols, g->dil = d->dilation;
   g->D = d->depth, g->vol = d->kd == 3;
   g->nty = (d->rows + WN_TY - 1) / WN_TY;
