@@ -118,6 +118,30 @@ def run_forward(net, inp, d=D):
                [True] * 5)
 
 
+def headline_by_batch(net, dev, batches=(128, 384, 512)):
+    """The headline forward at other batch sizes (images per step), same protocol as other_configs: the timed region's
+    256 images are two rounds of one chain per CU; rounds 1-2 quoted 128 images, and the persistent kernels' prologues
+    and tails keep amortising beyond 256 (memory: 17 / 52 / 70 GB)."""
+    cfg, res = CONFIGS["headline"], {}
+    for b in batches:
+        _, inp, _ = config_inputs(cfg, b, 0, dev)
+        for _ in range(2):
+            run_forward(net, inp, cfg["D"])
+        torch.cuda.synchronize()
+        blocks = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(2):
+                run_forward(net, inp, cfg["D"])
+            torch.cuda.synchronize()
+            blocks.append((time.perf_counter() - t0) / 2 * 1e3)
+        ms = sorted(blocks)[1]
+        res[f"B={b}"] = {"ms_per_step": round(ms, 2), "depthmaps_per_s": round(b / ms * 1e3, 1)}
+        del inp
+        torch.cuda.empty_cache()
+    return res
+
+
 def other_configs(dev, skip):
     """BASELINE configs 2-5 at their stated sizes on this GPU: ms per forward at batch 1 and at the config's batch,
     and the depth error of image 0 against the reference-generated fixture (same contract as the headline)."""
@@ -674,6 +698,7 @@ def main():
             for key, leg in (("pcie_inclusive", lambda: host_feed_rates(net, B, dev)),
                              ("evaluate_rate", lambda: evaluate_rate(net, B, dev, line["value"])),
                              ("batch_latency", lambda: batch_latency(net)),
+                             ("headline_by_batch", lambda: headline_by_batch(net, dev)),
                              ("other_configs", lambda: other_configs(dev, skip=("headline",)))):
                 try:
                     line[key] = leg()

@@ -17,15 +17,21 @@
 //   * the haloed raw tiles (dilation 1: 18 rows x 40 columns from the aligned column x0 - 4) arrive by LDS-DMA
 //     (16-byte pieces, 12 instructions per 4-channel chunk per CU) in a 3-6 stage ring that runs ahead across tile
 //     boundaries (a chunk is only 32 MFMAs per wave, shorter than a DMA round trip); one barrier per step of one
-//     or two chunks (template KS);
+//     or two chunks (template KS).  Round 4: the pieces are `buffer_load_dwordx4 .. offen lds` on a descriptor of the
+//     channel plane -- one 32-bit byte offset per piece, computed once per tile; pieces outside the image carry
+//     0xFFFFFFFF and the hardware's range check writes their zeros (wn_dma16_buf);
 //   * wave w owns patch row w (16 patches) and both cout tiles.  Lane (k = lane>>4, p = lane&15) reads the 4 x 4
 //     input patch p of channel k from the raw tile and transforms it in registers (B^T d B: 32 adds): the 16
 //     coefficients it ends up with are exactly its A-fragment values (A = V_xi: 16 patches x 4 cins), so the
 //     transformed input never touches LDS;
 //   * per chunk 16 xi x 2 MFMAs with B = U_xi (4 cins x 16 couts) read from LDS; 128 accumulator registers;
-//   * output transform in registers (D = patches x couts: a lane holds 4 consecutive patches of one cout, i.e.
-//     8 consecutive output columns of 2 rows): A^T m A (24 adds per patch), bias, 16-byte stores, per-wave
-//     GroupNorm partials.
+//   * output transform in registers: A^T m A (24 adds per patch), bias, per-wave GroupNorm partials.  Dilated
+//     layers: D = patches x couts (a lane holds 4 consecutive patches of one cout = 8 output columns of 2 rows,
+//     16-byte stores); dilation 1 (round 4): operands swapped, D = couts x patches (a lane holds 4 couts of ONE patch,
+//     float2 stores: 16 lanes = 128 contiguous bytes of an output row).  All stores through buffer descriptors.
+//   * (round 4) per k-step half: the 32 MFMAs as one burst, then the next step's input transform as one block
+//     (MVSN_WN_XF); every VALU instruction next to the multiplies costs the matrix pipe ~2 cycles per MFMA
+//     (profiles/r04_micro/README.md), so address arithmetic lives in descriptors and scalar registers.
 // MODE 1: the previous layer's LeakyReLU(GroupNorm(.)) is applied in LDS, once per element, by the wave that
 // fetched the piece (out-of-image pieces keep their zeros, as the padding of the materialised tensor would be).
 // LDS layout details that matter: dilation-1 tiles sit one float further (patches start at even columns: a row is
