@@ -768,19 +768,33 @@ constexpr int HD_CST = HD_ROWS * HD_XS + 4;                                     
 constexpr int HD_KSTEPS = 19;
 static_assert(3 * HD_CST < 65536, "k-step offsets are packed as 16-bit values");
 
-__global__ __launch_bounds__(256, 4) void conv5x5s2_head_kernel(const float *__restrict__ in, const float *__restrict__ wpk,
+#ifndef MVSN_HEAD_WGS_PER_CU
+#define MVSN_HEAD_WGS_PER_CU 3
+#endif
+#ifndef MVSN_HEAD_CNTWAIT   // 1: counted wait at the top of a tile (measured equal; 0 does not lean on retirement order)
+#define MVSN_HEAD_CNTWAIT 0
+#endif
+#ifndef MVSN_HEAD_ABLATE   // timing experiments only: 1 no stores, 2 no tile fetch, 4 no multiplies
+#define MVSN_HEAD_ABLATE 0
+#endif
+#ifndef MVSN_HEAD_ST_AUX
+#define MVSN_HEAD_ST_AUX 0
+#endif
+__global__ __launch_bounds__(256, MVSN_HEAD_WGS_PER_CU) void conv5x5s2_head_kernel(const float *__restrict__ in, const float *__restrict__ wpk,
                                                              const float *__restrict__ bias, int H, int W, int Ho,
-                                                             int Wo, int ntx, int tiles, float *__restrict__ out) {
-  __shared__ __attribute__((aligned(16))) float tile[3 * HD_CST];
+                                                             int Wo, int ntx, int tiles, int total,
+                                                             float *__restrict__ out) {
+  // Round 4: persistent workgroups (MVSN_HEAD_WGS_PER_CU per CU) walking (image, tile) ids with a two-slot tile ring
+  // filled by `buffer_load_dwordx4 .. lds`: tile i + 1 lands while tile i is multiplied, the weight fragments are
+  // fetched once per workgroup.  (One short-lived workgroup per tile -- the round-2 form -- spent two thirds of its
+  // life in the fragment gather, the staging through registers and the store tail: 0.41 of the fp32 roof.)
+  __shared__ __attribute__((aligned(16))) float ring[2][3 * HD_CST];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = blockIdx.y;
   const size_t plane = (size_t)H * W;
-  const float *inn = in + (size_t)n * 3 * plane;
 
   // weight fragments of every k-step (k = 4 ks + (lane>>4) -> channel k / 25, tap k % 25) out of the generic packed
-  // layout [tap][cout tile][lane = cin*16 + cout], once per workgroup (it walks gridDim.x-strided tiles of its image);
-  // the LDS offset of this lane's k inside the tile
+  // layout [tap][cout tile][lane = cin*16 + cout]; the LDS offset of this lane's k inside the tile
   const int kk = lane >> 4, cl = lane & 15;
   float wf[HD_KSTEPS][2];
   unsigned kpk[(HD_KSTEPS + 1) / 2] = {};   // tile offsets of the k-steps, two 16-bit values per register
@@ -794,62 +808,105 @@ __global__ __launch_bounds__(256, 4) void conv5x5s2_head_kernel(const float *__r
     const unsigned ko = ch * HD_CST + (tap / 5) * HD_XS + (tap % 5) + 2;   // input column of tap tx: 2 xx + tx - 2 -> tile column + 2
     kpk[ks >> 1] |= (ks & 1) ? ko << 16 : ko;
   }
-  float *outn = out + (size_t)n * 32 * Ho * Wo;
+  const float bv0 = bias ? bias[cl] : 0.0f, bv1 = bias ? bias[16 + cl] : 0.0f;
 
-  for (int tile_id = blockIdx.x; tile_id < tiles; tile_id += gridDim.x) {
-  const int tyi = tile_id / ntx, txi = tile_id - tyi * ntx;
-  const int y0 = tyi * HD_TY, x0 = txi * HD_TX;
-  if (tile_id != (int)blockIdx.x) __syncthreads();   // everyone is done reading the previous tile
-
-  // stage the haloed tile: rows 2 y0 - 2 .. + 18, columns 2 x0 - 4 .. + 67 as 16-byte groups (W % 4 == 0: a group is
-  // entirely inside or entirely outside the image)
-  constexpr int GROUPS = 3 * HD_ROWS * (HD_XS / 4);   // 1026
-  for (int e = tid; e < GROUPS; e += 256) {
-    const int c = e / (HD_ROWS * (HD_XS / 4)), r = e - c * (HD_ROWS * (HD_XS / 4));
-    const int row = r / (HD_XS / 4), q = r - row * (HD_XS / 4);
-    const int gy = 2 * y0 - 2 + row, gx = 2 * x0 - 4 + 4 * q;
-    floatx4 v = floatx4{0.f, 0.f, 0.f, 0.f};
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *reinterpret_cast<const floatx4 *>(inn + (size_t)c * plane + (size_t)gy * W + gx);
-    *reinterpret_cast<floatx4 *>(tile + c * HD_CST + row * HD_XS + 4 * q) = v;
+  // The haloed tile: rows 2 y0 - 2 .. + 18, columns 2 x0 - 4 .. + 67 as 16-byte groups (W % 4 == 0: a group is entirely
+  // inside or entirely outside the image).  A channel's 342 groups are contiguous in LDS, so piece k of channel c is
+  // 64 consecutive groups = one DMA instruction; rows outside the image fall outside the range of the channel plane's
+  // descriptor (zeros from the hardware), columns outside get the offset 0xFFFFFFFF.
+  constexpr int CG = HD_ROWS * (HD_XS / 4);            // 342 groups per channel
+  constexpr int CP = (CG + 63) / 64;                   // 6 pieces per channel
+  constexpr int NP = (3 * CP + 3) / 4;                 // pieces per wave (the last round only waves 0, 1)
+  int prel[NP], pqx[NP];                               // (row - 2) * W + 4 q - 4 and 4 q - 4 of this lane's group; < 0 row: none
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int pc = wave + 4 * i, k = pc % CP;
+    const int gi = k * 64 + lane, row = gi / (HD_XS / 4), q = gi - row * (HD_XS / 4);
+    pqx[i] = gi < CG ? 4 * q - 4 : -0x40000000;       // a group past the channel's 342: never inside [0, W)
+    prel[i] = (row - 2) * W + 4 * q - 4;
   }
-
-  __syncthreads();
-
-  // pixel tile pt = wave*4 + j: output row pt >> 1, columns (pt & 1) * 16 .. + 15
-  floatx4 acc[4][2];
-  int pbase[4];
+  auto issue = [&](int id, int slot) {
+    const int n = id / tiles, t = id - n * tiles;
+    const int tyi = t / ntx, txi = t - tyi * ntx;
+    const int org = 2 * (tyi * HD_TY) * W + 2 * (txi * HD_TX), x2 = 2 * (txi * HD_TX);
+    const float *inn = in + (size_t)n * 3 * plane;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int pt = wave * 4 + j;
-    pbase[j] = (2 * (pt >> 1)) * HD_XS + 2 * ((pt & 1) * 16 + cl);
-    acc[j][0] = acc[j][1] = floatx4{0.f, 0.f, 0.f, 0.f};
-  }
-#pragma unroll
-  for (int ks = 0; ks < HD_KSTEPS; ++ks) {
-    const int ko = (ks & 1) ? (int)(kpk[ks >> 1] >> 16) : (int)(kpk[ks >> 1] & 0xffffu);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float a = tile[pbase[j] + ko];
-      acc[j][0] = mfma16x16x4(a, wf[ks][0], acc[j][0]);
-      acc[j][1] = mfma16x16x4(a, wf[ks][1], acc[j][1]);
-    }
-  }
-
-  // lane: cout t*16 + cl, the four consecutive pixels 4*(lane>>4) .. + 3 of each pixel tile
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const float bv = bias ? bias[t * 16 + cl] : 0.0f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int pt = wave * 4 + j;
-      const int oy = y0 + (pt >> 1), ox = x0 + (pt & 1) * 16 + 4 * kk;
-      if (oy < Ho && ox < Wo) {   // Wo % 4 == 0: all four pixels or none
-        floatx4 v = acc[j][t];
-        v[0] += bv, v[1] += bv, v[2] += bv, v[3] += bv;
-        *reinterpret_cast<floatx4 *>(outn + ((size_t)(t * 16 + cl) * Ho + oy) * Wo + ox) = v;
+    for (int i = 0; i < NP; ++i) {
+      const int pc = wave + 4 * i;                     // (uniform) piece of this wave
+      if (pc < 3 * CP) {
+        const int c = pc / CP, k = pc - c * CP;
+        const int gx = x2 + pqx[i];
+        const unsigned voff = (gx >= 0 && gx < W) ? (unsigned)((org + prel[i]) * 4) : 0xFFFFFFFFu;   // rows above wrap out of range too
+        if (pqx[i] > -0x40000000 && !(MVSN_HEAD_ABLATE & 2))
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(inn + (size_t)c * plane), 0, (int)(plane * 4), 0x00020000),
+              (__attribute__((address_space(3))) void *)(&ring[slot][c * HD_CST + k * 256]), 16, (int)voff, 0, 0, 0);
       }
     }
-  }
+  };
+
+  // pixel tile pt = wave*4 + j: output row pt >> 1, columns (pt & 1) * 16 .. + 15
+  // (tile j of the wave sits at a constant distance from tile 0 -- one address per k-step, the rest as the reads' immediates)
+  const int pbase0 = (4 * wave) * HD_XS + 2 * cl;
+  const int oplane = Ho * Wo;
+
+  int id = blockIdx.x;
+  if (id < total) issue(id, 0);
+  for (int it = 0; id < total; id += gridDim.x, ++it) {
+    const int slot = it & 1;
+    // (the counted form: behind this tile's DMA instructions the wave has issued exactly the previous tile's eight
+    // stores, so the tile has landed when at most eight are outstanding -- measured equal to the full wait:
+    // profiles/r04_micro)
+    if (MVSN_HEAD_CNTWAIT && it > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // this tile has landed for every wave; everyone is done reading the other slot
+    if (id + (int)gridDim.x < total) issue(id + gridDim.x, slot ^ 1);
+    const float *tile0 = &ring[0][0] + slot * (3 * HD_CST) + pbase0;
+
+    floatx4 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j][0] = acc[j][1] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < ((MVSN_HEAD_ABLATE & 4) ? 1 : HD_KSTEPS); ++ks) {
+      const int ko = (ks & 1) ? (int)(kpk[ks >> 1] >> 16) : (int)(kpk[ks >> 1] & 0xffffu);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = tile0[ko + (j >> 1) * 2 * HD_XS + (j & 1) * 32];
+        acc[j][0] = mfma16x16x4(a, wf[ks][0], acc[j][0]);
+        acc[j][1] = mfma16x16x4(a, wf[ks][1], acc[j][1]);
+      }
+    }
+
+    // lane: cout t*16 + cl, the four consecutive pixels 4*(lane>>4) .. + 3 of each pixel tile.  Stores through a
+    // descriptor of the image's 32 output planes: one 32-bit offset per lane and column half, the row / cout-tile
+    // part as the instruction's scalar offset; columns past the image carry an out-of-range offset and are dropped
+    // by the hardware, rows past it likewise.
+    const int n = id / tiles, t = id - n * tiles;
+    const int tyi = t / ntx, txi = t - tyi * ntx;
+    const int y0 = tyi * HD_TY, x0 = txi * HD_TX;
+    const __amdgpu_buffer_rsrc_t osrd =
+        __builtin_amdgcn_make_buffer_rsrc(out + (size_t)n * 32 * oplane, 0, (int)((size_t)32 * oplane * 4), 0x00020000);
+    unsigned ovoff[2];
+#pragma unroll
+    for (int hx = 0; hx < 2; ++hx) {
+      const int ox = x0 + hx * 16 + 4 * kk;   // Wo % 4 == 0: all four pixels or none
+      ovoff[hx] = ox < Wo ? (unsigned)((cl * oplane + ox) * 4) : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const float bv = tt ? bv1 : bv0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int pt = wave * 4 + j;
+        const int oy = y0 + (pt >> 1);
+        floatx4 v = acc[j][tt];
+        v[0] += bv, v[1] += bv, v[2] += bv, v[3] += bv;
+        // (a row past the image: the same store with an out-of-range offset -- always eight stores per tile)
+        if (!(MVSN_HEAD_ABLATE & 1) || v[0] == 12345.f)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), osrd,
+                                               oy < Ho ? (int)ovoff[pt & 1] : -1, oy < Ho ? (tt * 16 * oplane + oy * Wo) * 4 : 0, MVSN_HEAD_ST_AUX);
+      }
+    }
   }   // tiles of this workgroup
 }
 
@@ -1078,18 +1135,18 @@ extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, co
   // ---- the extractor's 3 -> 32 5x5 stride-2 head: K = 75 packing (no fused transform / statistics on this layer) ----
   if (desc->precision == MVSN_CONV_FP32 && desc->c_in == 3 && desc->c_out == 32 && desc->kd == 1 && desc->kh == 5 &&
       desc->kw == 5 && desc->stride == 2 && desc->dilation == 1 && desc->depth == 1 && (desc->cols & 7) == 0 &&
+      (size_t)desc->rows * desc->cols * 4 < ((size_t)1 << 31) &&   // descriptor ranges / 32-bit offsets of the kernel
       !in_stats && !in_residual && !out_staged && !out_partials && ((size_t)in & 15) == 0 && ((size_t)out & 15) == 0) {
     MVSN_REQUIRE(desc->n <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_forward: batch too large for one launch");
     const int Ho = (desc->rows - 1) / 2 + 1, Wo = (desc->cols - 1) / 2 + 1;
     const int nty = (Ho + HD_TY - 1) / HD_TY, ntx = (Wo + HD_TX - 1) / HD_TX, tiles = nty * ntx;
     // (__launch_bounds__(256, 4): 128 VGPRs -- the k-step offsets packed two per register -- so that FOUR of these
-    // workgroups share a CU, 156 VGPRs allowed three: 2.10 -> 1.83 ms on the bench's 768 frames)
-    // one tile per workgroup: measured 0.84 ms for the 384-frame batch against 1.02 ms with ~8 persistent
-    // workgroups per CU walking 21 tiles each (four short-lived workgroups per CU overlap each other's staging,
-    // multiplies and stores; a persistent one serialises them behind its barrier)
-    const int gx = tiles;
-    hipLaunchKernelGGL(conv5x5s2_head_kernel, dim3(gx, desc->n), dim3(256), 0, (hipStream_t)stream, in,
-                       weight_packed, bias, desc->rows, desc->cols, Ho, Wo, ntx, tiles, out);
+    // workgroups share a CU and cover each other's barrier and store tails)
+    MVSN_REQUIRE((long long)tiles * desc->n < (1ll << 31) - 65536, MVSN_E_TOOLARGE, "mvsn_conv_forward: batch too large for one launch");
+    const int total = tiles * desc->n;
+    const int gx = std::min(total, MVSN_HEAD_WGS_PER_CU * device_cus());
+    hipLaunchKernelGGL(conv5x5s2_head_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, in, weight_packed, bias,
+                       desc->rows, desc->cols, Ho, Wo, ntx, tiles, total, out);
     return check_launch("mvsn_conv_forward(5x5 stride-2 head)");
   }
   MVSN_REQUIRE(!in_stats || (in_gamma && in_beta), MVSN_E_BADARG, "mvsn_conv_forward: input transform needs gamma/beta");
