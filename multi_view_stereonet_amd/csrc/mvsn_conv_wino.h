@@ -11,6 +11,7 @@ struct WinoGeom {
   int n, cin, H, W, dil;
   int D;      // planes per sample (1 for the 2-D layers)
   bool vol;   // 3 x 3 x 3 layer (volume form)
+  bool s2;    // 5 x 5 stride-2 layer on the input's four phases
   int nty, ntx, tiles, nchunks;
   size_t packed_floats;
 };

@@ -1059,9 +1059,235 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 5 x 5 stride-2 32 -> 32 layers (the extractor's downsampling convolutions, multi_view_stereonet.py:78-129) as
+// Winograd F(2x2,3x3) on the four stride-2 phases of the input: with P_{py,px}(r, c) = in(2r + py, 2c + px),
+//   out(oy, ox) = sum_{py,px} sum_{a,b} g_{py,px}[a][b] * P_{py,px}(oy + a - 1, ox + b - 1),
+//   g_{py,px}[a][b] = w[2a + py][2b + px]   (zero where 2a + py = 5 or 2b + px = 5),
+// i.e. a 3 x 3 stride-1 pad-1 layer with 128 input channels.  Per output and (cin, cout) pair 16 products per 2 x 2
+// patch and phase; an odd phase's third tap row / column is zero, so are its coefficients xi = (3, .) / (., 3): 49 of
+// the 64 coefficient GEMMs remain -- 392 multiplies per 2 x 2 outputs and channel pair instead of the direct form's
+// 800 (x 0.49).  The raw tile stays in the image's own layout (fetched by descriptor LDS-DMA like conv_wino_kernel's); a
+// phase is the same tile sampled at stride 2 from (py, px) -- what a dilation-2 layer's patches do.
+//
+// Persistent workgroups of 8 waves, one per CU; tile = 16 x 32 outputs (8 x 16 patches, wave = patch row); a step =
+// 4 input channels x 4 phases (98 MFMAs per wave) on one raw stage (4 channels x 35 rows x 72 columns) and that
+// step's 32 KB of U, both double-buffered, one barrier per step.
+constexpr int S2_TY = 16, S2_TX = 32;                   // output tile
+constexpr int S2_ROWS = 2 * S2_TY + 3, S2_XS = 2 * S2_TX + 8, S2_DQ = S2_XS / 4;   // raw tile: rows 2 y0 - 2 .., columns 2 x0 - 4 ..
+constexpr int S2_GROUPS = S2_ROWS * S2_DQ, S2_PIECES = (S2_GROUPS + 63) / 64;       // 630 groups, 10 pieces per channel
+constexpr int S2_RCST = S2_ROWS * S2_XS + 1;            // channel stride = 1 (mod 4): the four channels of a k-step on disjoint banks
+constexpr int S2_STAGE = 4 * S2_RCST;                   // raw stage (floats)
+constexpr int S2_UST = 4 * WN_UFLOATS;                  // U of a step: [phase][xi][cout tile][lane]
+constexpr int S2_STEPS = 8;                             // steps per tile (32 input channels)
+constexpr size_t S2_LDS_BYTES = (size_t)(2 * S2_STAGE + 2 * S2_UST + 32) * sizeof(float);
+static_assert(S2_PIECES * 4 % WN_WAVES == 0, "a step's raw pieces divide evenly among the waves");
+static_assert(S2_LDS_BYTES <= 160 * 1024, "LDS plan");
+
+__global__ void wino_s2_pack_kernel(const float *__restrict__ w, float *__restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= S2_STEPS * S2_UST) return;
+  const int lane = idx & 63, t = (idx >> 6) & 1, xi = (idx >> 7) & 15, ph = (idx >> 11) & 3, cc = idx >> 13;
+  const int py = ph >> 1, px = ph & 1;
+  const int co = t * 16 + (lane & 15), ci = cc * 4 + (lane >> 4);
+  const float *g = w + ((size_t)co * 32 + ci) * 25;
+  const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+  const int i = xi >> 2, j = xi & 3;
+  float u = 0.0f;
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) {
+      const int ky = 2 * a + py, kx = 2 * b + px;
+      if (ky < 5 && kx < 5) u += G[i][a] * g[ky * 5 + kx] * G[j][b];
+    }
+  out[idx] = u;
+}
+
+struct WinoS2Args {
+  int n, H, W, Ho, Wo, ntx, tiles;
+  WinoDiv fd_ntx;
+};
+
+__global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_s2_kernel(WinoS2Args g, const float *__restrict__ in,
+                                                                     const float *__restrict__ upk,
+                                                                     const float *__restrict__ bias,
+                                                                     float *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *U = smem + 2 * S2_STAGE;
+  float *bias_lds = U + 2 * S2_UST;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const size_t plane = (size_t)g.H * g.W;
+  const int oplane = g.Ho * g.Wo;
+  const int total = g.n * g.tiles, G = gridDim.x;
+  const int slot = xcd_tile_index(blockIdx.x, G);
+  const int my_items = slot < total ? (total - slot + G - 1) / G : 0;
+  const int total_steps = my_items * S2_STEPS;
+  if (tid < 32) bias_lds[tid] = bias ? bias[tid] : 0.0f;   // published by the first barrier
+
+  // ---- fetch side: wave w takes pieces (w & 1) * 5 .. + 4 of channel w >> 1 of the step, and 4 KB of its U
+  constexpr int PER = S2_PIECES * 4 / WN_WAVES;   // 5
+  const int dch = wave >> 1, dp0 = (wave & 1) * PER;
+  int pf_item = 0, pf_cc = 0, pf_n = 0;
+  int pf_goff[PER];
+  auto pf_plan = [&]() {
+    const int flat = pf_item * G + slot;
+    const int n = flat / g.tiles, tile = flat - n * g.tiles;
+    const int tyi = wdiv(tile, g.fd_ntx), txi = tile - tyi * g.ntx;
+    const int gy0 = 2 * tyi * S2_TY - 2, gx0 = 2 * txi * S2_TX - 4;
+    pf_n = n;
+    int lo;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = (dp0 + i) * 64 + lo;
+      const int row = e / S2_DQ, q = e - row * S2_DQ;
+      const int gy = gy0 + row, gx = gx0 + 4 * q;
+      // rows outside the image fall outside the plane's descriptor too; columns would wrap into a neighbouring row
+      pf_goff[i] = (gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) ? (gy * g.W + gx) * 4 : -1;
+    }
+  };
+  auto pf_issue = [&](int step) {   // DMA of this workgroup's step `step` into stage step & 1
+    if (step >= total_steps) return;
+    const float *src = in + ((size_t)pf_n * 32 + pf_cc * 4 + dch) * plane;
+    float *dst = smem + (step & 1) * S2_STAGE + dch * S2_RCST;
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+      if ((dp0 + i) * 64 + lane < S2_GROUPS)   // lanes past the tile's last group stay out of the slot
+        wn_dma16_buf<true>(src, (unsigned)plane * 4u, (unsigned)pf_goff[i], dst + (dp0 + i) * 256);
+    const float *us = upk + (size_t)pf_cc * S2_UST + wave * 1024 + lane * 4;
+    float *ud = U + (step & 1) * S2_UST + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wn_dma16<true>(us + i * 256, ud + i * 256);
+    if (++pf_cc == S2_STEPS) {
+      pf_cc = 0;
+      ++pf_item;
+      if (pf_item < my_items) pf_plan();
+    }
+  };
+  if (my_items > 0) pf_plan();
+  pf_issue(0);
+
+  const int pcol = lane & 15, kc = lane >> 4;
+  // this lane's patch (row wave, column pcol) of channel kc: phase (0, 0) sample (0, 0) inside a raw stage
+  const int rbase = kc * S2_RCST + (4 * wave) * S2_XS + 4 * pcol + 2;
+
+  floatx4 acc[16][2];
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi) acc[xi][0] = acc[xi][1] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  int item = 0, cc = 0;
+  for (int step = 0; step < total_steps; ++step) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the step (and its last tile's stores)
+    wn_barrier<true>();                                  // ... everyone's; everyone is done with the other stage
+    pf_issue(step + 1);
+    const float *raw = smem + (step & 1) * S2_STAGE + rbase;
+    const float *us = U + (step & 1) * S2_UST + lane;
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+      // the phases (py, 0) and (py, 1) together: their 4 x 4 samples at stride 2 are neighbouring columns of the raw
+      // tile -- one ds_read2_b32 per pair, the input transform B^T d B on (px = 0, px = 1) register pairs (v_pk_add_f32).
+      // The row an odd phase only multiplies by zero taps is not read; its last column is (its coefficients are skipped).
+      typedef float s2_f2 __attribute__((ext_vector_type(2)));
+      s2_f2 d[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float *q = raw + (py + 2 * i) * S2_XS + 2 * j;
+          d[i][j] = (py && i == 3) ? s2_f2{0.f, 0.f} : s2_f2{q[0], q[1]};
+        }
+      s2_f2 t[4][4], v[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        t[0][j] = d[0][j] - d[2][j];
+        t[1][j] = d[1][j] + d[2][j];
+        t[2][j] = d[2][j] - d[1][j];
+        t[3][j] = d[1][j] - d[3][j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i * 4 + 0] = t[i][0] - t[i][2];
+        v[i * 4 + 1] = t[i][1] + t[i][2];
+        v[i * 4 + 2] = t[i][2] - t[i][1];
+        v[i * 4 + 3] = t[i][1] - t[i][3];
+      }
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi) {
+        if (py && (xi >> 2) == 3) continue;   // U_xi = 0 for the odd row phase
+        const float *u = us + ((py * 2) * 16 + xi) * 128;
+        acc[xi][0] = mfma16x16x4(v[xi].x, u[0], acc[xi][0]);
+        acc[xi][1] = mfma16x16x4(v[xi].x, u[64], acc[xi][1]);
+        if ((xi & 3) != 3) {                  // ... and for the odd column phase
+          acc[xi][0] = mfma16x16x4(v[xi].y, u[16 * 128], acc[xi][0]);
+          acc[xi][1] = mfma16x16x4(v[xi].y, u[16 * 128 + 64], acc[xi][1]);
+        }
+      }
+    }
+    if (++cc == S2_STEPS) {
+      cc = 0;
+      // ---- tile epilogue: Y = A^T m A per (patch, cout); lane: cout t * 16 + (lane & 15), patches 4 kc .. + 3 of
+      // patch row `wave` = output columns 8 kc .. + 7 of rows 2 wave, 2 wave + 1: two 16-byte stores per row
+      const int flat = item * G + slot;
+      const int n = flat / g.tiles, tile = flat - n * g.tiles;
+      const int tyi = wdiv(tile, g.fd_ntx), txi = tile - tyi * g.ntx;
+      const int y0 = tyi * S2_TY + 2 * wave, x0 = txi * S2_TX;
+      const __amdgpu_buffer_rsrc_t osrd = wn_rsrc(out + (size_t)n * 32 * oplane, (unsigned)(32 * oplane) * 4u);
+      int lo;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
+      const int ocl = lo & 15, oq = lo >> 4;
+      unsigned ovoff[2];
+#pragma unroll
+      for (int hx = 0; hx < 2; ++hx)   // Wo % 4 == 0: four columns or none
+        ovoff[hx] = x0 + 8 * oq + 4 * hx < g.Wo ? (unsigned)((ocl * oplane + 8 * oq + 4 * hx) * 4) : 0xFFFFFFFFu;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const float bv = bias_lds[tt * 16 + ocl];
+        float y[4][2][2];   // [patch r][row a][column b]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float tm[2][4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            tm[0][j] = acc[0 + j][tt][r] + acc[4 + j][tt][r] + acc[8 + j][tt][r];
+            tm[1][j] = acc[4 + j][tt][r] - acc[8 + j][tt][r] - acc[12 + j][tt][r];
+          }
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            y[r][a][0] = tm[a][0] + tm[a][1] + tm[a][2] + bv;
+            y[r][a][1] = tm[a][1] - tm[a][2] - tm[a][3] + bv;
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+          if (y0 + a < g.Ho) {   // uniform
+            const unsigned so = (unsigned)((tt * 16 * oplane + (y0 + a) * g.Wo + x0) * 4);
+            wn_store4<0>(osrd, ovoff[0], so, floatx4{y[0][a][0], y[0][a][1], y[1][a][0], y[1][a][1]});
+            wn_store4<0>(osrd, ovoff[1], so, floatx4{y[2][a][0], y[2][a][1], y[3][a][0], y[3][a][1]});
+          }
+      }
+#pragma unroll
+      for (int xi = 0; xi < 16; ++xi) acc[xi][0] = acc[xi][1] = floatx4{0.f, 0.f, 0.f, 0.f};
+      ++item;
+    }
+  }
+}
+
 bool wino_geom(const mvsn_conv_desc *d, WinoGeom *g) {
   if (!d || d->precision != MVSN_CONV_FP32_WINO) return false;
   if (d->n <= 0 || d->c_in <= 0 || d->c_out != 32 || d->depth < 1 || d->rows <= 0 || d->cols <= 0) return false;
+  g->s2 = false;
+  if (d->kd == 1 && d->kh == 5 && d->kw == 5 && d->stride == 2) {   // 5 x 5 stride 2 on the input's four phases (conv_wino_s2_kernel)
+    if (d->c_in != 32 || d->dilation != 1 || d->depth != 1 || d->cols % 8 != 0) return false;
+    if ((unsigned long long)d->rows * d->cols * 32ull * 4ull >= (1ull << 31)) return false;   // 32-bit descriptor offsets
+    g->s2 = true;
+    g->n = d->n, g->cin = 32, g->H = d->rows, g->W = d->cols, g->dil = 1, g->D = 1, g->vol = false;
+    g->nty = ((d->rows - 1) / 2 + 1 + S2_TY - 1) / S2_TY;
+    g->ntx = ((d->cols - 1) / 2 + 1 + S2_TX - 1) / S2_TX;
+    g->tiles = g->nty * g->ntx;
+    g->nchunks = S2_STEPS * 4;
+    g->packed_floats = (size_t)S2_STEPS * S2_UST;
+    return (long)g->n * g->tiles < (1L << 30);
+  }
   if ((d->kd != 1 && d->kd != 3) || d->kh != 3 || d->kw != 3 || d->stride != 1) return false;
   if (d->kd == 1 && d->depth != 1) return false;
   if (d->dilation != 1 && d->dilation != 2 && d->dilation != 4 && d->dilation != 8) return false;
@@ -1099,6 +1325,10 @@ int wino_pack_2d(const float *weight, int cin, float *packed, hipStream_t stream
 int wino_pack(const mvsn_conv_desc *d, const float *weight, float *packed, hipStream_t stream) {
   WinoGeom g;
   if (!wino_geom(d, &g)) return MVSN_E_BADARG;
+  if (g.s2) {
+    hipLaunchKernelGGL(wino_s2_pack_kernel, dim3((S2_STEPS * S2_UST + 255) / 256), dim3(256), 0, stream, weight, packed);
+    return check_launch("mvsn_conv_pack_weights(winograd, 5x5 stride 2)");
+  }
   const int total = g.nchunks * WN_UFLOATS;
   hipLaunchKernelGGL(wino_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, weight, g.cin, 32, g.nchunks,
                      g.vol ? 3 : 1, packed);
@@ -1107,6 +1337,7 @@ int wino_pack(const mvsn_conv_desc *d, const float *weight, float *packed, hipSt
 
 // RIDE units per wave and step of the instantiation a layer runs on (0: that kernel carries nothing)
 static int wino_ride_units(const WinoGeom &g) {
+  if (g.s2) return 0;
   if (g.vol) return 1;         // 12 steps per (plane, tile): 96 units, of which a job of the layer's own size needs 64
   if (g.nchunks != 8) return 0;
   // 4 steps of two k-steps / 8 steps of one: 64 units = 64 KB per tile either way.  Dilation 4 carries on the
@@ -1130,6 +1361,23 @@ bool wino_can_carry(const WinoGeom &g, const mvsn_apply_job *job) {
 int wino_launch(const WinoGeom &g, const float *in, const float *upk, const float *bias, const float *in_stats,
                 const float *in_gamma, const float *in_beta, float *out, float *out_partials, hipStream_t stream,
                 const WinoBlocks *blocks, const mvsn_apply_job *job) {
+  if (g.s2) {
+    if (blocks || job || in_stats || out_partials) {
+      set_error("mvsn_conv_forward(winograd, 5x5 stride 2): no input transform, statistics, channel blocks or carried job");
+      return MVSN_E_BADARG;
+    }
+    WinoS2Args a;
+    a.n = g.n, a.H = g.H, a.W = g.W, a.Ho = (g.H - 1) / 2 + 1, a.Wo = (g.W - 1) / 2 + 1, a.ntx = g.ntx, a.tiles = g.tiles;
+    a.fd_ntx = wino_div((unsigned)g.ntx);
+    static LdsOptIn opt;
+    if (int rc = ensure_lds(opt, (const void *)conv_wino_s2_kernel, S2_LDS_BYTES, "mvsn_conv_forward(winograd, 5x5 stride 2)"))
+      return rc;
+    const long total = (long)g.n * g.tiles;
+    const int cus = device_cus();
+    hipLaunchKernelGGL(conv_wino_s2_kernel, dim3((unsigned)(total < cus ? total : cus)), dim3(WN_THREADS), S2_LDS_BYTES,
+                       stream, a, in, upk, bias, out);
+    return check_launch("mvsn_conv_forward(winograd, 5x5 stride 2)");
+  }
   RideArgs rd = {};
   if (job) {
     if (blocks || !wino_can_carry(g, job)) {

@@ -105,6 +105,9 @@ class EngineOptions:
         self.winograd_with_input_transform = True
         # ... and the 3x3x3 layers of the cost-volume regulariser as 2-D Winograd products summed over the depth tap
         self.winograd_volume = True
+        # ... and the extractor's 5x5 stride-2 32 -> 32 layers as F(2x2,3x3) on the input's four stride-2 phases
+        # (392 multiplies per 2x2 outputs and channel pair instead of 800)
+        self.winograd_stride2 = True
         self.volume_materialise = True     # LReLU(GN(.)) of the regulariser layers as one in-place pass (see cost_volume_filter)
         # Skip the stand-alone normalise/activate pass at both ends of a refiner tower (see
         # residual_tower_unfused); False keeps one pass per block (tests compare the two).
@@ -148,7 +151,7 @@ class EngineOptions:
         self.banded_repair = True
 
     NAMES = ("banded_repair", "towers", "plan_max_chains", "plan_graph", "plan_max_bytes", "carry_passes", "carry_min_bytes", "carry_volume_passes", "carry_alternate", "chain_form", "fold_residual_blocks", "conv_precision", "winograd", "winograd_with_input_transform",
-             "winograd_volume", "volume_materialise", "trim_tower_ends", "cat_free_heads", "lazy_stats_max_samples",
+             "winograd_volume", "winograd_stride2", "volume_materialise", "trim_tower_ends", "cat_free_heads", "lazy_stats_max_samples",
              "lazy_stats_max_records")
 
 
@@ -527,7 +530,8 @@ class PlaneSweepEngine:
                 self.bf16_layers += 1
         if d.precision == _native.CONV_FP32 and self.winograd and c.packed_wino is not None and in_residual is None and not write_staged and \
                 (in_stats is None or self.winograd_with_input_transform) and \
-                (c.dims == 2 or self.winograd_volume):
+                (c.dims == 2 or self.winograd_volume) and \
+                (c.stride == 1 or (self.winograd_stride2 and in_stats is None and not want_stats and carry is None)):
             dwn = c.desc(n, depth, rows, cols, _native.CONV_FP32_WINO)
             if lib.mvsn_conv_winograd_supported(ctypes.byref(dwn)):
                 d, packed = dwn, c.packed_wino

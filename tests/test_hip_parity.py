@@ -415,6 +415,35 @@ def test_conv_to1_block_folds_last_residual_block(rows, cols, n, with_res, with_
     close(got, ref, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("n,rows,cols,with_bias", [(3, 64, 128, False), (2, 37, 72, True), (2, 100, 200, False),
+                                                   (1, 256, 512, False), (5, 8, 16, True)])
+def test_conv_5x5_stride2_winograd_on_phases(n, rows, cols, with_bias):
+    """The extractor's 5x5 stride-2 32 -> 32 layers as Winograd F(2x2,3x3) on the input's four stride-2 phases
+    (conv_wino_s2_kernel) against ATen and against the direct kernel (ragged rows / columns, partial tiles, bias)."""
+    from multi_view_stereonet_amd.multi_view_stereonet import _Conv
+    eng = net_for("gta_sfm_150epochs").engine()
+    g = torch.Generator().manual_seed(rows * 5 + cols)
+    x = torch.randn(n, 32, rows, cols, generator=g)
+    w = torch.randn(32, 32, 5, 5, generator=g) * 0.05
+    b = torch.randn(32, generator=g) * 0.1 if with_bias else None
+    c = _Conv(eng.lib, w.to(DEV), b.to(DEV) if with_bias else None, stride=2)
+    assert c.packed_wino is not None
+    ref = F.conv2d(x.double(), w.double(), b.double() if with_bias else None, stride=2, padding=2).float()
+    eng.timeline = []
+    try:
+        eng.winograd_stride2 = True
+        got, _ = eng.conv(c, x.to(DEV))
+        assert any("k5s2 32->32 wino" in t[0] for t in eng.timeline)
+        eng.winograd_stride2 = False
+        direct, _ = eng.conv(c, x.to(DEV))
+    finally:
+        eng.winograd_stride2 = True
+        eng.timeline = None
+    close(direct, ref, rtol=1e-4, atol=1e-4)
+    close(got, ref, rtol=1e-4, atol=1e-4)
+    assert (got.cpu() - ref).abs().max() <= 4 * (direct.cpu() - ref).abs().max() + 1e-5
+
+
 def test_refiner_tower_end_trimming_is_equivalent():
     """The tower with the head activation and the last block never materialised (gn_lrelu_add2 +
     conv_to1_block) against the one-pass-per-block form, on every refiner of the pretrained weights."""
