@@ -1102,6 +1102,12 @@ __global__ void wino_s2_pack_kernel(const float *__restrict__ w, float *__restri
   out[idx] = u;
 }
 
+#ifndef MVSN_S2_PIN
+#define MVSN_S2_PIN 1
+#endif
+#ifndef MVSN_S2_CNTWAIT
+#define MVSN_S2_CNTWAIT 1
+#endif
 struct WinoS2Args {
   int n, H, W, Ho, Wo, ntx, tiles;
   WinoDiv fd_ntx;
@@ -1177,7 +1183,10 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_s2_kernel(WinoS2Args 
 
   int item = 0, cc = 0;
   for (int step = 0; step < total_steps; ++step) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the step (and its last tile's stores)
+    // this wave's pieces of the step have landed.  (Behind them the wave has issued at most the eight stores of the tile
+    // it just finished: vector memory instructions retire in issue order, see wait_landed of conv_wino_kernel.)
+    if (MVSN_S2_CNTWAIT && cc == 0 && step > 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wn_barrier<true>();                                  // ... everyone's; everyone is done with the other stage
     pf_issue(step + 1);
     const float *raw = smem + (step & 1) * S2_STAGE + rbase;
@@ -1210,6 +1219,13 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_s2_kernel(WinoS2Args 
         v[i * 4 + 1] = t[i][1] + t[i][2];
         v[i * 4 + 2] = t[i][2] - t[i][1];
         v[i * 4 + 3] = t[i][1] - t[i][3];
+      }
+      // (pinned as register pairs: with the odd column phase's unused halves visible the compiler narrows half of the
+      // packed adds to scalar ones and shuffles the pairs with moves -- 200 VALU instructions per step instead of ~60)
+      if (MVSN_S2_PIN) {
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi)
+          if (!(py && (xi >> 2) == 3)) asm volatile("" : "+v"(v[xi]));
       }
 #pragma unroll
       for (int xi = 0; xi < 16; ++xi) {
@@ -1258,12 +1274,12 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_s2_kernel(WinoS2Args 
           }
         }
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-          if (y0 + a < g.Ho) {   // uniform
-            const unsigned so = (unsigned)((tt * 16 * oplane + (y0 + a) * g.Wo + x0) * 4);
-            wn_store4<0>(osrd, ovoff[0], so, floatx4{y[0][a][0], y[0][a][1], y[1][a][0], y[1][a][1]});
-            wn_store4<0>(osrd, ovoff[1], so, floatx4{y[2][a][0], y[2][a][1], y[3][a][0], y[3][a][1]});
-          }
+        for (int a = 0; a < 2; ++a) {   // (a row past the image: the same stores with out-of-range offsets -- always eight per tile)
+          const bool rok = y0 + a < g.Ho;   // uniform
+          const unsigned so = rok ? (unsigned)((tt * 16 * oplane + (y0 + a) * g.Wo + x0) * 4) : 0u;
+          wn_store4<0>(osrd, rok ? ovoff[0] : 0xFFFFFFFFu, so, floatx4{y[0][a][0], y[0][a][1], y[1][a][0], y[1][a][1]});
+          wn_store4<0>(osrd, rok ? ovoff[1] : 0xFFFFFFFFu, so, floatx4{y[2][a][0], y[2][a][1], y[3][a][0], y[3][a][1]});
+        }
       }
 #pragma unroll
       for (int xi = 0; xi < 16; ++xi) acc[xi][0] = acc[xi][1] = floatx4{0.f, 0.f, 0.f, 0.f};
