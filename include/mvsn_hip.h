@@ -201,7 +201,10 @@ typedef struct {
  *                     relative).  2-D 3x3 stride-1 layers with 32 output channels, dilation 1/2/4/8, and the
  *                     3x3x3 32 -> 32 layers (volume form: 2-D Winograd products summed over the depth tap, 12
  *                     multiplies per output instead of 27), cols % 4 == 0 (mvsn_conv_winograd_supported);
- *                     weights are packed per form.
+ *                     weights are packed per form.  Also the 5x5 stride-2 32 -> 32 layers of the feature extractor
+ *                     (multi_view_stereonet.py:78-129), cols % 8 == 0: F(2x2,3x3) on the input's four stride-2 phases,
+ *                     392 products per 2x2 outputs and (cin, cout) pair instead of 800; no fused input transform, no
+ *                     GroupNorm partials on that form (MVSN_E_BADARG).
  *   MVSN_CONV_BF16    plain bf16 operands (the hi halves only), fp32 accumulation, on the same kernels and packed
  *                     weights as MVSN_CONV_BF16X3: BASELINE config 5's speed tier.  ~2^-9 relative per operand:
  *                     the final depth lands OUTSIDE the 1e-3 parity contract (measured ~2e-3 mean-rel). */
