@@ -416,7 +416,8 @@ def test_conv_to1_block_folds_last_residual_block(rows, cols, n, with_res, with_
 
 
 @pytest.mark.parametrize("n,rows,cols,with_bias", [(3, 64, 128, False), (2, 37, 72, True), (2, 100, 200, False),
-                                                   (1, 256, 512, False), (5, 8, 16, True)])
+                                                   (1, 256, 512, False), (5, 8, 16, True),
+                                                   (150, 64, 128, False), (70, 37, 72, True)])   # > 256 tiles: several per workgroup
 def test_conv_5x5_stride2_winograd_on_phases(n, rows, cols, with_bias):
     """The extractor's 5x5 stride-2 32 -> 32 layers as Winograd F(2x2,3x3) on the input's four stride-2 phases
     (conv_wino_s2_kernel) against ATen and against the direct kernel (ragged rows / columns, partial tiles, bias)."""
