@@ -415,6 +415,23 @@ def test_conv_to1_block_folds_last_residual_block(rows, cols, n, with_res, with_
     close(got, ref, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("n,rows,cols,with_bias", [(2, 37, 72, True), (1, 1, 8, False), (10, 256, 512, False), (70, 50, 136, True)])
+def test_conv_5x5_stride2_head_persistent_kernel(n, rows, cols, with_bias):
+    """The extractor's 3 -> 32 head (conv5x5s2_head_kernel: persistent workgroups, two-slot tile ring by LDS-DMA,
+    descriptor stores) against ATen -- partial tiles, one row, and more tiles than resident workgroups (1280 / 840:
+    the ring's second slot and the walk over (image, tile) ids)."""
+    from multi_view_stereonet_amd.multi_view_stereonet import _Conv
+    eng = net_for("gta_sfm_150epochs").engine()
+    g = torch.Generator().manual_seed(rows * 11 + cols)
+    x = torch.randn(n, 3, rows, cols, generator=g)
+    w = torch.randn(32, 3, 5, 5, generator=g) * 0.1
+    b = torch.randn(32, generator=g) * 0.1 if with_bias else None
+    c = _Conv(eng.lib, w.to(DEV), b.to(DEV) if with_bias else None, stride=2)
+    got, _ = eng.conv(c, x.to(DEV))
+    ref = F.conv2d(x, w, b, stride=2, padding=2)
+    close(got, ref, rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("n,rows,cols,with_bias", [(3, 64, 128, False), (2, 37, 72, True), (2, 100, 200, False),
                                                    (1, 256, 512, False), (5, 8, 16, True),
                                                    (150, 64, 128, False), (70, 37, 72, True)])   # > 256 tiles: several per workgroup
