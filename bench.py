@@ -306,6 +306,20 @@ def cpu_baseline(cfg, budget_s=15.0):
     return res, out
 
 
+def oracle_check(cfg, index, got):
+    """Image `index` of rank 0's step (seed = the fixture's + index) through the CPU oracle, against the GPU's depth map of
+    that image: same fields as l1_vs_ref (the contract: max_rel_per_pixel < 1e-3)."""
+    from oracle import mvsn_oracle as oracle
+    w = load_weights(cfg["weights"])
+    _, inp, _ = config_inputs(cfg, 1, index, torch.device("cpu"))      # (rank * batch + i = index)
+    ref = oracle.forward(w, inp["left_image_pyr"], inp["K_pyr"], inp["T_right_in_left"], inp["right_image_pyr"],
+                         cfg["D"])["left_idepthmap_pyr"][0]
+    res = {k: v for k, v in l1_against(ref, got).items() if k != "rel_definitions"}
+    res["image"] = index
+    res["reference"] = "oracle/mvsn_oracle.py on the same seeded input (CPU)"
+    return res
+
+
 def self_launch(n):
     """Re-execute this command line under torch.distributed.run with n local ranks (one per GPU)."""
     import socket
@@ -625,7 +639,11 @@ def main():
         t = (pmc or {}).get(name)
         if t:
             traffic = (t["fetch_bytes_per_chain"] + t["write_bytes_per_chain"]) * B * Sn
-            traffic_source = (f"profiles/{PMC_TRAFFIC_FILE}: FETCH_SIZE (x2: gfx950 half-count of 16-byte streaming reads) + "
+            # (older files carry no flag: the raw / reported pair says whether the kernel's fetch figure was doubled)
+            doubled = t.get("fetch_doubled", t["fetch_bytes_per_chain"] != t.get("fetch_bytes_per_chain_raw"))
+            how = ("FETCH_SIZE x2 (gfx950 half-count of 16-byte streaming reads: this kernel's tiles arrive by 16-byte LDS-DMA)"
+                   if doubled else "FETCH_SIZE as read (this kernel's 4- / 8-byte accesses are not half-counted)")
+            traffic_source = (f"profiles/{PMC_TRAFFIC_FILE}: {how} + "
                               f"WRITE_SIZE of separate rocprofv3 --pmc passes of the bench command with this library "
                               f"(digest {pmc['_library_digest'][:12]}, {pmc.get('_chains_per_launch', '?')} chains per launch), "
                               "per chain x this batch -- a committed pass, NOT a counter read during this run")
@@ -743,6 +761,11 @@ def main():
             line["cpu_baseline"] = cb
             o0 = ref_out["left_idepthmap_pyr"][0]
             line["l1_vs_oracle"] = float((got0 - o0).abs().mean())
+            # image 0 sits in slice A of the two-slice towers and in the first round of every persistent kernel: the
+            # first image of slice B and the LAST image of the step (last round, slice B) against the oracle as well
+            for key, idx in (("l1_vs_oracle_slice_b", (B + 1) // 2), ("l1_vs_oracle_last", B - 1)):
+                if idx > 0:
+                    line[key] = oracle_check(cfg, idx, idepth[idx:idx + 1].cpu())
         print(json.dumps(line))
     if world > 1:
         torch.distributed.barrier()

@@ -788,14 +788,19 @@ extern "C" int mvsn_incremental_cost_volume_guarded(const float *src_image_lvl4,
                                                     mvsn_stream_t stream) {
   using namespace mvsn;
   if (form == MVSN_CHAIN_AUTO && n_chains > 0 && rows > 0 && cols > 0) form = chain_auto_form(n_chains, rows, cols);
+  // everything the repair launch needs is validated BEFORE the banded launch is enqueued: an error return must not
+  // leave an unrepaired banded chain (NaN on a time-out) behind on the stream
+  size_t need = 0;
+  if (form == MVSN_CHAIN_BANDED && n_chains > 0 && rows > 0 && cols > 0) {
+    need = mvsn_incremental_cost_volume_repair_workspace_bytes(n_chains, rows, cols);
+    MVSN_REQUIRE(need == 0 || (repair_workspace && repair_workspace_bytes >= need), MVSN_E_WORKSPACE,
+                 "mvsn_incremental_cost_volume_guarded: repair workspace of %zu bytes required", need);
+  }
   if (int rc = chain_run(src_image_lvl4, H_lvl4, H_inc, plane0_features, left_features, refiner_packed, n_chains, batch,
                          num_idepth_samples, rows, cols, cost_volume, mask_volume, feature_volume, workspace,
                          workspace_bytes, form, nullptr, nullptr, stream))
     return rc;
   if (form != MVSN_CHAIN_BANDED) return 0;   // the other forms have no inter-workgroup hand-offs to time out
-  const size_t need = mvsn_incremental_cost_volume_repair_workspace_bytes(n_chains, rows, cols);
-  MVSN_REQUIRE(need == 0 || (repair_workspace && repair_workspace_bytes >= need), MVSN_E_WORKSPACE,
-               "mvsn_incremental_cost_volume_guarded: repair workspace of %zu bytes required", need);
   const unsigned *gate = reinterpret_cast<const unsigned *>(static_cast<const char *>(workspace) +
                                                             chain_band_status_offset(n_chains, rows, cols));
   return chain_run(src_image_lvl4, H_lvl4, H_inc, plane0_features, left_features, refiner_packed, n_chains, batch,

@@ -1135,13 +1135,16 @@ extern "C" int mvsn_conv_forward(const mvsn_conv_desc *desc, const float *in, co
   // ---- the extractor's 3 -> 32 5x5 stride-2 head: K = 75 packing (no fused transform / statistics on this layer) ----
   if (desc->precision == MVSN_CONV_FP32 && desc->c_in == 3 && desc->c_out == 32 && desc->kd == 1 && desc->kh == 5 &&
       desc->kw == 5 && desc->stride == 2 && desc->dilation == 1 && desc->depth == 1 && (desc->cols & 7) == 0 &&
-      (size_t)desc->rows * desc->cols * 4 < ((size_t)1 << 31) &&   // descriptor ranges / 32-bit offsets of the kernel
+      // descriptor ranges / 32-bit offsets of the kernel: the input plane AND a sample's full 32-channel output extent
+      // ((int)(32 * oplane * 4) is the output descriptor's range, (cl * oplane + ox) * 4 a store offset)
+      (size_t)desc->rows * desc->cols * 4 < ((size_t)1 << 31) &&
+      (size_t)32 * ((desc->rows - 1) / 2 + 1) * ((desc->cols - 1) / 2 + 1) * 4 < ((size_t)1 << 31) &&
       !in_stats && !in_residual && !out_staged && !out_partials && ((size_t)in & 15) == 0 && ((size_t)out & 15) == 0) {
     MVSN_REQUIRE(desc->n <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_forward: batch too large for one launch");
     const int Ho = (desc->rows - 1) / 2 + 1, Wo = (desc->cols - 1) / 2 + 1;
     const int nty = (Ho + HD_TY - 1) / HD_TY, ntx = (Wo + HD_TX - 1) / HD_TX, tiles = nty * ntx;
-    // (__launch_bounds__(256, 4): 128 VGPRs -- the k-step offsets packed two per register -- so that FOUR of these
-    // workgroups share a CU and cover each other's barrier and store tails)
+    // (persistent workgroups, MVSN_HEAD_WGS_PER_CU per CU -- three without a spill -- that cover each other's barrier and
+    // store tails; each walks its tiles through a two-slot DMA ring)
     MVSN_REQUIRE((long long)tiles * desc->n < (1ll << 31) - 65536, MVSN_E_TOOLARGE, "mvsn_conv_forward: batch too large for one launch");
     const int total = tiles * desc->n;
     const int gx = std::min(total, MVSN_HEAD_WGS_PER_CU * device_cus());

@@ -195,6 +195,19 @@ class _SharedState:
         self.seen = 0
         self.banded_latched = False
         self.warned = False
+        self.clean = 0                 # forwards since the latch was set (it expires: a transiently shared device)
+
+    # A repaired forward keeps AUTO off the banded form for this many forwards, then the form is tried again (a device that
+    # was shared for a moment should not cost the module its small-batch chain for good; a device that IS shared repairs
+    # one forward in LATCH_FORWARDS and latches again).  net.reset_device_status() re-arms at once.
+    LATCH_FORWARDS = 256
+
+    def tick(self):
+        """Once per forward (after poll): lets the latch expire."""
+        if self.banded_latched:
+            self.clean += 1
+            if self.clean >= self.LATCH_FORWARDS:
+                self.banded_latched, self.warned, self.clean = False, False, 0
 
     def status_ptr(self) -> int:
         if self.words is None:
@@ -209,7 +222,7 @@ class _SharedState:
         count = int(self.words_np[1])
         fresh, self.seen = count - self.seen, count
         if fresh:
-            self.banded_latched = True
+            self.banded_latched, self.clean = True, 0
             if not self.warned:
                 self.warned = True
                 warnings.warn(
@@ -1238,6 +1251,8 @@ class MultiViewStereoNet(nn.Module):
         if synchronize:                # (callers that have just synchronised pass False: two host reads remain)
             torch.cuda.synchronize()
         fresh = eng.net_state.poll()
+        # (without the repair launch the status word lives in device memory: reading it synchronises -- a caller that
+        # passes synchronize=False has done so itself, see multi_view_forward / metrics.evaluate)
         if not self.options.banded_repair:
             status = eng.chain_status()
             if status:
@@ -1251,7 +1266,7 @@ class MultiViewStereoNet(nn.Module):
         """Re-enable the banded chain form after check_device_status / a forward latched it off."""
         st = self.__dict__.get("_shared_state")
         if st is not None:
-            st.banded_latched, st.warned = False, False
+            st.banded_latched, st.warned, st.clean = False, False, 0
 
     def engine(self) -> PlaneSweepEngine:
         # The packed copies go stale when a parameter is rebound (.to(), load_state_dict: both invalidate above) or
@@ -1300,6 +1315,7 @@ class MultiViewStereoNet(nn.Module):
             # unit; two threads sharing this module interleave whole forwards, never launches)
             eng = self.engine()
             eng.net_state.poll()       # a repaired banded chain since the last forward latches AUTO off that form
+            eng.net_state.tick()       # ... for _SharedState.LATCH_FORWARDS forwards
             args = (int(num_idepth_samples), bool(do_cost_volume_filter), list(do_refiners))
             B = left_image_pyr[0].shape[0]
             lanes = min(self.stream_lanes, B) if capture is None else 1

@@ -342,7 +342,9 @@ def multi_view_forward(stereo_network, inputs: Dict[str, object], params: Dict[s
                          list(params.get("refiners", [True] * 5)))
     ms = _tock(on_gpu, a, b)
     if on_gpu and hasattr(stereo_network, "check_device_status"):
-        stereo_network.check_device_status(synchronize=False)      # (the timer has just synchronised)
+        # (this path only: _tock has just synchronised.  The sync_timer=False path above returns without a status check --
+        # its caller synchronises once at the end and checks then, metrics.evaluate)
+        stereo_network.check_device_status(synchronize=False)
     return {"left_idepthmap_pyr": out["left_idepthmap_pyr"],
             "left_idepthmap_raw_pyr": out["left_idepthmap_raw_pyr"],
             "left_idepthmap_mask_pyr": out["left_idepthmap_mask_pyr"],

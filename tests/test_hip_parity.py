@@ -1349,6 +1349,72 @@ def test_forward_headline_golden(name, wname, smooth):
     _check_mask4(name, out, fix)
 
 
+def test_forward_headline_launch_geometry_vs_golden_and_oracle():
+    """The HEADLINE launch geometry inside pytest (the golden forwards all ran at B = 1): 128 reference
+    images x 2 sources = 256 chains -- one plane-resident chain per CU (`chain_wino_kernel<16,32>`), the refiner towers
+    on two batch slices with carried passes, the regulariser on two slices.  Image 0 is g2's input and is held against the
+    reference's own depth map; the FIRST image of slice B (index 64) and the LAST image (127: slice B, last round of
+    every persistent kernel) are held against the oracle on the same seeded inputs -- contract per pixel < 1e-3, masks
+    of every level bit for bit (multi_view_stereonet.py:538-695)."""
+    fix = load_golden("g2_gta_512x256_d64_s2.npz")
+    rows, cols, D, S, _, seed0 = (int(x) for x in fix["meta"])
+    B = 128
+    net = net_for("gta_sfm_150epochs")
+    parts = [synthetic.make_batch(rows, cols, S, batch=1, seed=seed0 + i) for i in range(B)]
+    merged = {"left_image": torch.cat([p["left_image"] for p in parts], 0),
+              "right_image": [torch.cat([p["right_image"][s] for p in parts], 0) for s in range(S)],
+              "K": torch.cat([p["K"] for p in parts], 0),
+              "T_right_in_left": [torch.cat([p["T_right_in_left"][s] for p in parts], 0) for s in range(S)]}
+    inp = snu.multi_view_unpack_batch(merged, torch.device(DEV), 5)
+    out = net(inp["left_image_pyr"], inp["K_pyr"], inp["T_right_in_left"], inp["right_image_pyr"], D, True, [True] * 5)
+    eng = net.engine()
+    assert eng.last_chain_form == _native.CHAIN_WINOGRAD and eng.last_chain_shape[0] == B * S
+    assert bool(torch.isfinite(out["left_idepthmap_pyr"][0]).all())
+    got0 = out["left_idepthmap_pyr"][0][:1].cpu()
+    assert_contract(got0, fix["idepth_0"], "B=128 image 0 vs g2")
+    w = load_weights("gta_sfm_150epochs")
+    for idx in (B // 2, B - 1):
+        cpu_in = snu.multi_view_unpack_batch(parts[idx], torch.device("cpu"), 5)
+        ref = oracle.forward(w, cpu_in["left_image_pyr"], cpu_in["K_pyr"], cpu_in["T_right_in_left"],
+                             cpu_in["right_image_pyr"], D)
+        for lvl in range(5):
+            got = out["left_idepthmap_pyr"][lvl][idx:idx + 1].cpu()
+            mean_rel, max_rel = rel_err(got, ref["left_idepthmap_pyr"][lvl])
+            assert mean_rel < 2e-4 and max_rel < 1e-3, (idx, lvl, mean_rel, max_rel)
+            m = out["left_idepthmap_mask_pyr"][lvl][idx:idx + 1].cpu()
+            # (masks derive from the level-4 predicate; the oracle evaluates the same fp32 expression order)
+            assert int((m != ref["left_idepthmap_mask_pyr"][lvl]).sum()) <= 2 * 4 ** (4 - lvl), (idx, lvl)
+        assert_contract(out["left_idepthmap_pyr"][0][idx:idx + 1].cpu(), ref["left_idepthmap_pyr"][0],
+                        f"B=128 image {idx} vs oracle")
+
+
+def test_bench_real_multi_rank_line_on_one_gpu():
+    """The REAL N > 1 line of bench.py (not the launcher self-test): two ranks under torch.distributed.run that both use
+    cuda:0 and exchange over gloo (`--single-device-selftest`) -- forward, timed region with barriers and max over
+    ranks, all-gather of the per-image metric rows, per-rank roofline fractions, parity of image 0 (test.py:146-164,
+    188-280).  RCCL itself needs N GPUs; everything else of the N-rank path runs here."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-device-selftest",
+                        "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-tiers"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["backend"] == "gloo"
+    assert line["config"]["global_batch"] == 16 and len(line["per_rank_ms_per_step"]) == 2
+    assert len(line["roofline"]["frac_per_rank"]) == 2 and all(0.0 < f < 1.0 for f in line["roofline"]["frac_per_rank"])
+    l1 = line["l1_vs_ref"]
+    assert np.isfinite(l1["l1"]) and l1["max_rel_per_pixel"] < 1e-3, l1
+    assert np.isfinite(line["mean_idepth"]) and line["value"] > 0 and "selftest" in line
+    print("bench --gpus 2 --single-device-selftest:", lines[0][:400])
+
+
 def test_forward_headline_golden_direct_chain_form():
     """The headline fixture once more with the chain's convolutions in their DIRECT form (the path of the coarse grids
     the Winograd plan does not cover): both forms sit inside the contract, and agree with each other far below it."""

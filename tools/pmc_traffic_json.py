@@ -63,7 +63,7 @@ def main():
             continue
         raw = fb / nf / chains
         out[name] = {"_note": note, "fetch_bytes_per_chain_raw": round(raw),
-                     "fetch_bytes_per_chain": round(raw * (2 if doubled else 1)),
+                     "fetch_bytes_per_chain": round(raw * (2 if doubled else 1)), "fetch_doubled": bool(doubled),
                      "write_bytes_per_chain": round(wb / nw / chains), "algorithmic_bytes_per_chain": algo,
                      "dispatches": int(nf)}
     print(json.dumps(out, indent=1))
