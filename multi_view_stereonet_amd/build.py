@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmvsn_hip.so")
-SOURCES = ["mvsn_error.hip", "mvsn_setup.hip", "mvsn_warp.hip", "mvsn_chain.hip", "mvsn_chain_wino.hip", "mvsn_chain_band.hip", "mvsn_chain_steps.hip", "mvsn_conv.hip", "mvsn_conv_bf16x3.hip", "mvsn_conv_wino.hip", "mvsn_misc.hip", "mvsn_consistency.hip", "mvsn_prepare.hip", "mvsn_metrics.hip", "mvsn_tower.hip"]
+SOURCES = ["mvsn_error.hip", "mvsn_setup.hip", "mvsn_warp.hip", "mvsn_chain.hip", "mvsn_chain_wino.hip", "mvsn_chain_band.hip", "mvsn_chain_slab.hip", "mvsn_chain_steps.hip", "mvsn_conv.hip", "mvsn_conv_bf16x3.hip", "mvsn_conv_wino.hip", "mvsn_misc.hip", "mvsn_consistency.hip", "mvsn_prepare.hip", "mvsn_metrics.hip", "mvsn_tower.hip"]
 
 
 def hipcc() -> str:

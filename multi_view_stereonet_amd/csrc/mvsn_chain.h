@@ -95,4 +95,14 @@ void chain_band_debug_flags(int flags);   // test hook, see mvsn_debug_set_band_
 int chain_band_launch(const ChainArgs &a, int n_chains, void *workspace, size_t workspace_bytes, int flags,
                       hipStream_t stream);
 
+// Slab plans of the banded form (mvsn_chain_slab.hip): a few fat bands per chain, 512-thread workgroups -- what the
+// banded dispatcher launches once more chains are in flight than two passes of the thin-band plan hold
+struct SlabPlan {
+  int G, threads;
+  size_t chain_u64, lds_bytes;
+  void (*kernel)(ChainArgs, int, const void *, const void *, const void *, const void *, const void *, const void *,
+                 const void *, const void *, const void *, const void *);
+};
+bool chain_slab_plan(int rows, int cols, SlabPlan *p);
+
 }  // namespace mvsn

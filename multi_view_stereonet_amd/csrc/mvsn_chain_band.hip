@@ -919,14 +919,14 @@ __global__ __launch_bounds__(256) void band_zero_kernel(u64 *__restrict__ p, siz
 
 // ---- host side -------------------------------------------------------------------------------------------------
 struct BandPlan {
-  int G;
+  int G, threads, slot;   // workgroups per chain, threads per workgroup, LDS opt-in slot of the kernel
   size_t chain_u64, lds_bytes;
   void (*kernel)(ChainArgs, int, MVSN_VIS10);
 };
 
 template <class GEO>
-static BandPlan band_plan_of() {
-  return BandPlan{GEO::G, GEO::CHAIN_U64, (size_t)GEO::LDS_FLOATS * sizeof(float), chain_band_kernel<GEO>};
+static BandPlan band_plan_of(int slot) {
+  return BandPlan{GEO::G, CB_THREADS, slot, GEO::CHAIN_U64, (size_t)GEO::LDS_FLOATS * sizeof(float), chain_band_kernel<GEO>};
 }
 
 static int g_band_debug_flags = 0;
@@ -935,13 +935,26 @@ void chain_band_debug_flags(int flags) { g_band_debug_flags = flags; }
 // 16x32 has two plans: 8 bands of 2 rows (half split) while that many workgroups per chain fit the chip in one pass,
 // 4 bands of 4 rows beyond (bit-identical results: same arithmetic per output, same GroupNorm records in the same
 // order).  Debug flag bit 2 pins the 4-band plan (A/B, tests).
+// 30x40 / 32x64: the thin-band plan (15 / 16 workgroups per chain) while the chains fit two of its passes (AUTO's
+// small-batch form); beyond that the SLAB plan (mvsn_chain_slab.hip: 3 / 4 fat bands per chain, 85 / 64 chains per pass).
+// Debug flag bit 4 (16) pins the slab plan (also on 16x32, where it exists for the tests only), bit 5 (32) the thin one.
 static bool band_plan(int rows, int cols, int n_chains, BandPlan *p) {
-  if (rows == 16 && cols == 32) {
-    if (!(g_band_debug_flags & 4) && n_chains <= device_cus() / Band16x32H::G) *p = band_plan_of<Band16x32H>();
-    else *p = band_plan_of<Band16x32>();
-  } else if (rows == 30 && cols == 40) *p = band_plan_of<Band30x40>();
-  else if (rows == 32 && cols == 64) *p = band_plan_of<Band32x64>();
-  else return false;
+  const bool known = (rows == 16 && cols == 32) || (rows == 30 && cols == 40) || (rows == 32 && cols == 64);
+  if (!known) return false;
+  const int thin_g = rows == 16 ? Band16x32::G : (rows == 30 ? Band30x40::G : Band32x64::G);
+  const bool many = rows != 16 && n_chains > 2 * (device_cus() / thin_g);
+  if (((g_band_debug_flags & 16) || many) && !(g_band_debug_flags & 32)) {
+    SlabPlan sp;
+    if (chain_slab_plan(rows, cols, &sp)) {
+      *p = BandPlan{sp.G, sp.threads, rows == 16 ? 4 : (rows == 30 ? 5 : 6), sp.chain_u64, sp.lds_bytes, sp.kernel};
+      return true;
+    }
+  }
+  if (rows == 16) {
+    if (!(g_band_debug_flags & 4) && n_chains <= device_cus() / Band16x32H::G) *p = band_plan_of<Band16x32H>(3);
+    else *p = band_plan_of<Band16x32>(0);
+  } else if (rows == 30) *p = band_plan_of<Band30x40>(1);
+  else *p = band_plan_of<Band32x64>(2);
   return true;
 }
 
@@ -955,16 +968,21 @@ int chain_band_groups(int n_chains, int rows, int cols) {
   return band_plan(rows, cols, n_chains, &p) ? p.G : 0;
 }
 
-// chains per pass: every workgroup of a pass must be co-resident (one per CU).  (Of the plan for MANY chains: the
-// largest number a single pass can take on this grid.)
+// chains per pass of the THIN-band plan: every workgroup of a pass must be co-resident (one per CU).  (16x32: of the
+// 4-band plan, the largest number a single pass can take on that grid.)
 int chain_band_chains_per_pass(int rows, int cols) {
-  BandPlan p;
-  return band_plan(rows, cols, 1 << 20, &p) ? device_cus() / p.G : 0;
+  if (rows == 16 && cols == 32) return device_cus() / Band16x32::G;
+  if (rows == 30 && cols == 40) return device_cus() / Band30x40::G;
+  if (rows == 32 && cols == 64) return device_cus() / Band32x64::G;
+  return 0;
 }
 
+// chains of the largest pass (= of the first one: the passes are of equal size up to the last)
 static int band_ws_chains(const BandPlan &p, int n_chains) {
   const int cap = device_cus() / p.G;
-  return n_chains < cap ? n_chains : cap;
+  if (cap < 1 || n_chains <= cap) return n_chains;
+  const int passes = (n_chains + cap - 1) / cap;
+  return (n_chains + passes - 1) / passes;
 }
 
 size_t chain_band_workspace_bytes(int n_chains, int rows, int cols) {
@@ -992,11 +1010,12 @@ int chain_band_launch(const ChainArgs &a, int n_chains, void *workspace, size_t 
   const int cap = device_cus() / p.G, wsn = band_ws_chains(p, n_chains);
   MVSN_REQUIRE(cap >= 1, MVSN_E_TOOLARGE, "mvsn_incremental_cost_volume(banded): %d bands exceed the %d CUs", p.G,
                device_cus());
-  static LdsOptIn opt[4];
-  LdsOptIn &o = opt[a.rows == 16 ? (p.G == 8 ? 3 : 0) : (a.rows == 30 ? 1 : 2)];
-  if (int rc = ensure_lds(o, (const void *)p.kernel, p.lds_bytes, "mvsn_incremental_cost_volume(banded)")) return rc;
-  for (int n0 = 0; n0 < n_chains; n0 += cap) {
-    const int nn = n_chains - n0 < cap ? n_chains - n0 : cap;
+  static LdsOptIn opt[7];
+  if (int rc = ensure_lds(opt[p.slot], (const void *)p.kernel, p.lds_bytes, "mvsn_incremental_cost_volume(banded)")) return rc;
+  // passes of equal size (85 + 85 + 85 + 1 chains would cost a whole pass for the last one)
+  const int passes = (n_chains + cap - 1) / cap, per = (n_chains + passes - 1) / passes;
+  for (int n0 = 0; n0 < n_chains; n0 += per) {
+    const int nn = n_chains - n0 < per ? n_chains - n0 : per;
     // every polled word starts from tag 0 (no step carries it): zeroed ahead of each pass -- with the first pass (which
     // fills the workspace: nn == wsn) also the status block behind the granules, so that a later pass keeps what an
     // earlier one reported
@@ -1009,9 +1028,9 @@ int chain_band_launch(const ChainArgs &a, int n_chains, void *workspace, size_t 
     b.ws_chains = wsn;
 #ifdef MVSN_BAND_HIDE_PTRS   // A/B aid (see MVSN_VIS10): the buffers reach the kernel through the by-value struct only
     const ChainArgs hidden{};
-    hipLaunchKernelGGL(p.kernel, dim3(nn * p.G), dim3(CB_THREADS), p.lds_bytes, stream, b, flags, CHAIN_VISIBLE(hidden));
+    hipLaunchKernelGGL(p.kernel, dim3(nn * p.G), dim3(p.threads), p.lds_bytes, stream, b, flags, CHAIN_VISIBLE(hidden));
 #else
-    hipLaunchKernelGGL(p.kernel, dim3(nn * p.G), dim3(CB_THREADS), p.lds_bytes, stream, b, flags, CHAIN_VISIBLE(b));
+    hipLaunchKernelGGL(p.kernel, dim3(nn * p.G), dim3(p.threads), p.lds_bytes, stream, b, flags, CHAIN_VISIBLE(b));
 #endif
   }
   return check_launch("mvsn_incremental_cost_volume(banded)");

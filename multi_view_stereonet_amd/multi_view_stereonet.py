@@ -1020,6 +1020,8 @@ class PlaneSweepEngine:
             if form == _native.CHAIN_BANDED and not (self.banded_ok and not self.net_state.banded_latched):
                 # lanes on several streams (see forward): what AUTO picks once the banded form is out of reach
                 form = self.lib.mvsn_incremental_cost_volume_form_for(1 << 20, rows, cols)
+                if form == _native.CHAIN_BANDED:       # (30x40 / 32x64: AUTO is the banded form at any chain count)
+                    form = _native.CHAIN_STEPWISE if cols % 4 == 0 else _native.CHAIN_DIRECT
         if form == _native.CHAIN_WINOGRAD and self.lib.mvsn_incremental_cost_volume_form(rows, cols) != form:
             form = _native.CHAIN_DIRECT        # no Winograd plan for this coarse grid
         if form == _native.CHAIN_STEPWISE and cols % 4 != 0:

@@ -897,6 +897,152 @@ def test_banded_chain_gather_paths_vs_oracle(kind, N, D, grid):
     assert torch.equal(got["banded"][1], got[other][1])
 
 
+SLAB = 16     # mvsn_debug_set_band_flags: pin the slab plan of the banded form (few fat bands per chain, 512 threads)
+
+
+@pytest.mark.parametrize("kind,N,D,grid,extra", [
+    ("small", 2, 9, (16, 32), 0), ("mixed", 3, 10, (16, 32), 0), ("vertical", 2, 7, (16, 32), 0),
+    ("small", 3, 9, (30, 40), 0), ("mixed", 2, 8, (30, 40), 0), ("vertical", 2, 6, (30, 40), 0),
+    ("small", 2, 8, (32, 64), 0), ("mixed", 2, 9, (32, 64), 0), ("vertical", 3, 6, (32, 64), 0),
+    ("small", 2, 8, (32, 64), 1), ("small", 3, 7, (30, 40), 1), ("small", 1, 1, (32, 64), 0), ("small", 2, 2, (30, 40), 0)])
+def test_slab_chain_gather_paths_vs_oracle(kind, N, D, grid, extra):
+    """The SLAB plan of the banded form (mvsn_chain_slab.hip: 3 / 4 fat bands per chain resident in LDS, what AUTO runs
+    on the 30x40 / 32x64 coarse grids once many chains are in flight; on 16x32 two bands, for this test) against the
+    oracle's recurrence (multi_view_stereonet.py:279-290, :424-440) and against another form of this library: the gather
+    from the planes ("small": every tap within one row of the band), every tap from the granules ("vertical": 3-6 rows per
+    plane; `extra` = 1 forces that path on small motion too), steps that alternate ("mixed"); D = 1 / 2 (no step / one)."""
+    w = load_weights("gta_sfm_150epochs")
+    net = net_for("gta_sfm_150epochs")
+    eng = net.engine()
+    g = torch.Generator().manual_seed(5)
+    H, Hinc = _motion_family(N, D, kind, seed=3)
+    r4, c4 = grid
+    src4 = torch.rand(N, 3, r4, c4, generator=g) * 2 - 1
+    F0 = torch.randn(N, 32, r4, c4, generator=g)
+    FL = torch.randn(N, 32, r4, c4, generator=g)
+    fvol_ref, cost_ref, mask_ref = _oracle_chain(w, src4, H, Hinc, F0, FL)
+    dev = [x.to(DEV) for x in (src4, H, Hinc, F0, FL)]
+    got = {}
+    other = "winograd" if grid == (16, 32) else "stepwise"
+    try:
+        for form in ("banded", other):
+            net.options.chain_form = form
+            eng.lib.mvsn_debug_set_band_flags((SLAB | extra) if form == "banded" else 0)
+            cost, mask, fvol = eng.incremental_cost_volume(*dev, want_features=True)
+            torch.cuda.synchronize()
+            assert eng.chain_status() == 0, form
+            got[form] = (cost.cpu(), mask.cpu(), fvol.cpu())
+    finally:
+        eng.lib.mvsn_debug_set_band_flags(0)
+        net.options.chain_form = "auto"
+    for form, (cost, mask, fvol) in got.items():
+        assert int((mask != mask_ref).sum()) == 0, form
+        for name, a, b in (("features", fvol, fvol_ref), ("cost", cost, cost_ref)):
+            mean_rel, max_rel = rel_err(a, b)
+            print(f"chain[{form}{'/slab' if form == 'banded' else ''}] {kind} N={N} D={D} {name}: mean-rel {mean_rel:.3e} "
+                  f"max-rel {max_rel:.3e}")
+            assert mean_rel < 1e-5 and max_rel < 1e-4, (form, name, mean_rel, max_rel)
+    assert torch.equal(got["banded"][1], got[other][1])
+
+
+@pytest.mark.parametrize("grid,N,D", [((30, 40), 90, 4), ((32, 64), 70, 4), ((30, 40), 40, 5)])
+def test_slab_chain_selected_for_many_chains_and_in_passes(grid, N, D):
+    """Beyond two passes of the thin-band plan (34 / 32 chains on 256 CUs) the banded form runs the slab plan, and more
+    chains than fit the chip at one workgroup per band (85 / 64) run as consecutive passes of equal size: every chain
+    of a multi-pass call equals the same chain run in a small call of its own, bit for bit (the chains are independent)."""
+    net = net_for("gta_sfm_150epochs")
+    eng = net.engine()
+    r4, c4 = grid
+    g = torch.Generator().manual_seed(23)
+    H, Hinc = _motion_family(N, D, "small", seed=9)
+    dev = [x.to(DEV) for x in (torch.rand(N, 3, r4, c4, generator=g) * 2 - 1, H, Hinc,
+                               torch.randn(N, 32, r4, c4, generator=g), torch.randn(N, 32, r4, c4, generator=g))]
+    assert eng.lib.mvsn_incremental_cost_volume_form_for(N, r4, c4) == _native.CHAIN_BANDED      # AUTO's choice
+    net.options.chain_form = "auto"
+    cost, mask, fvol = eng.incremental_cost_volume(*dev, want_features=True)
+    torch.cuda.synchronize()
+    assert eng.last_chain_form == _native.CHAIN_BANDED and eng.chain_status() == 0
+    try:
+        net.options.chain_form = "banded"
+        eng.lib.mvsn_debug_set_band_flags(SLAB)
+        for a in range(0, N, 7):
+            sl = slice(a, min(a + 3, N))
+            c1, m1, f1 = eng.incremental_cost_volume(*[x[sl].contiguous() for x in dev], want_features=True)
+            torch.cuda.synchronize()
+            assert eng.chain_status() == 0
+            assert torch.equal(c1, cost[sl]) and torch.equal(m1, mask[sl]) and torch.equal(f1, fvol[sl]), a
+    finally:
+        eng.lib.mvsn_debug_set_band_flags(0)
+        net.options.chain_form = "auto"
+
+
+@pytest.mark.parametrize("grid,N,D", [((30, 40), 5, 24), ((32, 64), 4, 20), ((30, 40), 85, 6), ((32, 64), 64, 6)])
+def test_slab_chain_hand_offs_under_uneven_load(grid, N, D):
+    """The slab plan's four hand-offs per step (boundary rows of F, of the moved features, of the two raw convolution
+    outputs with the GroupNorm sums) under UNEVEN load from a second stream, consumers L1-warm: 12 repeats, every word of
+    every output compared with the first run's."""
+    net = net_for("gta_sfm_150epochs")
+    eng = net.engine()
+    r4, c4 = grid
+    g = torch.Generator().manual_seed(29)
+    H, Hinc = _motion_family(N, D, "mixed" if N < 10 else "small", seed=4)
+    dev = [x.to(DEV) for x in (torch.rand(N, 3, r4, c4, generator=g) * 2 - 1, H, Hinc,
+                               torch.randn(N, 32, r4, c4, generator=g), torch.randn(N, 32, r4, c4, generator=g))]
+    try:
+        net.options.chain_form = "banded"
+        eng.lib.mvsn_debug_set_band_flags(SLAB)
+        cost0, mask0, fvol0 = eng.incremental_cost_volume(*dev, want_features=True)
+        torch.cuda.synchronize()
+        assert eng.chain_status() == 0
+        side = torch.cuda.Stream()
+        big = torch.empty(64 << 20, dtype=torch.float32, device=DEV)
+        for it in range(12):
+            if N < 10:      # (a full-chip launch has no CU to spare: the side stream would take bands' CUs away)
+                with torch.cuda.stream(side):
+                    for k in range(1 + it % 4):
+                        n = (8 + 8 * ((it + k) % 7)) << 20
+                        big[:n].add_(1.0)
+            cost, mask, fvol = eng.incremental_cost_volume(*dev, want_features=True)
+            torch.cuda.synchronize()
+            assert eng.chain_status() == 0
+            assert torch.equal(cost, cost0) and torch.equal(mask, mask0) and torch.equal(fvol, fvol0), it
+    finally:
+        eng.lib.mvsn_debug_set_band_flags(0)
+        net.options.chain_form = "auto"
+
+
+@pytest.mark.parametrize("grid,N,D", [((30, 40), 2, 8), ((32, 64), 3, 6)])
+def test_slab_chain_missing_band_is_repaired_in_stream(grid, N, D):
+    """A band that never runs (test hook; what a shared device can do to a launch that needs co-residency): the others'
+    waits are bounded, the status word is set, and the gated direct-form launch behind the banded one recomputes the
+    call in-stream -- finite outputs equal to the direct form's."""
+    net = net_for("gta_sfm_150epochs")
+    eng = net.engine()
+    r4, c4 = grid
+    g = torch.Generator().manual_seed(31)
+    H, Hinc = _motion_family(N, D, "small", seed=6)
+    dev = [x.to(DEV) for x in (torch.rand(N, 3, r4, c4, generator=g) * 2 - 1, H, Hinc,
+                               torch.randn(N, 32, r4, c4, generator=g), torch.randn(N, 32, r4, c4, generator=g))]
+    net.reset_device_status()
+    net.check_device_status()
+    net.reset_device_status()
+    try:
+        net.options.chain_form = "direct"
+        alone, mask_alone, _ = eng.incremental_cost_volume(*dev)
+        net.options.chain_form = "banded"
+        eng.lib.mvsn_debug_set_band_flags(SLAB | 2 | (10 << 8))
+        fixed, mask_fixed, _ = eng.incremental_cost_volume(*dev)
+        torch.cuda.synchronize()
+        assert eng.chain_status() != 0 and bool(torch.isfinite(fixed).all())
+        assert torch.equal(fixed, alone) and torch.equal(mask_fixed, mask_alone)
+        with pytest.warns(RuntimeWarning, match="hand-off"):
+            assert net.check_device_status() == 1
+    finally:
+        eng.lib.mvsn_debug_set_band_flags(0)
+        net.options.chain_form = "auto"
+        net.reset_device_status()
+
+
 @pytest.mark.parametrize("D", [1, 2, 3])
 @pytest.mark.parametrize("grid", [(16, 32), (30, 40), (32, 64)])
 def test_chain_with_one_to_three_planes_all_forms(grid, D):

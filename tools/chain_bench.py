@@ -20,17 +20,23 @@ for N in [int(a) for a in sys.argv[1:]] or [2, 256]:
     Hinc = torch.eye(3).repeat(N, D, 1, 1); Hinc[:, 1:, 0, 2] = 12.0 / (D - 1)
     F0 = torch.randn(N, 32, rows, cols, generator=g).cuda(); FL = torch.randn(B, 32, rows, cols, generator=g).cuda()
     H, Hinc = H.cuda(), Hinc.cuda()
-    for form in ("direct", "winograd", "stepwise", "banded", "banded4", "banded-x"):
+    for form in ("direct", "winograd", "stepwise", "banded", "banded4", "slab", "banded-x"):
         if form == "banded-x":        # banded with MVSN_BAND_FLAGS (A/B switches of the kernel, e.g. 8 = no pre-spin)
             if "MVSN_BAND_FLAGS" not in os.environ:
                 continue
             eng.lib.mvsn_debug_set_band_flags(int(os.environ["MVSN_BAND_FLAGS"]))
             form, tag = "banded", "banded-x"
+        elif form == "slab":            # the slab plan of the banded form pinned (debug flag 16): few fat bands per chain
+            eng.lib.mvsn_debug_set_band_flags(16)
+            form, tag = "banded", "slab"
         elif form == "banded4":         # 16x32: the 4-band plan pinned (debug flag 4) against the 8-band half-split plan
             if (rows, cols) != (16, 32) or N > 32:
                 continue
             eng.lib.mvsn_debug_set_band_flags(4)
             form, tag = "banded", "banded4"
+        elif form == "banded":         # the thin-band plan pinned (debug flag 32)
+            eng.lib.mvsn_debug_set_band_flags(32)
+            tag = form
         else:
             eng.lib.mvsn_debug_set_band_flags(0)
             tag = form
