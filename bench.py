@@ -59,14 +59,25 @@ CONFIGS = {
 }
 
 
+_FRAMES = {}     # (rows, cols, S, seed, smooth, jitter) -> one synthetic (image, S sources) set on the host
+
+
+def one_set(rows, cols, S, seed, smooth=False, jitter=0.0):
+    """One seeded synthetic set, generated once per process: the side legs of the default line (other batch sizes, the
+    host-fed and evaluate rates, the oracle checks) reuse the timed region's images instead of re-drawing ~2000 frames."""
+    key = (rows, cols, S, seed, bool(smooth), float(jitter))
+    if key not in _FRAMES:
+        _FRAMES[key] = synthetic.make_batch(rows, cols, S, batch=1, seed=seed, smooth=smooth, pose_jitter=jitter)
+    return _FRAMES[key]
+
+
 def config_inputs(cfg, batch, rank, device):
     """B independent (image, S sources) sets of a config; image 0 of rank 0 is the golden fixture's input."""
     import numpy as np
     fix = np.load(os.path.join(ROOT, "tests", "golden", cfg["golden"]))
     seed0, smooth = int(fix["meta"][5]), bool(fix["smooth"]) if "smooth" in fix.files else False
     jitter = float(fix["jitter"]) if "jitter" in fix.files else 0.0
-    parts = [synthetic.make_batch(cfg["rows"], cfg["cols"], cfg["S"], batch=1, seed=seed0 + rank * batch + i,
-                                  smooth=smooth, pose_jitter=jitter) for i in range(batch)]
+    parts = [one_set(cfg["rows"], cfg["cols"], cfg["S"], seed0 + rank * batch + i, smooth, jitter) for i in range(batch)]
     merged = {"left_image": torch.cat([p["left_image"] for p in parts], 0),
               "right_image": [torch.cat([p["right_image"][s] for p in parts], 0) for s in range(cfg["S"])],
               "K": torch.cat([p["K"] for p in parts], 0),
@@ -105,7 +116,7 @@ LEVEL_PMC_FILE = "r04_level_pmc.json"       # ... of the refiner towers level by
 def make_inputs(batch, first_seed, device):
     """B independent (image, 2 sources) sets; set i uses seed first_seed+i, so image 0 of rank 0 is
     the golden fixture's input."""
-    parts = [synthetic.make_batch(ROWS, COLS, S, batch=1, seed=first_seed + i) for i in range(batch)]
+    parts = [one_set(ROWS, COLS, S, first_seed + i) for i in range(batch)]
     merged = {"left_image": torch.cat([p["left_image"] for p in parts], 0),
               "right_image": [torch.cat([p["right_image"][s] for p in parts], 0) for s in range(S)],
               "K": torch.cat([p["K"] for p in parts], 0),

@@ -139,9 +139,8 @@ __device__ __forceinline__ void sb_sweep(const gu64 *base, unsigned off, unsigne
 template <int NC, int CSA, int RS>
 __device__ __forceinline__ void slab_layer(const float *__restrict__ act, const float *__restrict__ U,
                                            const float *__restrict__ ug, int wb, int lane, float (&y)[2][4][4]) {
-  const int k = lane >> 4;
   // conv0: channel 4 * 8 + 3 = 35 is the K padding (zero weights): its lane re-reads plane 34
-  const float *wbase = act + k * CSA + wb;
+  const float *wbase = act + (lane >> 4) * CSA + wb;
   const float *ub = U + lane * 4;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -149,7 +148,14 @@ __device__ __forceinline__ void slab_layer(const float *__restrict__ act, const 
     float d[2][3][4];
     floatx4 u[2][4];
     auto fetch = [&](int buf, int c4) {
-      const float *wp = wbase + c4 * 4 * CSA + half * RS - ((NC == 9 && c4 == 8 && k == 3) ? CSA : 0);
+      const float *wp = wbase + c4 * 4 * CSA + half * RS;
+      if constexpr (NC == 9) {
+        if (c4 == 8) {   // (formed here, from an opaque copy of the lane id: as a fourth base address held across the layer it spilled)
+          int kk = lane;
+          asm volatile("" : "+v"(kk));
+          wp -= (kk >> 4) == 3 ? CSA : 0;
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const float2 lo = *reinterpret_cast<const float2 *>(wp + i * RS);
@@ -299,18 +305,37 @@ __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int
   const float *bias0 = sparams, *gn0w = sparams + 32, *gn0b = sparams + 64, *bias1 = sparams + 96,
               *gn1w = sparams + 128, *gn1b = sparams + 160, *bias2 = sparams + 192;
 
-  // this lane's patch: patch q of the band (row-major), outputs (lo + 2 pr + a, 2 pc + b), e = a * 2 + b
-  const int q = wave * 16 + (lane & 15);
-  const bool pvalid = q < GEO::NPATCH;
-  const int qq = pvalid ? q : 0;
-  const int pr = qq / PCOLS, pc = qq - pr * PCOLS;
+  // This lane's patch: patch q of the band (row-major), outputs (lo + 2 pr + a, 2 pc + b), e = a * 2 + b.  Only the
+  // window origin lives across the layers; everything else about the patch is re-derived per phase from an opaque copy of
+  // the thread id (lane_geo below): held across the three layers those values were what spilled (a reload in front of a
+  // layer's first multiply waits a scratch round trip).
   const bool tile_live = wave * 16 < GEO::NPATCH;       // wave-uniform
-  const int wb = (2 * pr) * RS + 2 * pc;                // window origin inside a plane (local row 0 = image row lo - 1)
-  const int ob = wb + RS + 1;                           // output (0, 0)
-  const int cbase = (lane >> 4) * 4;                    // this lane's couts: ct * 16 + cbase + r
-  const int py0 = lo + 2 * pr, px0 = 2 * pc;
-  const bool top_pub = pvalid && pr == 0 && m > 0;                    // first pixel row of the band faces band m - 1
-  const bool bot_pub = pvalid && pr == GEO::PROWS - 1 && m < NB - 1;  // last pixel row faces band m + 1
+  int wb;                                               // window origin inside a plane (local row 0 = image row lo - 1)
+  {
+    const int q = wave * 16 + (lane & 15), qq = q < GEO::NPATCH ? q : 0;
+    const int pr = qq / PCOLS, pc = qq - pr * PCOLS;
+    wb = (2 * pr) * RS + 2 * pc;
+  }
+  struct LaneGeo {
+    bool pvalid, top_pub, bot_pub;
+    int pr, ob, cbase, px0, py0;
+  };
+  auto lane_geo = [&]() {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    LaneGeo g;
+    const int l = t & 63, q = (t >> 6) * 16 + (l & 15);
+    g.pvalid = q < GEO::NPATCH;
+    const int qq = g.pvalid ? q : 0;
+    g.pr = qq / PCOLS;
+    const int pc = qq - g.pr * PCOLS;
+    g.ob = (2 * g.pr) * RS + 2 * pc + RS + 1;           // output (0, 0)
+    g.cbase = (l >> 4) * 4;                             // this lane's couts: ct * 16 + cbase + r
+    g.py0 = lo + 2 * g.pr, g.px0 = 2 * pc;
+    g.top_pub = g.pvalid && g.pr == 0 && m > 0;                    // first pixel row of the band faces band m - 1
+    g.bot_pub = g.pvalid && g.pr == GEO::PROWS - 1 && m < NB - 1;  // last pixel row faces band m + 1
+    return g;
+  };
   const float inv_n = 1.0f / (8.0f * (float)P);
   __syncthreads();
 
@@ -321,10 +346,6 @@ __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int
   float *costg = a.cost + (size_t)n * 32 * D * P;
   float *fvolg = a.fvol ? a.fvol + (size_t)n * 32 * D * P : nullptr;
   const float *flp = a.fl + (size_t)(n % a.B) * 32 * P;
-  int fl_off = cbase * P + py0 * cols + px0;
-  int slice_off = (cbase * D) * P + py0 * cols + px0;
-  // granule index of this lane's (side 0, cout tile 0, r = 0) boundary-row store inside a hand-off region
-  int pub_off = ((m * 2) * 32 + cbase) * cols + px0;
 
   // Halo role of a thread: (side: 0 = row lo - 1, 1 = row hi + 1; channels 8 cg .. + 7; column x) of the two rows the
   // neighbours own.  Re-derived from an opaque copy of the thread id wherever it is used: kept across the layers its
@@ -362,10 +383,13 @@ __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int
       const int p = tid + it * SB_THREADS;
       if (p < P) {
         const int yy = p / cols, xx = p - yy * cols;
+        // the row coordinate alone, by the gather's own expressions (warp_coord / bilinear_taps: the x side is dead code here)
         WarpCoord c = warp_coord(Hl, (float)xx, (float)yy, (float)rows, (float)cols);
-        Bilinear b = bilinear_taps(c.ix, c.iy, rows, cols);
+        float iy = c.iy < 0.0f ? 0.0f : (c.iy > (float)(rows - 1) ? (float)(rows - 1) : c.iy);
+        int y0 = (int)floorf(iy);
+        if (!(y0 >= 0 && y0 < rows)) y0 = 0;
         const int blo = (yy / BR) * BR;
-        slow |= b.y0 < blo - 1 || b.y0 + 1 > blo + BR;   // (the unclamped + 1 row: a zero halo row at the image's edge)
+        slow |= y0 < blo - 1 || y0 + 1 > blo + BR;   // (the unclamped + 1 row: a zero halo row at the image's edge)
       }
     }
     if (__any(slow) && lane == 0) atomicOr(&fastw[dn & 1], 1);
@@ -431,11 +455,11 @@ __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int
 
   // boundary rows of this lane's 8 x (2x2) values -> the region of a hand-off (rows: e = 0, 1 top; e = 2, 3 bottom);
   // four byte offsets (side x cout tile), the rows of a cout tile by immediates
-  auto publish_rows = [&](size_t region, unsigned tag, const float (&v)[2][4][4]) {
+  auto publish_rows = [&](const LaneGeo &L, size_t region, unsigned tag, const float (&v)[2][4][4]) {
     const gu64 *R = ws + region;
-    int po = pub_off;
-    asm volatile("" : "+v"(po));
-    if (top_pub) {
+    // granule index of this lane's (side 0, cout tile 0, r = 0) boundary-row store inside the region
+    const int po = ((m * 2) * 32 + L.cbase) * cols + L.px0;
+    if (L.top_pub) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         const unsigned o = (unsigned)(po + ct * 16 * cols) * 8u;
@@ -445,7 +469,7 @@ __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int
         sb_publish2<3 * cols * 8>(R, o, tag, v[ct][3][0], v[ct][3][1]);
       }
     }
-    if (bot_pub) {
+    if (L.bot_pub) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         const unsigned o = (unsigned)(po + 32 * cols + ct * 16 * cols) * 8u;
@@ -463,9 +487,8 @@ __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int
 
   // ---- the recurrence ------------------------------------------------------------------------
   for (int d = 1; d < D; ++d) {
-    asm volatile("" : "+v"(tid), "+v"(lane16), "+v"(slice_off), "+v"(fl_off), "+v"(pub_off));
+    asm volatile("" : "+v"(tid), "+v"(lane16));
     const int lane_s = tid & 63;
-    const float *fl_lane = flp + fl_off;
     const int par = d & 1;
     SB_STAMP(0);
 
@@ -514,6 +537,9 @@ __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int
     // A2: previous plane's features moved by the incremental homography
     float fp[2][4][4];
     {
+      const LaneGeo L = lane_geo();
+      const bool pvalid = L.pvalid;
+      const int px0 = L.px0, py0 = L.py0, cbase = L.cbase, ob = L.ob;
       float Hl[9];
 #pragma unroll
       for (int i = 0; i < 9; ++i) Hl[i] = Hin[d * 9 + i];
@@ -592,18 +618,18 @@ __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int
       }
     }
     // E1b (publish): the band's boundary rows of the moved features are the neighbours' conv0 halo rows
-    publish_rows(GEO::E1B, (unsigned)d, fp);
+    publish_rows(lane_geo(), GEO::E1B, (unsigned)d, fp);
     SB_STAMP(3);
     sb_barrier();   // B1: every gather of plane d-1 is done
     SB_STAMP(4);
 
     // A3: lay out the refiner input [image(3) | moved features(32)] on rows lo-1 .. hi+1
-    if (pvalid) {
+    if (const LaneGeo L = lane_geo(); L.pvalid) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float *dst = act + (3 + ct * 16 + cbase + r) * CSA + ob;
+          float *dst = act + (3 + ct * 16 + L.cbase + r) * CSA + L.ob;
           dst[0] = fp[ct][r][0], dst[1] = fp[ct][r][1], dst[RS] = fp[ct][r][2], dst[RS + 1] = fp[ct][r][3];
         }
     }
@@ -643,6 +669,9 @@ __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int
     // halo rows normalised + activated into the planes.
     auto exchange = [&](int layer, size_t region, const float *bias, const float *gamma, const float *beta, bool residual,
                         auto &&meanwhile) {
+      const LaneGeo L = lane_geo();
+      const bool pvalid = L.pvalid;
+      const int cbase = L.cbase, ob = L.ob;
       float *gs = gstat + layer * 4;
       float s[4] = {0.f, 0.f, 0.f, 0.f};   // [ct][sum, sum of squares]
       float shift[2];
@@ -669,9 +698,10 @@ __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int
         sb_publish2<0>(Sl, g8, (unsigned)d, s[0], s[1]);
         sb_publish2<32>(Sl, g8, (unsigned)d, s[2], s[3]);
       }
-      publish_rows(region, (unsigned)d, y);
+      publish_rows(L, region, (unsigned)d, y);
       SB_STAMP(16 + layer * 4);
       sb_barrier();   // B3 / B7: planes and U free
+      // (issued in front of the hand-off's polling loads; behind them measured the same: profiles/r05_slab/README.md)
       dma_u(upk + (layer == 0 ? CW_U0_FLOATS : CW_U0_FLOATS + CW_U1_FLOATS), 8);
       meanwhile();    // work that needs none of the hand-off, placed where the workgroup would otherwise only wait
       SB_STAMP(17 + layer * 4);
@@ -768,6 +798,11 @@ __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int
 
     if (tile_live) slab_layer<8, CSA, RS>(act, U, upk + CW_U0_FLOATS + CW_U1_FLOATS, wb, lane, y);
     float2 fl[2][4][2];   // left features of this lane's outputs, in flight across the barrier
+    const LaneGeo L = lane_geo();
+    const bool pvalid = L.pvalid;
+    const int cbase = L.cbase, ob = L.ob, px0 = L.px0, py0 = L.py0, pr = L.pr;
+    const float *fl_lane = flp + (cbase * P + py0 * cols + px0);
+    const int slice_off = (cbase * D) * P + py0 * cols + px0;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -792,7 +827,7 @@ __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int
 #pragma unroll
           for (int e = 0; e < 4; ++e) y[ct][r][e] = fp[ct][r][e] + (y[ct][r][e] + b2);   // y := F_d
         }
-      if (d + 1 < D) publish_rows(GEO::E1, (unsigned)(d + 1), y);
+      if (d + 1 < D) publish_rows(L, GEO::E1, (unsigned)(d + 1), y);
       if (next_slow && pvalid) {   // the next step gathers from the granules: the whole band
         const gu64 *Fg = ws + GEO::FG;
         int go = cbase * P + py0 * cols + px0;
@@ -846,7 +881,10 @@ __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int
 #undef SB_STAMP
   dma_landed();       // the last step's look-ahead fetch must not outlive the workgroup's LDS
   // a hand-off that timed out leaves wrong numbers behind: poison the cost slice (see chain_band_kernel)
-  if (__syncthreads_or(dead) && pvalid) costg[(size_t)(D - 1) * P + slice_off] = __builtin_nanf("");
+  if (__syncthreads_or(dead)) {
+    const LaneGeo L = lane_geo();
+    if (L.pvalid) costg[(size_t)(D - 1) * P + (L.cbase * D) * P + L.py0 * cols + L.px0] = __builtin_nanf("");
+  }
 }
 
 // ---- host side: the slab plans as seen by the banded form's dispatcher (mvsn_chain_band.hip) -------------------------

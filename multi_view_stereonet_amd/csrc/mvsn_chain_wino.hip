@@ -409,6 +409,17 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a, MVS
     const int lane_s = tid & 63;
     const float *fl_lane = flp + fl_off;
     CW_STAMP(0);
+#ifndef MVSN_CW_NO_HTOUCH
+    // The two 36-byte homographies of a step are scalar loads at the top of the step; every other step they start a new
+    // 64-byte line.  Touch the NEXT step's lines now: four scalar loads into registers nothing reads, held (tied into the
+    // first barrier's wait below) until they have landed.  Measured (tools/chain_bench.py, three interleaved runs):
+    // 2.403-2.407 ms per 256 chains against 2.413-2.423 without (profiles/r05_slab/README.md).
+    float ht0 = 0.f, ht1 = 0.f, ht2 = 0.f, ht3 = 0.f;
+    if (d + 1 < D)
+      asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x20\n\ts_load_dword %2, %5, 0x0\n\ts_load_dword %3, %5, 0x20"
+                   : "=s"(ht0), "=s"(ht1), "=s"(ht2), "=s"(ht3)
+                   : "s"(Hn + (d + 1) * 9), "s"(Hin + (d + 1) * 9));
+#endif
 
     // A1: image plane d and its mask (global gathers; the 6 KB source image stays in L1/L2)
     float img[IMG_IT][3], mk[IMG_IT];
@@ -461,6 +472,9 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a, MVS
     }
     CW_STAMP(1);
     cw_barrier();  // B1: every gather of plane d-1 is done
+#ifndef MVSN_CW_NO_HTOUCH
+    asm volatile("" : "+s"(ht0), "+s"(ht1), "+s"(ht2), "+s"(ht3));   // (behind the barrier's s_waitcnt lgkmcnt(0))
+#endif
     CW_STAMP(2);
 
     // A3: lay out the refiner input [image(3) | moved features(32)]

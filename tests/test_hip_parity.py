@@ -1197,8 +1197,9 @@ def test_banded_chain_in_passes(grid, N, D):
     want = _native.CHAIN_BANDED if r4 != 16 else _native.CHAIN_WINOGRAD
     assert lib.mvsn_incremental_cost_volume_form_for(N, r4, c4) == want
     assert lib.mvsn_incremental_cost_volume_form_for(cap, r4, c4) == _native.CHAIN_BANDED
+    # beyond two thin-band passes: 16x32 has the plane-resident kernel; 30x40 / 32x64 stay banded (its slab plan takes over)
     assert lib.mvsn_incremental_cost_volume_form_for(2 * cap + 1, r4, c4) == (
-        _native.CHAIN_STEPWISE if r4 != 16 else _native.CHAIN_WINOGRAD)
+        _native.CHAIN_BANDED if r4 != 16 else _native.CHAIN_WINOGRAD)
     net.options.chain_form = "banded"
     try:
         cost, mask, fvol = eng.incremental_cost_volume(*dev, want_features=True)
