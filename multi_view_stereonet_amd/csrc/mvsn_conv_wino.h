@@ -12,6 +12,7 @@ struct WinoGeom {
   int D;      // planes per sample (1 for the 2-D layers)
   bool vol;   // 3 x 3 x 3 layer (volume form)
   bool s2;    // 5 x 5 stride-2 layer on the input's four phases
+  bool wide;  // volume form on planes 32 < W <= 40 columns wide: tiles of 10 rows x the whole width (see conv_wino_kernel)
   int nty, ntx, tiles, nchunks;
   size_t packed_floats;
 };

@@ -259,7 +259,14 @@ __global__ void wino_pack_kernel(const float *__restrict__ w, int cin, int cout,
 //         fit next to the raw ring, so each step's 16 KB of U travel through a second ring one step behind the
 //         raw tiles (the slot of step s is free once every wave has passed the barrier of step s + 1).
 // RIDE    256-float units of a carried normalise / activate / add job per wave and step (0: none), see RideArgs
-template <int MODE, int KS, int NSTAGE, int DIL, bool VOL = false, int RIDE = 0>
+// WIDE    (volume form) tile = 10 rows x 40 columns instead of 16 x 32: planes 32 < W <= 40 columns wide -- the 30x40
+//         coarse grid of 640x480 frames -- are 2 x 2 tiles of 16 x 32 at 58.6 % utilisation (the regulariser of BASELINE
+//         config 4 ran at 0.40 of the matrix pipe where the 16x32 / 32x64 grids reach 0.68); as 10-row strips of the whole
+//         width a plane is 3 tiles of 5 x 20 = 100 patches: 78 %.  The 128 patch slots of a tile are dealt row-major
+//         (slot q = 16 wave + lane & 15 -> patch row q / 20, column q % 20; slots >= 100 idle): only the lane -> patch
+//         map, the tile constants and the epilogue's per-lane validity differ.
+constexpr int WN_WIDE_TY = 10, WN_WIDE_TX = 40, WN_WIDE_PC = WN_WIDE_TX / 2, WN_WIDE_NP = (WN_WIDE_TY / 2) * WN_WIDE_PC;
+template <int MODE, int KS, int NSTAGE, int DIL, bool VOL = false, int RIDE = 0, bool WIDE = false>
 __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, const float *__restrict__ in,
                                                                   const float *__restrict__ upk,
                                                                   const float *__restrict__ bias,
@@ -281,8 +288,11 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   constexpr bool LDS_BARRIER = !VOL;               // see wn_barrier (r4: with the LDS-only barrier the volume form carrying a
                                                    // pass is no faster either: 14.6 vs 14.4 ms per step for the six carriers)
 #endif
-  constexpr int PA = wn_pa(DIL), XS = wn_xs(DIL), DQ = XS / 4, GROUPS = wn_groups(DIL), PIECES = wn_pieces(DIL);
-  constexpr int RCST = wn_rcst(DIL);
+  static_assert(!WIDE || (VOL && DIL == 1), "wide tiles: volume form only");
+  constexpr int TY = WIDE ? WN_WIDE_TY : WN_TY, TX = WIDE ? WN_WIDE_TX : WN_TX;
+  constexpr int PA = wn_pa(DIL), XS = TX + 2 * PA, DQ = XS / 4, GROUPS = (TY + 2 * DIL) * DQ, PIECES = (GROUPS + 63) / 64;
+  constexpr int RCST = (TY + 2 * DIL) * XS + 16;
+  static_assert(WIDE || (XS == wn_xs(DIL) && GROUPS == wn_groups(DIL) && PIECES == wn_pieces(DIL) && RCST == wn_rcst(DIL)), "");
   constexpr int STAGE = KS * 4 * RCST;               // ring stage (floats)
   float *U = smem + NSTAGE * STAGE;                  // nchunks * WN_UFLOATS, resident (VOL: ring of NSTAGE steps)
   // dilation 1: raw tiles stored one float further (4-byte-aligned DMA destination), see tr_load
@@ -354,7 +364,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       tile -= pf_z * g.tiles;
     }
     const int tyi = wdiv(tile, g.fd_ntx), txi = tile - tyi * g.ntx;
-    const int y0 = tyi * WN_TY, x0 = txi * WN_TX;
+    const int y0 = tyi * TY, x0 = txi * TX;
     pf_n = n;
     // (the pieces' rows / columns are re-derived per tile from an opaque copy of the lane id: hoisted out of the tile
     // loop they occupy six registers for the whole launch -- spilled, and reloaded per step, in the carrying kernels)
@@ -434,7 +444,12 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
 
   const int pcol = lane & 15, kc = lane >> 4;   // this lane's patch column / channel within the chunk; patch row = wave
   // first output row / column of patch row `wave` / patch column `pcol` inside the tile (the second is + DIL)
-  const int ya = (wave / DIL) * 2 * DIL + wave % DIL, xa = (pcol / DIL) * 2 * DIL + pcol % DIL;
+  int ya = (wave / DIL) * 2 * DIL + wave % DIL, xa = (pcol / DIL) * 2 * DIL + pcol % DIL;
+  if constexpr (WIDE) {   // slot q of the tile -> patch (q / 20, q % 20); idle slots read patch 0 (their outputs are never stored)
+    const int q = wave * 16 + pcol, qq = q < WN_WIDE_NP ? q : 0;
+    const int pr = qq / WN_WIDE_PC;
+    ya = 2 * pr, xa = 2 * (qq - pr * WN_WIDE_PC);
+  }
   const int my_items = slot < total ? (total - slot + G - 1) / G : 0;
   const int total_steps = my_items * nsteps;
 
@@ -485,7 +500,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       }
       if (xf_chunk == 0) {
         const int tyi = wdiv(tile, g.fd_ntx), txi = tile - tyi * g.ntx;
-        const int y0 = tyi * WN_TY, x0 = txi * WN_TX;
+        const int y0 = tyi * TY, x0 = txi * TX;
         xf_mask = 0;
         int lo;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
@@ -825,11 +840,21 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     int lq;   // (re-derived, see finish_tile)
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lq));
     const int pc = lq & 15, gq = lq >> 4;
-    const int oy = y0 + 2 * wave, ox = x0 + 2 * pc;
-    const bool row0 = oy < g.H, row1 = oy + 1 < g.H, cok = ox < g.W;   // W % 4 == 0: a column pair is inside or outside
+    int oy = y0 + 2 * wave, ox = x0 + 2 * pc;
+    bool slot_ok = true;   // WIDE: the tile's 128 slots hold 100 patches
+    if constexpr (WIDE) {
+      const int q = wave * 16 + pc;
+      slot_ok = q < WN_WIDE_NP;
+      const int qq = slot_ok ? q : 0, pr = qq / WN_WIDE_PC;
+      oy = y0 + 2 * pr, ox = x0 + 2 * (qq - pr * WN_WIDE_PC);
+    }
+    // rows: wave-uniform in the 16 x 32 form, per lane in the WIDE form (there a row past the image is an out-of-range
+    // offset like a column past it, and the stores are unconditional)
+    const bool row0 = oy < g.H, row1 = oy + 1 < g.H, cok = slot_ok && ox < g.W;   // W % 4 == 0: a column pair is inside or outside
     const size_t cstride = VOL ? (size_t)g.D * plane : plane;
     const __amdgpu_buffer_rsrc_t osrd = wn_rsrc(out + (size_t)n * 32 * cstride + (size_t)z * plane, (unsigned)(32 * cstride * 4));
     const unsigned ovoff = cok ? ((unsigned)(4 * gq) * (unsigned)cstride + (unsigned)(oy * g.W + ox)) * 4u : 0xFFFFFFFFu;
+    const unsigned ovoff0 = (!WIDE || row0) ? ovoff : 0xFFFFFFFFu, ovoff1 = (!WIDE || row1) ? ovoff : 0xFFFFFFFFu;
     float s[2] = {0.f, 0.f};
     float y[2][4][4];   // [t][r][2 * row + column]
 #pragma unroll
@@ -849,8 +874,8 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         y[t][r][3] = s1[1] - s1[2] - s1[3] + bv[r];
         if (!(MVSN_WN_ABLATE & 64) || n < 0) {   // (rows: uniform; columns outside the image: dropped by the range check)
           const unsigned so = (unsigned)((size_t)(t * 16 + r) * cstride * 4);
-          if (row0) wn_store2<MVSN_WN_NT_TR ? 2 : 0>(osrd, ovoff, so, y[t][r][0], y[t][r][1]);
-          if (row1) wn_store2<MVSN_WN_NT_TR ? 2 : 0>(osrd, ovoff, so + (unsigned)g.W * 4u, y[t][r][2], y[t][r][3]);
+          if (WIDE || row0) wn_store2<MVSN_WN_NT_TR ? 2 : 0>(osrd, ovoff0, so, y[t][r][0], y[t][r][1]);
+          if (WIDE || row1) wn_store2<MVSN_WN_NT_TR ? 2 : 0>(osrd, ovoff1, so + (unsigned)g.W * 4u, y[t][r][2], y[t][r][3]);
         }
         if (row0 && cok) s[t] += y[t][r][0] + y[t][r][1];
         if (row1 && cok) s[t] += y[t][r][2] + y[t][r][3];
@@ -867,7 +892,9 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       };
       // valid outputs of the record: 4 couts x rows x 2 columns x the tile's valid patch columns (uniform)
       const int vp = (g.W - x0) >> 1;
-      const float npos = (float)(8 * ((row0 ? 1 : 0) + (row1 ? 1 : 0)) * (vp > 16 ? 16 : vp));
+      float npos = (float)(8 * ((row0 ? 1 : 0) + (row1 ? 1 : 0)) * (vp > 16 ? 16 : vp));
+      if constexpr (WIDE)   // per lane: 4 couts x 2 columns x the valid rows of the record's valid patches
+        npos = sum16(cok ? (float)(8 * ((row0 ? 1 : 0) + (row1 ? 1 : 0))) : 0.0f);
       float m[2], qv[2] = {0.f, 0.f};
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -911,7 +938,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       tile_id -= z * g.tiles;
     }
     const int tyi = wdiv(tile_id, g.fd_ntx), txi = tile_id - tyi * g.ntx;
-    const int y0 = tyi * WN_TY, x0 = txi * WN_TX;
+    const int y0 = tyi * TY, x0 = txi * TX;
 
     // acc is first written by the tile's first 32 multiplies (C = 0): no zeroing pass.  The empty asm "defines"
     // the registers here, so the allocator does not carry 128 undefined values around the tile loop.
@@ -1295,7 +1322,7 @@ bool wino_geom(const mvsn_conv_desc *d, WinoGeom *g) {
   if (d->kd == 1 && d->kh == 5 && d->kw == 5 && d->stride == 2) {   // 5 x 5 stride 2 on the input's four phases (conv_wino_s2_kernel)
     if (d->c_in != 32 || d->dilation != 1 || d->depth != 1 || d->cols % 8 != 0) return false;
     if ((unsigned long long)d->rows * d->cols * 32ull * 4ull >= (1ull << 31)) return false;   // 32-bit descriptor offsets
-    g->s2 = true;
+    g->s2 = true, g->wide = false;
     g->n = d->n, g->cin = 32, g->H = d->rows, g->W = d->cols, g->dil = 1, g->D = 1, g->vol = false;
     g->nty = ((d->rows - 1) / 2 + 1 + S2_TY - 1) / S2_TY;
     g->ntx = ((d->cols - 1) / 2 + 1 + S2_TX - 1) / S2_TX;
@@ -1314,6 +1341,15 @@ bool wino_geom(const mvsn_conv_desc *d, WinoGeom *g) {
   g->D = d->depth, g->vol = d->kd == 3;
   g->nty = (d->rows + WN_TY - 1) / WN_TY;
   g->ntx = (d->cols + WN_TX - 1) / WN_TX;
+  // volume form on planes a little wider than one 16 x 32 tile: 10-row strips of the whole width (WIDE) wherever that
+  // takes fewer tile slots per plane (30 x 40: 3 strips of 100 patches instead of 2 x 2 tiles of 128 slots)
+  g->wide = false;
+#ifndef MVSN_WN_NO_WIDE
+  if (d->kd == 3 && d->cols > WN_TX && d->cols <= WN_WIDE_TX) {
+    const int strips = (d->rows + WN_WIDE_TY - 1) / WN_WIDE_TY;
+    if (strips < g->nty * g->ntx) g->wide = true, g->nty = strips, g->ntx = 1;
+  }
+#endif
   g->tiles = g->nty * g->ntx;
   if (g->vol) {   // volume form: 32 -> 32 channels, dilation 1; U streams, 3 x 8 chunks
     if (d->c_in != 32 || d->dilation != 1) return false;
@@ -1423,7 +1459,8 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   const int ks = (head || g.dil == 8 || (job && g.dil == 4)) ? 1 : 2;
   // (a carrying launch waits with one step of DMA in flight, see RideArgs: a fourth stage would never be used)
   const int nstage = head ? 6 : ((g.dil == 1 && g.nchunks <= 8 && !job) ? 4 : 3);
-  size_t lds = ((size_t)nstage * ks * 4 * wn_rcst(g.dil) +
+  const size_t rcst = g.wide ? (size_t)(WN_WIDE_TY + 2) * (WN_WIDE_TX + 2 * wn_pa(1)) + 16 : (size_t)wn_rcst(g.dil);
+  size_t lds = ((size_t)nstage * ks * 4 * rcst +
                 (g.vol ? (size_t)nstage * ks : (size_t)((g.nchunks + ks - 1) / ks * ks)) * WN_UFLOATS) * sizeof(float);
   lds += 32 * sizeof(float);                                      // bias
   if (job && !g.vol) lds += (size_t)WN_WAVES * wino_ride_units(g) * 1024;   // the carried job's residual slots
@@ -1455,13 +1492,15 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   grid = dim3((unsigned)(total < cus ? total : cus));   // persistent: one workgroup per CU walks items grid-strided
   const bool xf = in_stats != nullptr;
   if (job) {   // the same kernels with the carried job's loads / stores in their steps
-    if (g.vol) { if (xf) WN_CASE(1, 2, 3, 1, true, 1); else WN_CASE(0, 2, 3, 1, true, 1); }
+    if (g.vol && g.wide) { if (xf) WN_CASE(1, 2, 3, 1, true, 1, true); else WN_CASE(0, 2, 3, 1, true, 1, true); }
+    else if (g.vol) { if (xf) WN_CASE(1, 2, 3, 1, true, 1); else WN_CASE(0, 2, 3, 1, true, 1); }
     else if (g.dil == 1) { if (xf) WN_CASE(1, 2, 3, 1, false, 2); else WN_CASE(0, 2, 3, 1, false, 2); }
     else if (g.dil == 2) { if (xf) WN_CASE(1, 2, 3, 2, false, 2); else WN_CASE(0, 2, 3, 2, false, 2); }
     else if (g.dil == 4) { if (xf) WN_CASE(1, 1, 3, 4, false, 1); else WN_CASE(0, 1, 3, 4, false, 1); }
     else { if (xf) WN_CASE(1, 1, 3, 8, false, 1); else WN_CASE(0, 1, 3, 8, false, 1); }
   } else
-  if (g.vol) { if (xf) WN_CASE(1, 2, 3, 1, true); else WN_CASE(0, 2, 3, 1, true); }
+  if (g.vol && g.wide) { if (xf) WN_CASE(1, 2, 3, 1, true, 0, true); else WN_CASE(0, 2, 3, 1, true, 0, true); }
+  else if (g.vol) { if (xf) WN_CASE(1, 2, 3, 1, true); else WN_CASE(0, 2, 3, 1, true); }
   else if (head) { if (xf) WN_CASE(1, 1, 6, 1); else WN_CASE(0, 1, 6, 1); }
   else if (g.dil == 1 && g.nchunks > 8) { if (xf) WN_CASE(1, 2, 3, 1); else WN_CASE(0, 2, 3, 1); }
   else if (g.dil == 1) { if (xf) WN_CASE(1, 2, 4, 1); else WN_CASE(0, 2, 4, 1); }

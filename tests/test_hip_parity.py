@@ -217,7 +217,10 @@ def test_conv_winograd_form(cin, rows, cols, n, dil):
 
 
 @pytest.mark.parametrize("depth,rows,cols,n", [(8, 16, 32, 2), (5, 9, 36, 1), (64, 16, 32, 1), (3, 37, 68, 2), (1, 16, 32, 2),
-                                               (2, 8, 12, 3), (16, 16, 32, 20)])
+                                               (2, 8, 12, 3), (16, 16, 32, 20),
+                                               # 32 < cols <= 40: 10-row strips of the whole width (WIDE tiles): the 30x40 grid
+                                               # of BASELINE config 4, a ragged last strip, a narrower plane, many items
+                                               (6, 30, 40, 2), (3, 23, 36, 1), (96, 30, 40, 1), (4, 30, 40, 70)])
 def test_conv_winograd_volume_form(depth, rows, cols, n):
     """3x3x3 32->32 layers as 2-D Winograd products summed over the depth tap (MVSN_CONV_FP32_WINO with kd = 3):
     values and GroupNorm statistics against ATen and the direct fp32 kernel, plus the fused input transform."""
@@ -2185,7 +2188,8 @@ def test_sliced_refiner_tower_is_bit_identical():
 
 @pytest.mark.parametrize("mode1,n,jn,depth,rows,cols,expect", [(False, 2, 2, 8, 16, 32, 1), (True, 2, 2, 5, 16, 32, 1),
                                                                 (False, 3, 2, 4, 12, 24, 0),     # 4*12*24 % 256 != 0
-                                                                (False, 2, 2, 6, 32, 64, 1)])
+                                                                (False, 2, 2, 6, 32, 64, 1),
+                                                                (False, 2, 2, 32, 30, 40, 1), (True, 3, 3, 32, 30, 40, 1)])   # WIDE tiles
 def test_conv3d_forward_carry_is_bit_identical(mode1, n, jn, depth, rows, cols, expect):
     """The volume form (3x3x3 regulariser layer) carrying an in-place LReLU(GN(.)) pass over another volume."""
     from multi_view_stereonet_amd.multi_view_stereonet import _Job
