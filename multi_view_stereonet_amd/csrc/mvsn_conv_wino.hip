@@ -1132,6 +1132,10 @@ __global__ void wino_s2_pack_kernel(const float *__restrict__ w, float *__restri
 #ifndef MVSN_S2_PIN
 #define MVSN_S2_PIN 1
 #endif
+// MVSN_S2_CNTWAIT: the counted wait at the top of a tile's first step (see the step loop).  Kept on: 1-3 % faster than a
+// full drain (profiles/r05_slab/s2_counted_wait_ab.txt); what it leans on -- at least eight vector-memory instructions
+// between a step's last DMA piece and the wait on every path that ran a tile epilogue -- is asserted on the compiled
+// code by tools/check_dma_isa.py (CPU test tests/test_dma_isa_cpu.py).
 #ifndef MVSN_S2_CNTWAIT
 #define MVSN_S2_CNTWAIT 1
 #endif

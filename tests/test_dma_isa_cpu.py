@@ -18,3 +18,5 @@ def test_inline_asm_dma_kernels_keep_their_shape():
     assert p.returncode == 0, p.stdout + p.stderr
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("conv_wino_kernel<")]
     assert len(lines) >= 4 and all(ln.endswith("OK") for ln in lines), p.stdout
+    s2 = [ln for ln in p.stdout.splitlines() if ln.startswith("conv_wino_s2_kernel:")]
+    assert len(s2) == 1 and s2[0].endswith("OK") and " 1 counted wait" in s2[0], p.stdout

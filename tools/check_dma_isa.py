@@ -151,10 +151,109 @@ def check(name, p, body):
     return errs, len(dma_blocks), counted, (paths_total, mixed)
 
 
+S2_KERNEL = re.compile(r"^(_ZN4mvsn19conv_wino_s2_kernel\S*):")
+
+
+def check_s2(text):
+    """conv_wino_s2_kernel waits for a step's DMA pieces with `s_waitcnt vmcnt(8)` at the top of a tile's first step
+    (MVSN_S2_CNTWAIT): behind the pieces the wave has issued the finished tile's output stores, and the count is right
+    only while AT LEAST eight vector-memory instructions sit between the last piece and the wait on every path that ran
+    a tile epilogue (more only make the wait stricter; fewer -- a store the compiler merged or dropped -- would let a piece
+    be in flight when the tile is read).  Asserted here; plus the
+    DMA-block integrity and no-scratch properties of the other inline-assembly kernels."""
+    lines = text.split("\n")
+    start = next((i for i, l in enumerate(lines) if S2_KERNEL.match(l)), None)
+    if start is None:
+        return ["conv_wino_s2_kernel not found"], 0
+    end = next(j for j in range(start, len(lines)) if lines[j].startswith(".Lfunc_end"))
+    bbs, blk, nblk = [["<entry>", []]], None, 0
+    for l in lines[start + 1:end]:
+        t = l.strip()
+        if t.startswith(";;#ASMSTART"):
+            blk = nblk
+            nblk += 1
+            continue
+        if t.startswith(";;#ASMEND"):
+            blk = None
+            continue
+        m = re.match(r"^(\.LBB\d+_\d+):", t)
+        if m:
+            bbs.append([m.group(1), []])
+            continue
+        if not t or t.startswith((";", ".", "//")) or t.endswith(":"):
+            continue
+        t = t.split(";")[0].strip()
+        if t:
+            bbs[-1][1].append((t, blk))
+    index = {bb[0]: i for i, bb in enumerate(bbs)}
+    preds = {i: set() for i in range(len(bbs))}
+    for i, (label, ins) in enumerate(bbs):
+        falls = True
+        for t, _ in ins:
+            m = re.match(r"s_(c?branch\S*)\s+(\.LBB\d+_\d+)", t)
+            if m:
+                preds[index[m.group(2)]].add(i)
+                if m.group(1) == "branch":
+                    falls = False
+            if t.startswith(("s_endpgm", "s_setpc")):
+                falls = False
+        if falls and i + 1 < len(bbs):
+            preds[i + 1].add(i)
+
+    def is_dma(x):
+        return x.startswith("global_load_lds_dwordx4") or (x.startswith("buffer_load_dwordx4") and x.endswith(" lds"))
+    errs, waits = [], 0
+    if any(t.startswith("scratch_") for _, ins in bbs for t, _ in ins):
+        errs.append("scratch instructions present (spills)")
+    for bi, (label, ins) in enumerate(bbs):
+        for k, (t, bk) in enumerate(ins):
+            m = re.match(r"s_waitcnt vmcnt\((\d+)\)", t)
+            if not (m and bk is not None and int(m.group(1)) > 0):
+                continue
+            n = int(m.group(1))
+            waits += 1
+            # every path back from the wait: count non-DMA VMEM instructions until the first DMA piece
+            work, done, full = [(bi, k, 0)], set(), 0
+            while work:
+                b, pos, seen = work.pop()
+                j, hit = pos - 1, False
+                while j >= 0:
+                    tj = bbs[b][1][j][0]
+                    if VMEM.match(tj):
+                        if is_dma(tj):
+                            hit = True
+                            break
+                        seen += 1
+                        if seen >= n:
+                            hit = True
+                            break
+                    j -= 1
+                if hit:
+                    full += seen >= n
+                    # (seen == 0: the path of a step that did not end a tile -- the walk is path-insensitive, and the
+                    # source takes the counted wait only when the step before DID end one: `cc == 0 && step > 0`)
+                    if 0 < seen < n:
+                        errs.append(f"vmcnt({n}) with only {seen} vector-memory instructions behind the last DMA piece on a path through {bbs[b][0]}")
+                    continue
+                for pb in preds[b]:
+                    if (pb, seen) not in done:
+                        done.add((pb, seen))
+                        work.append((pb, len(bbs[pb][1]), seen))
+            if not full:
+                errs.append(f"vmcnt({n}): no path with {n} vector-memory instructions between the last DMA piece and the wait")
+    return errs, waits
+
+
 def main():
     text = assemble()
     bad = 0
     checked = 0
+    errs, waits = check_s2(text)
+    print(f"conv_wino_s2_kernel: {waits} counted wait(s), each behind >= its count of younger vector-memory instructions: "
+          f"{'OK' if not errs else 'FAIL'}")
+    for e in errs[:10]:
+        print("   ", e)
+    bad += bool(errs)
     for name, p, body in kernels(text):
         if not (p["ride"] > 0 and p["dil"] == 1):
             continue
