@@ -109,8 +109,8 @@ def l1_against(ref0, got0, golden=None):
     return res
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 dense peak
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC_FILE = "r04_pmc_traffic.json"   # FETCH_SIZE / WRITE_SIZE passes of the bench command (tools/prof_round.sh)
-LEVEL_PMC_FILE = "r04_level_pmc.json"       # ... of the refiner towers level by level (tools/level_profile.py)
+PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"   # FETCH_SIZE / WRITE_SIZE passes of the bench command (tools/prof_round.sh)
+LEVEL_PMC_FILE = "r05_level_pmc.json"       # ... of the refiner towers level by level (tools/level_profile.py)
 
 
 def make_inputs(batch, first_seed, device):
@@ -179,9 +179,13 @@ def other_configs(dev, skip):
                 torch.cuda.synchronize()
                 blocks.append((time.perf_counter() - t0) / reps * 1e3)
             ms = sorted(blocks)[2]
+            eng = net.engine()
+            form = {1: "direct", 2: "winograd", 3: "stepwise", 4: "banded"}.get(eng.last_chain_form, "?")
+            if form == "banded":        # which plan: thin bands (15 / 16 / 8 / 4 workgroups per chain) or slabs (3 / 4)
+                n_ch, r4, c4 = eng.last_chain_shape
+                form += f" ({eng.lib.mvsn_incremental_cost_volume_banded_groups(n_ch, r4, c4)} workgroups per chain)"
             entry[f"B={b}"] = {"ms_per_forward": round(ms, 3), "depthmaps_per_s": round(b / ms * 1e3, 1),
-                               "chain_form": {1: "direct", 2: "winograd", 3: "stepwise", 4: "banded"}.get(
-                                   net.engine().last_chain_form, "?")}
+                               "chain_form": form}
             if b == 1:
                 entry["l1_vs_ref"] = l1_against(ref0, out["left_idepthmap_pyr"][0][:1].cpu(), cfg["golden"])
             del inp, out

@@ -97,7 +97,7 @@ int mvsn_homography_warp(const float *image, const float *H, int batch, int chan
 #define MVSN_CHAIN_STEPWISE 3 /* one plane per round of full-chip launches (warp, three Winograd convolutions with the
                                  GroupNorm statistics of the producing launch, the residual pass, the cost slice):
                                  for coarse grids whose planes do not fit one CU (30x40, 32x64), any number of chains
-                                 (cols % 4 == 0); AUTO's choice there once the banded form would need three passes */
+                                 (cols % 4 == 0); a selectable form -- since round 5 AUTO stays on the banded form there */
 #define MVSN_CHAIN_BANDED 4   /* one chain on SEVERAL workgroups: the coarse plane cut into bands of pixel rows (16x32: 8
                                  bands of 2 rows up to CUs / 8 chains -- every layer split by transform-row half across a
                                  band's waves -- and 4 bands of 4 rows beyond, bit-identical; 30x40: 15 of 2; 32x64: 16 of
@@ -107,8 +107,13 @@ int mvsn_homography_warp(const float *image, const float *H, int batch, int chan
                                  write-through granules -- no fence, no placement assumption.  For few chains in flight
                                  (batch 1: the reference's loop, test.py:38,197-200): the workgroups of a launch must be
                                  co-resident, so more chains than CUs / bands run as consecutive passes inside the call
-                                 (AUTO: one pass on 16x32, up to two on 30x40 / 32x64), and only ONE such call may be in
-                                 flight per device.  Needs workspace (..._workspace_bytes_for); the word at
+                                 (AUTO: one pass on 16x32), and only ONE such call may be in flight per device.
+                                 30x40 / 32x64 beyond two passes of the thin bands (34 / 32 chains on 256 CUs): the SLAB
+                                 plan -- 3 bands of 10 rows / 4 bands of 8 rows per chain, each a 512-thread workgroup
+                                 that keeps its band's activation planes resident in LDS like the plane-resident
+                                 Winograd kernel (85 / 64 chains per pass, passes of equal size; four hand-offs per
+                                 step; mvsn_incremental_cost_volume_banded_groups tells which plan a call runs).
+                                 Needs workspace (..._workspace_bytes_for); the word at
                                  mvsn_incremental_cost_volume_status_offset() inside it is 0 after a clean run. */
 size_t mvsn_feature_refiner_packed_floats(void);
 /* Pack the ten FeatureRefiner tensors (state_dict order: conv0.{weight,bias}, bn0.{weight,bias},
@@ -130,6 +135,9 @@ size_t mvsn_incremental_cost_volume_workspace_bytes_for(int n_chains, int num_id
 /* MVSN_CHAIN_BANDED only: byte offset, inside the workspace, of the 32-bit status word the launch leaves behind
  * (0 = every inter-workgroup hand-off completed; non-zero = a bounded wait timed out and the outputs are invalid) */
 size_t mvsn_incremental_cost_volume_status_offset(int n_chains, int rows, int cols);
+/* MVSN_CHAIN_BANDED only: workgroups per chain of the plan a call with this many chains runs (16x32: 8 or 4 thin bands;
+ * 30x40 / 32x64: 15 / 16 thin bands, or 3 / 4 slabs with many chains in flight; 0: the grid has no banded plan) */
+int mvsn_incremental_cost_volume_banded_groups(int n_chains, int rows, int cols);
 int mvsn_incremental_cost_volume(const float *src_image_lvl4, const float *H_lvl4, const float *H_inc,
                                  const float *plane0_features, const float *left_features,
                                  const float *refiner_packed, int n_chains, int batch,

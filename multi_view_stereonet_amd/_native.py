@@ -56,6 +56,7 @@ SIGNATURES = {
     "mvsn_incremental_cost_volume_form_for": (c_int, [c_int] * 3),
     "mvsn_incremental_cost_volume_workspace_bytes_for": (c_size_t, [c_int] * 5),
     "mvsn_incremental_cost_volume_status_offset": (c_size_t, [c_int] * 3),
+    "mvsn_incremental_cost_volume_banded_groups": (c_int, [c_int] * 3),
     "mvsn_incremental_cost_volume": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 4 + [c_size_t, c_int, c_void_p]),
     "mvsn_incremental_cost_volume_repair_workspace_bytes": (c_size_t, [c_int] * 3),
     "mvsn_incremental_cost_volume_guarded": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 4 +

@@ -646,6 +646,10 @@ extern "C" size_t mvsn_incremental_cost_volume_status_offset(int n_chains, int r
   return n_chains > 0 ? mvsn::chain_band_status_offset(n_chains, rows, cols) : 0;
 }
 
+extern "C" int mvsn_incremental_cost_volume_banded_groups(int n_chains, int rows, int cols) {
+  return n_chains > 0 ? mvsn::chain_band_groups(n_chains, rows, cols) : 0;
+}
+
 extern "C" int mvsn_debug_set_band_flags(int flags) {
   mvsn::chain_band_debug_flags(flags);
   return 0;
