@@ -13,7 +13,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {   # timeline name -> (rocprof kernel-name fragments, algorithmic bytes per chain and launch, note)
     "mvsn_conv_forward[conv3d k3 32->32 wino]": (
-        ["conv_wino_kernel<0, 2, 3, 1, true, 0>", "conv_wino_kernel<1, 2, 3, 1, true, 0>"], 2 * 32 * 64 * 512 * 4,
+        ["conv_wino_kernel<0, 2, 3, 1, true, 0", "conv_wino_kernel<1, 2, 3, 1, true, 0"], 2 * 32 * 64 * 512 * 4,
         "volume Winograd kernel; tiles by 16-byte LDS-DMA: raw FETCH_SIZE doubled (gfx950 half-count); each input plane is "
         "fetched for three output planes, the re-fetches mostly L2 hits", True),
     "mvsn_incremental_cost_volume": (
