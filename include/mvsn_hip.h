@@ -108,7 +108,7 @@ int mvsn_homography_warp(const float *image, const float *H, int batch, int chan
                                  (batch 1: the reference's loop, test.py:38,197-200): the workgroups of a launch must be
                                  co-resident, so more chains than CUs / bands run as consecutive passes inside the call
                                  (AUTO: one pass on 16x32), and only ONE such call may be in flight per device.
-                                 30x40 / 32x64 beyond two passes of the thin bands (34 / 32 chains on 256 CUs): the SLAB
+                                 30x40 / 32x64 beyond one pass of the thin bands (17 / 16 chains on 256 CUs): the SLAB
                                  plan -- 3 bands of 10 rows / 4 bands of 8 rows per chain, each a 512-thread workgroup
                                  that keeps its band's activation planes resident in LDS like the plane-resident
                                  Winograd kernel (85 / 64 chains per pass, passes of equal size; four hand-offs per

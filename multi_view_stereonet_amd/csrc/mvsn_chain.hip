@@ -611,8 +611,8 @@ static int chain_auto_form(int n_chains, int rows, int cols) {
   // (16x32) only while all of them fit the chip at once; on the 30x40 / 32x64 grids also as two consecutive passes
   // (measured, MI355X: 32 chains 5.1 / 7.1 ms against the stepwise form's 7.3 / 10.4 ms; three passes tie with it)
   if (mvsn::chain_band_supported(rows, cols)) {
-    // 30x40 / 32x64 (no plane-resident plan): the banded form for any number of chains -- thin bands up to two passes,
-    // the slab plan (3 / 4 fat bands per chain resident in LDS, mvsn_chain_slab.hip) beyond; the stepwise form, which
+    // 30x40 / 32x64 (no plane-resident plan): the banded form for any number of chains -- thin bands while they fit one
+    // pass, the slab plan (3 / 4 fat bands per chain resident in LDS, mvsn_chain_slab.hip) beyond; the stepwise form, which
     // sends the plane through HBM every step, is no longer AUTO's choice there
     if (!mvsn::chain_wino_supported(rows, cols)) return MVSN_CHAIN_BANDED;
     const int cap = mvsn::chain_band_chains_per_pass(rows, cols);

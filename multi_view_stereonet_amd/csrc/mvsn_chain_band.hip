@@ -935,14 +935,15 @@ void chain_band_debug_flags(int flags) { g_band_debug_flags = flags; }
 // 16x32 has two plans: 8 bands of 2 rows (half split) while that many workgroups per chain fit the chip in one pass,
 // 4 bands of 4 rows beyond (bit-identical results: same arithmetic per output, same GroupNorm records in the same
 // order).  Debug flag bit 2 pins the 4-band plan (A/B, tests).
-// 30x40 / 32x64: the thin-band plan (15 / 16 workgroups per chain) while the chains fit two of its passes (AUTO's
-// small-batch form); beyond that the SLAB plan (mvsn_chain_slab.hip: 3 / 4 fat bands per chain, 85 / 64 chains per pass).
+// 30x40 / 32x64: the thin-band plan (15 / 16 workgroups per chain) while the chains fit ONE of its passes (17 / 16 chains
+// on 256 CUs: 2.4 / 4.0 ms per pass at D = 96 / 128); beyond that the SLAB plan (mvsn_chain_slab.hip: 3 / 4 fat bands
+// per chain, 85 / 64 chains per pass of 4.4 / 5.9 ms -- less than two thin passes).
 // Debug flag bit 4 (16) pins the slab plan (also on 16x32, where it exists for the tests only), bit 5 (32) the thin one.
 static bool band_plan(int rows, int cols, int n_chains, BandPlan *p) {
   const bool known = (rows == 16 && cols == 32) || (rows == 30 && cols == 40) || (rows == 32 && cols == 64);
   if (!known) return false;
   const int thin_g = rows == 16 ? Band16x32::G : (rows == 30 ? Band30x40::G : Band32x64::G);
-  const bool many = rows != 16 && n_chains > 2 * (device_cus() / thin_g);
+  const bool many = rows != 16 && n_chains > device_cus() / thin_g;
   if (((g_band_debug_flags & 16) || many) && !(g_band_debug_flags & 32)) {
     SlabPlan sp;
     if (chain_slab_plan(rows, cols, &sp)) {

@@ -1200,11 +1200,12 @@ def test_banded_chain_in_passes(grid, N, D):
     want = _native.CHAIN_BANDED if r4 != 16 else _native.CHAIN_WINOGRAD
     assert lib.mvsn_incremental_cost_volume_form_for(N, r4, c4) == want
     assert lib.mvsn_incremental_cost_volume_form_for(cap, r4, c4) == _native.CHAIN_BANDED
-    # beyond two thin-band passes: 16x32 has the plane-resident kernel; 30x40 / 32x64 stay banded (its slab plan takes over)
+    # beyond the thin-band pass: 16x32 has the plane-resident kernel; 30x40 / 32x64 stay banded (its slab plan takes over)
     assert lib.mvsn_incremental_cost_volume_form_for(2 * cap + 1, r4, c4) == (
         _native.CHAIN_BANDED if r4 != 16 else _native.CHAIN_WINOGRAD)
     net.options.chain_form = "banded"
     try:
+        eng.lib.mvsn_debug_set_band_flags(32)      # the thin-band plan pinned (30x40 / 32x64 would pick slabs beyond one pass)
         cost, mask, fvol = eng.incremental_cost_volume(*dev, want_features=True)
         torch.cuda.synchronize()
         assert eng.chain_status() == 0
@@ -1222,6 +1223,7 @@ def test_banded_chain_in_passes(grid, N, D):
             mean_rel, max_rel = rel_err(a.cpu(), b.cpu())
             assert mean_rel < 1e-5 and max_rel < 2e-4, (name, mean_rel, max_rel)
     finally:
+        eng.lib.mvsn_debug_set_band_flags(0)
         net.options.chain_form = "auto"
 
 
