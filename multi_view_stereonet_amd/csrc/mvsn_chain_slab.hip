@@ -39,6 +39,9 @@ namespace mvsn {
 constexpr int SB_THREADS = 512, SB_WAVES = 8;
 constexpr float SB_GN_EPS = 1e-5f;
 constexpr unsigned SB_SPIN_LIMIT = 1u << 21;
+#ifndef MVSN_SB_ABLATE   // tuning aid (wrong results): 1 no U DMA in the step loop, 2 no gather plan, 4 hand-off polls return at once
+#define MVSN_SB_ABLATE 0
+#endif
 constexpr int SB_USLOTS = 16;                  // half-k-step blocks of U resident in LDS (4 KB each)
 
 template <int ROWS, int COLS, int NB_, int CSA_>
@@ -111,6 +114,7 @@ __device__ __forceinline__ void sb_sweep(const gu64 *base, unsigned off, unsigne
   const unsigned voff = off * 8u;
   for (unsigned spins = 0;; ++spins) {
     bool ok = true;
+    if ((MVSN_SB_ABLATE & 4) && spins > 0) return;
     if (active) {
       u64 x[N];
       sb_issue<0, N, STRIDE>(base, voff, x);
@@ -284,7 +288,9 @@ __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int
   int lane16 = lane * 16;
   // a layer's first 16 half-k-step blocks -> slots 0..15; run i = (slot s = i >> 2, (cout tile, xi quad) r = i & 3) is the
   // 1 KB run ((c4 * 2 + ct) * 4 + half * 2 + xq) of the chain_wino layout; wave w takes runs w, w + 8, ...
+  bool dma_on = true;
   auto dma_u = [&](const float *src, int nc) {
+    if ((MVSN_SB_ABLATE & 1) && !dma_on) return;
     int l16 = lane16;
     asm volatile("" : "+v"(l16));   // (the eight 64-bit addresses of a call are formed here, not once per step for all three)
     for (int i = wave; i < SB_USLOTS * 4; i += SB_WAVES) {
@@ -486,6 +492,7 @@ __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int
   };
 
   // ---- the recurrence ------------------------------------------------------------------------
+  dma_on = false;
   for (int d = 1; d < D; ++d) {
     asm volatile("" : "+v"(tid), "+v"(lane16));
     const int lane_s = tid & 63;
@@ -788,7 +795,7 @@ __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int
     SB_STAMP(10);
     const float nm1 = exchange(1, GEO::E3, bias1, gn1w, gn1b, true, [&] {   // x2 = x1 + LReLU(GN(conv1(x1)))
       // the slow-path decision of the NEXT step (read by this step's epilogue and by the next step's gather)
-      if (d + 1 < D) plan_gather(d + 1);
+      if (d + 1 < D && !(MVSN_SB_ABLATE & 2)) plan_gather(d + 1);
     });
     SB_STAMP(11);
     dma_landed();
