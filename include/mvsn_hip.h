@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVSN_ABI_VERSION 3
+#define MVSN_ABI_VERSION 4
 
 #define MVSN_E_BADARG (-1)      /* null pointer, non-positive size, unsupported channel count */
 #define MVSN_E_TOOLARGE (-2)    /* shape exceeds what the kernel's LDS/global plan supports */
@@ -137,7 +137,7 @@ size_t mvsn_incremental_cost_volume_workspace_bytes_for(int n_chains, int num_id
 size_t mvsn_incremental_cost_volume_status_offset(int n_chains, int rows, int cols);
 /* MVSN_CHAIN_BANDED only: workgroups per chain of the plan a call with this many chains runs (16x32: 8 or 4 thin bands;
  * 30x40 / 32x64: 15 / 16 thin bands, or 3 / 4 slabs with many chains in flight; 0: the grid has no banded plan) */
-int mvsn_incremental_cost_volume_banded_groups(int n_chains, int rows, int cols);
+int mvsn_incremental_cost_volume_banded_groups(int n_chains, int rows, int cols);   /* (ABI 4) */
 int mvsn_incremental_cost_volume(const float *src_image_lvl4, const float *H_lvl4, const float *H_inc,
                                  const float *plane0_features, const float *left_features,
                                  const float *refiner_packed, int n_chains, int batch,

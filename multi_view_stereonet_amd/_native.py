@@ -38,7 +38,7 @@ class TowerDesc(Structure):
 
 CONV_FP32, CONV_BF16X3, CONV_FP32_WINO, CONV_BF16 = 0, 1, 2, 3
 CHAIN_AUTO, CHAIN_DIRECT, CHAIN_WINOGRAD, CHAIN_STEPWISE, CHAIN_BANDED = 0, 1, 2, 3, 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 # name -> (restype, argtypes); mirrors include/mvsn_hip.h one to one
