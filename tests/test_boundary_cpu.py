@@ -91,6 +91,32 @@ def test_conv_planning_is_host_side_and_validates():
     assert lib.mvsn_incremental_cost_volume_workspace_bytes(1, 32, 64) > 0        # config 5 grid
 
 
+def test_banded_plan_selection_host_logic():
+    """Which plan a banded call runs, and what it needs, from the host side alone (no device: the library assumes 256
+    CUs): thin bands while the chains fit one of their passes, slabs beyond (mvsn_chain_slab.hip); passes of equal size;
+    the status word behind the granules of the largest pass."""
+    lib = _native.load()
+    groups = lib.mvsn_incremental_cost_volume_banded_groups
+    assert [groups(n, 30, 40) for n in (1, 17, 18, 128, 1000)] == [15, 15, 3, 3, 3]
+    assert [groups(n, 32, 64) for n in (1, 16, 17, 64, 300)] == [16, 16, 4, 4, 4]
+    assert [groups(n, 16, 32) for n in (1, 32, 33, 64, 512)] == [8, 8, 4, 4, 4]       # 16x32: thin bands only
+    assert groups(4, 24, 40) == 0 and groups(0, 30, 40) == 0
+    form_for = lib.mvsn_incremental_cost_volume_form_for
+    assert all(form_for(n, r, c) == _native.CHAIN_BANDED for n in (1, 20, 128, 1000) for r, c in ((30, 40), (32, 64)))
+    assert form_for(64, 16, 32) == _native.CHAIN_BANDED and form_for(65, 16, 32) == _native.CHAIN_WINOGRAD
+    ws = lib.mvsn_incremental_cost_volume_workspace_bytes_for
+    off = lib.mvsn_incremental_cost_volume_status_offset
+    for (rows, cols) in ((30, 40), (32, 64)):
+        cap = 256 // groups(1000, rows, cols)
+        # one pass: the workspace grows with the chains; several passes: it is the largest pass's (equal sizes)
+        b18, b19 = ws(18, 96, rows, cols, _native.CHAIN_BANDED), ws(19, 96, rows, cols, _native.CHAIN_BANDED)
+        assert 0 < b18 < b19 and off(18, rows, cols) + 64 == b18
+        n = 2 * cap + 2                       # three passes of (n + 2) // 3 chains
+        per = -(-n // 3)
+        assert ws(n, 96, rows, cols, _native.CHAIN_BANDED) == ws(per, 96, rows, cols, _native.CHAIN_BANDED)
+        assert off(n, rows, cols) == off(per, rows, cols)
+
+
 def test_forward_refuses_cpu_tensors():
     net = MultiViewStereoNet()
     batch = synthetic.make_batch(64, 128, 1)
