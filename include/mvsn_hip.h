@@ -267,6 +267,15 @@ int mvsn_conv_forward_carry(const mvsn_conv_desc *desc, const float *in, const f
 /* partials (N,R,4,3) {count, mean, M2} per record and group (R = mvsn_conv_num_tiles records per sample, passed as
  * `tiles`) -> stats (N,4,2) = {mean, rstd}, eps 1e-5, biased variance; records are 48 bytes, 16-byte aligned */
 int mvsn_groupnorm_finalize(const float *partials, int n, int tiles, float *stats, mvsn_stream_t stream);
+/* The same statistics with a sample's records cut into up to 16 slices reduced by separate workgroups and added in slice
+ * order (ABI 4): for layers that leave MANY records per sample (more than 2048: a level-0 layer of a 1024x512 frame
+ * leaves 32768 = 1.5 MB) on FEW samples -- one workgroup per sample then reads megabytes alone.  The number of slices
+ * depends on `tiles` only (a sample's statistics do not depend on the batch it travels in; up to 2048 records it is 1 and
+ * the call IS mvsn_groupnorm_finalize).  Deterministic; equal to the one-workgroup result up to the rounding of the
+ * double-precision sums.  `workspace`: mvsn_groupnorm_finalize_split_workspace_bytes() bytes, 8-byte aligned. */
+size_t mvsn_groupnorm_finalize_split_workspace_bytes(int n, int tiles);
+int mvsn_groupnorm_finalize_split(const float *partials, int n, int tiles, float *stats, void *workspace,
+                                  size_t workspace_bytes, mvsn_stream_t stream);
 /* out = [residual +] LeakyReLU_0.2(GroupNorm(x)) on (N,32,spatial); residual may be NULL; out may alias x */
 int mvsn_groupnorm_lrelu_apply(const float *x, const float *stats, const float *gamma, const float *beta,
                                const float *residual, int n, long spatial, float *out, mvsn_stream_t stream);

@@ -70,6 +70,8 @@ SIGNATURES = {
     "mvsn_conv_forward_blocks": (c_int, [POINTER(ConvDesc), c_void_p, POINTER(c_int), c_int] + [c_void_p] * 4 + [c_void_p]),
     "mvsn_conv_forward_carry": (c_int, [POINTER(ConvDesc)] + [c_void_p] * 8 + [POINTER(ApplyJob), POINTER(c_int), c_void_p]),
     "mvsn_groupnorm_finalize": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "mvsn_groupnorm_finalize_split_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "mvsn_groupnorm_finalize_split": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mvsn_groupnorm_lrelu_apply": (c_int, [c_void_p] * 5 + [c_int, c_long, c_void_p, c_void_p]),
     "mvsn_groupnorm_lrelu_add2": (c_int, [c_void_p] * 8 + [c_int, c_long, c_void_p, c_void_p]),
     "mvsn_conv_to1_block": (c_int, [c_void_p] * 9 + [c_int] * 3 + [c_void_p, c_void_p]),

@@ -236,6 +236,57 @@ __device__ __forceinline__ void gn_finalize_block(const float *__restrict__ reco
   }
 }
 
+// First stage of a SPLIT finalize (mvsn_groupnorm_finalize_split: many records per sample, few samples -- one workgroup
+// per sample reads megabytes alone): the same accumulation over a slice of a sample's records, the three double sums per
+// group written out instead of finished.  out12 = [group][N, S, Q].
+__device__ __forceinline__ void gn_partial_block(const float *__restrict__ records, int tiles, double *out12) {
+  const int tid = threadIdx.x;
+  const floatx4 *p = reinterpret_cast<const floatx4 *>(records);
+  double acc[4][3];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) acc[g][0] = acc[g][1] = acc[g][2] = 0.0;
+  auto add = [&](const floatx4 &a, const floatx4 &b, const floatx4 &c) {
+    const float e[12] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3]};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const double cnt = (double)e[g * 3], mean = (double)e[g * 3 + 1];
+      acc[g][0] += cnt;
+      acc[g][1] += cnt * mean;
+      acc[g][2] += (double)e[g * 3 + 2] + cnt * mean * mean;
+    }
+  };
+  constexpr int GF_U = 8;
+  int t = tid;
+  for (; t + (GF_U - 1) * 256 < tiles; t += GF_U * 256) {
+    floatx4 r[GF_U][3];
+#pragma unroll
+    for (int u = 0; u < GF_U; ++u)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) r[u][k] = p[(size_t)(t + u * 256) * 3 + k];
+#pragma unroll
+    for (int u = 0; u < GF_U; ++u) add(r[u][0], r[u][1], r[u][2]);
+  }
+  for (; t < tiles; t += 256) add(p[(size_t)t * 3], p[(size_t)t * 3 + 1], p[(size_t)t * 3 + 2]);
+  __shared__ double gp_red[4][12];   // per wave
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      double v = acc[g][k];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      acc[g][k] = v;
+    }
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) gp_red[tid >> 6][g * 3 + k] = acc[g][k];
+  }
+  __syncthreads();
+  if (tid < 12) out12[tid] = gp_red[0][tid] + gp_red[1][tid] + gp_red[2][tid] + gp_red[3][tid];
+}
+
 // The statistics a consumer of sample n works with: `stats` is either the finalised (N,4,2) array (tiles == 0) or the
 // producer's records (N, tiles, 4, 3) -- then this workgroup (256 threads, all of them must call) forms them itself,
 // which saves the dependent mvsn_groupnorm_finalize launch in front of it (small batches: the launch costs more than

@@ -917,6 +917,35 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
   gn_finalize_block(partials + (size_t)n * tiles * 12, tiles, stats + (size_t)n * 8);
 }
 
+// Split finalize: slice k of sample n's records -> 12 double sums; then one thread per (sample, group) adds the K slices in
+// order.  (A level-0 layer of a 1024x512 frame leaves 32768 records = 1.5 MB per sample: one workgroup per sample read
+// them in ~45 us -- 14 such launches per batch-1 forward, and at 32 samples 32 of the 256 CUs were at work.)
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float *__restrict__ partials, int tiles, int per, int K,
+                                                         double *__restrict__ scratch) {
+  const int k = blockIdx.x, n = blockIdx.y;
+  const int lo = k * per, cnt = tiles - lo < per ? tiles - lo : per;
+  gn_partial_block(partials + ((size_t)n * tiles + lo) * 12, cnt, scratch + ((size_t)n * K + k) * 12);
+}
+__global__ __launch_bounds__(256) void gn_combine_kernel(const double *__restrict__ scratch, int n, int K,
+                                                         float *__restrict__ stats) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * 4) return;
+  const int s = t >> 2, g = t & 3;
+  double N = 0.0, S = 0.0, Q = 0.0;
+  for (int k = 0; k < K; ++k) {
+    const double *p = scratch + ((size_t)s * K + k) * 12 + g * 3;
+    N += p[0], S += p[1], Q += p[2];
+  }
+  const double mean = S / N;
+  double var = Q / N - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[(size_t)s * 8 + g * 2 + 0] = (float)mean;
+  stats[(size_t)s * 8 + g * 2 + 1] = (float)(1.0 / sqrt(var + (double)GN_FINALIZE_EPS));
+}
+// slices per sample: a function of the records per sample ALONE (a sample's statistics must not depend on the batch it
+// travels in); 1 up to 2048 records -- the range in which consumers may form the statistics themselves (gn_stats_here)
+static inline int gn_split_slices(int tiles) { return tiles <= 2048 ? 1 : (tiles + 2047) / 2048 < 16 ? (tiles + 2047) / 2048 : 16; }
+
 // out = [residual +] LeakyReLU(GroupNorm(x)), (N,32,spatial), float4 per thread.
 constexpr int GN_APPLY_MAX_N = 65535 / 32;   // samples per launch (grid.y = sample * 32 + channel)
 
@@ -1251,6 +1280,29 @@ extern "C" int mvsn_groupnorm_finalize(const float *partials, int n, int tiles, 
   MVSN_REQUIRE(partials && stats && n > 0 && tiles > 0, MVSN_E_BADARG, "mvsn_groupnorm_finalize: bad argument");
   hipLaunchKernelGGL(mvsn::gn_finalize_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, partials, tiles, stats);
   return mvsn::check_launch("mvsn_groupnorm_finalize");
+}
+
+extern "C" size_t mvsn_groupnorm_finalize_split_workspace_bytes(int n, int tiles) {
+  if (n <= 0 || tiles <= 0) return 0;
+  const int K = mvsn::gn_split_slices(tiles);
+  return K == 1 ? 0 : (size_t)n * K * 12 * sizeof(double);
+}
+
+extern "C" int mvsn_groupnorm_finalize_split(const float *partials, int n, int tiles, float *stats, void *workspace,
+                                             size_t workspace_bytes, mvsn_stream_t stream) {
+  MVSN_REQUIRE(partials && stats && n > 0 && tiles > 0, MVSN_E_BADARG, "mvsn_groupnorm_finalize_split: bad argument");
+  const int K = mvsn::gn_split_slices(tiles);
+  if (K == 1) return mvsn_groupnorm_finalize(partials, n, tiles, stats, stream);
+  const size_t need = mvsn_groupnorm_finalize_split_workspace_bytes(n, tiles);
+  MVSN_REQUIRE(workspace && workspace_bytes >= need && ((size_t)workspace & 7) == 0, MVSN_E_WORKSPACE,
+               "mvsn_groupnorm_finalize_split: 8-byte aligned workspace of %zu bytes required", need);
+  MVSN_REQUIRE(n <= 65535, MVSN_E_TOOLARGE, "mvsn_groupnorm_finalize_split: batch too large for one launch");
+  const int per = (tiles + K - 1) / K;
+  hipLaunchKernelGGL(mvsn::gn_partial_kernel, dim3(K, n), dim3(256), 0, (hipStream_t)stream, partials, tiles, per, K,
+                     (double *)workspace);
+  hipLaunchKernelGGL(mvsn::gn_combine_kernel, dim3((n * 4 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const double *)workspace, n, K, stats);
+  return mvsn::check_launch("mvsn_groupnorm_finalize_split");
 }
 
 // stat_tiles == 0: `stats` is the finalised (N,4,2) array; > 0: the producer's records (N, stat_tiles, 4, 3), finalised by

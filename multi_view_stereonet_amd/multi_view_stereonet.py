@@ -117,6 +117,9 @@ class EngineOptions:
         # the dependent 7 us finalize launch in front of it disappears.  Limits: samples per launch, records per sample.
         self.lazy_stats_max_samples = 8
         self.lazy_stats_max_records = 2048
+        # More than 2048 records per sample: the finalize launch reduces a sample's records in up to 16 slices
+        # (mvsn_groupnorm_finalize_split) instead of one workgroup per sample reading up to 1.5 MB alone.
+        self.split_finalize = True
         self.cat_free_heads = True         # refiner heads read [image, features, idepth] in place (no torch.cat)
         # The fused chain's three 3x3 convolutions: "auto" = one chain on SEVERAL workgroups ("banded") while few chains
         # are in flight (16x32: up to 64 chains, one pass; 30x40 / 32x64: up to two passes of 17 / 16 chains); otherwise
@@ -150,7 +153,7 @@ class EngineOptions:
         # trip.  The module then stops choosing the banded form (see MultiViewStereoNet.check_device_status).
         self.banded_repair = True
 
-    NAMES = ("banded_repair", "towers", "plan_max_chains", "plan_graph", "plan_max_bytes", "carry_passes", "carry_min_bytes", "carry_volume_passes", "carry_alternate", "chain_form", "fold_residual_blocks", "conv_precision", "winograd", "winograd_with_input_transform",
+    NAMES = ("split_finalize", "banded_repair", "towers", "plan_max_chains", "plan_graph", "plan_max_bytes", "carry_passes", "carry_min_bytes", "carry_volume_passes", "carry_alternate", "chain_form", "fold_residual_blocks", "conv_precision", "winograd", "winograd_with_input_transform",
              "winograd_volume", "winograd_stride2", "volume_materialise", "trim_tower_ends", "cat_free_heads", "lazy_stats_max_samples",
              "lazy_stats_max_records")
 
@@ -595,12 +598,26 @@ class PlaneSweepEngine:
             if lazy_stats and n <= self.lazy_stats_max_samples and partials.shape[1] <= self.lazy_stats_max_records:
                 stats = _Records(partials)
             else:
-                stats = self.empty((n, 4, 2), dtype=torch.float32, device=x.device)
-                self._call("mvsn_groupnorm_finalize", lib.mvsn_groupnorm_finalize, _native.ptr(partials), n,
-                           partials.shape[1], _native.ptr(stats), _native.stream())
+                stats = self.finalize_stats(partials)
         if write_staged:
             return out, stats, staged
         return out, stats
+
+    def finalize_stats(self, partials: torch.Tensor) -> torch.Tensor:
+        """GroupNorm records (N, R, 4, 3) -> (N, 4, 2) {mean, rstd}; many records per sample are reduced in slices
+        (mvsn_groupnorm_finalize_split: the slice count depends on R alone, so a sample's statistics do not depend on its
+        batch)."""
+        n, records = partials.shape[0], partials.shape[1]
+        stats = self.empty((n, 4, 2), dtype=torch.float32, device=partials.device)
+        ws_bytes = self.lib.mvsn_groupnorm_finalize_split_workspace_bytes(n, records) if self.split_finalize else 0
+        if ws_bytes:
+            ws = self.empty(ws_bytes, dtype=torch.uint8, device=partials.device)
+            self._call("mvsn_groupnorm_finalize", self.lib.mvsn_groupnorm_finalize_split, _native.ptr(partials), n, records,
+                       _native.ptr(stats), _native.ptr(ws), ws_bytes, _native.stream())
+        else:
+            self._call("mvsn_groupnorm_finalize", self.lib.mvsn_groupnorm_finalize, _native.ptr(partials), n, records,
+                       _native.ptr(stats), _native.stream())
+        return stats
 
     def conv_blocks(self, c: _Conv, blocks, want_stats=False, out: Optional[torch.Tensor] = None):
         """3x3 layer on the channel-wise concatenation of up to three tensors without assembling it
@@ -635,9 +652,7 @@ class PlaneSweepEngine:
                    nbytes=4.0 * (sum(b.numel() for b in blocks) + out.numel()))
         stats = None
         if want_stats:
-            stats = self.empty((n, 4, 2), dtype=torch.float32, device=x0.device)
-            self._call("mvsn_groupnorm_finalize", lib.mvsn_groupnorm_finalize, _native.ptr(partials), n,
-                       partials.shape[1], _native.ptr(stats), _native.stream())
+            stats = self.finalize_stats(partials)
         return out, stats
 
     def conv_to1(self, c: _Conv, x: torch.Tensor, prior: Optional[torch.Tensor] = None,

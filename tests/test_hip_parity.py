@@ -517,6 +517,44 @@ def test_statistics_formed_by_the_consumer_are_bit_identical():
         eng.timeline = None
 
 
+@pytest.mark.parametrize("n,records", [(1, 2049), (3, 8192), (1, 19200), (2, 32768), (5, 40001), (4, 2048)])
+def test_groupnorm_finalize_in_slices(n, records):
+    """mvsn_groupnorm_finalize_split (many records per sample: up to 16 workgroups per sample, their double sums added
+    in slice order) against the one-workgroup finalize and against the definition: equal to rounding, deterministic,
+    and independent of the batch a sample travels in (the slice count is a function of the record count alone)."""
+    lib = net_for("gta_sfm_150epochs").engine().lib
+    g = torch.Generator().manual_seed(records)
+    cnt = torch.randint(0, 3, (n, records, 4, 1), generator=g).float() * 64.0
+    mean = torch.randn(n, records, 4, 1, generator=g) * 0.5 + 0.3
+    m2 = torch.rand(n, records, 4, 1, generator=g) * cnt * 0.7
+    part = torch.cat([cnt, mean, m2], 3).contiguous().to(DEV)
+    one = torch.empty(n, 4, 2, device=DEV)
+    assert lib.mvsn_groupnorm_finalize(_native.ptr(part), n, records, _native.ptr(one), _native.stream()) == 0
+
+    def split(p):
+        k = p.shape[0]
+        out = torch.empty(k, 4, 2, device=DEV)
+        nb = lib.mvsn_groupnorm_finalize_split_workspace_bytes(k, records)
+        assert (nb == 0) == (records <= 2048)
+        ws = torch.empty(max(nb, 8), dtype=torch.uint8, device=DEV)
+        assert lib.mvsn_groupnorm_finalize_split(_native.ptr(p), k, records, _native.ptr(out), _native.ptr(ws), nb,
+                                                 _native.stream()) == 0, lib.mvsn_last_error()
+        return out
+    a, b = split(part), split(part)
+    assert torch.equal(a, b)
+    for i in range(n):
+        assert torch.equal(split(part[i:i + 1].contiguous())[0], a[i]), i
+    if records <= 2048:
+        assert torch.equal(a, one)
+    c, mu, q = cnt.double().squeeze(3), mean.double().squeeze(3), m2.double().squeeze(3)
+    N, S, Q = c.sum(1), (c * mu).sum(1), (q + c * mu * mu).sum(1)
+    ref_mean = S / N
+    ref_rstd = 1.0 / ((Q / N - ref_mean ** 2).clamp_min(0) + 1e-5).sqrt()
+    for got in (a, one):
+        close(got[:, :, 0], ref_mean, rtol=2e-6, atol=1e-7)
+        close(got[:, :, 1], ref_rstd, rtol=2e-6, atol=1e-7)
+
+
 def test_refiner_heads_without_concatenation_are_identical():
     """Refiner input handed to the head conv as [image, features, idepth] blocks vs. one torch.cat: bit-identical,
     for every refiner of the pretrained weights (the level-0 head has no feature block: 3 + 1 channels)."""
