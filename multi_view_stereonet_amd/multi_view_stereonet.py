@@ -121,11 +121,13 @@ class EngineOptions:
         # (mvsn_groupnorm_finalize_split) instead of one workgroup per sample reading up to 1.5 MB alone.
         self.split_finalize = True
         self.cat_free_heads = True         # refiner heads read [image, features, idepth] in place (no torch.cat)
-        # The fused chain's three 3x3 convolutions: "auto" = one chain on SEVERAL workgroups ("banded") while few chains
-        # are in flight (16x32: up to 64 chains, one pass; 30x40 / 32x64: up to two passes of 17 / 16 chains); otherwise
-        # Winograd F(2x2,3x3) with the plane resident in one CU where the coarse grid has such a plan (16x32 at 512x256
-        # frames), elsewhere one plane per round of full-chip launches ("stepwise"; cols % 4 == 0) or the fused direct
-        # implicit GEMM.  "direct" / "winograd" / "stepwise" / "banded" force one form.
+        # The fused chain's three 3x3 convolutions: "auto" = one chain on SEVERAL workgroups ("banded") -- on 16x32 while
+        # few chains are in flight (up to 64: one pass of thin bands), beyond that Winograd F(2x2,3x3) with the plane
+        # resident in one CU ("winograd"); on 30x40 / 32x64 (no plane fits a CU) at ANY chain count: thin bands up to
+        # 17 / 16 chains, the slab plan (3 / 4 LDS-resident fat bands per chain, 85 / 64 chains per pass) beyond.  Other
+        # grids: the fused direct implicit GEMM.  "direct" / "winograd" / "stepwise" / "banded" force one form
+        # ("stepwise" = one plane per round of full-chip launches, cols % 4 == 0: what the banded form falls back to
+        # when several stream lanes share the device).
         self.chain_form = "auto"
         # Refiner towers on two batch slices, software-pipelined: slice B's convolution (matrix-pipe-bound) carries
         # slice A's normalise/activate/add pass (HBM-bound) inside its own launch (mvsn_conv_forward_carry).  Used
