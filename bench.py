@@ -110,6 +110,7 @@ def l1_against(ref0, got0, golden=None):
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 dense peak
 PEAK_HBM_GBS = 8000.0
 PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"   # FETCH_SIZE / WRITE_SIZE passes of the bench command (tools/prof_round.sh)
+FEATURE_TIER_PMC_FILE = "r05_bf16_feature_tier_pmc.json"   # FETCH / WRITE of the regulariser's layers per tier (tools/vol_tiers.py)
 LEVEL_PMC_FILE = "r05_level_pmc.json"       # ... of the refiner towers level by level (tools/level_profile.py)
 
 
@@ -748,7 +749,11 @@ def main():
                      "3 x bf16 split (hi+lo operands, fp32 accumulate) on the 32->32 3x3 layers, f32 elsewhere"),
                     ("bf16", "bf16_operand_tier",
                      "bf16 operands, fp32 accumulate on the 32->32 3x3 layers (regulariser + refiner blocks), f32 "
-                     "elsewhere; NOT within the 1e-3 parity contract")):
+                     "elsewhere; NOT within the 1e-3 parity contract"),
+                    ("bf16s", "bf16_feature_tier",
+                     "bf16 FEATURES (BASELINE config 5): the bf16-operand tier + the regulariser's intermediate volumes "
+                     "STORED as bf16 (layer 0 fp32 -> bf16, layers 1-2 bf16 -> bf16, layer 3 bf16 -> fp32; fp32 "
+                     "accumulation and GroupNorm statistics); NOT within the 1e-3 parity contract")):
                 eng.conv_precision = tier
                 for _ in range(max(1, args.warmup)):
                     out_t = step()
@@ -768,6 +773,33 @@ def main():
                     "dominant_kernel": name_t, "dominant_kernel_ms": round(dom_t["ms"], 3),
                     "kernel_ms_per_step": {k: round(v["ms"], 3) for k, v in
                                            sorted(agg_t.items(), key=lambda kv: -kv[1]["ms"])[:6]}}
+            # the feature tier on the configuration BASELINE names it for: config 5's golden input at batch 1 (its error
+            # against the reference's own depth map) and at 32 images (its rate), beside the fp32 figures of other_configs
+            try:
+                c5 = CONFIGS["config5"]
+                eng.conv_precision = "bf16s"
+                _, inp5, ref5 = config_inputs(c5, 1, 0, dev)
+                out5 = run_forward(net, inp5, c5["D"])
+                entry = {"l1_vs_ref_config5": {k: v for k, v in l1_against(
+                    ref5, out5["left_idepthmap_pyr"][0][:1].cpu(), c5["golden"]).items() if k != "rel_definitions"}}
+                del inp5, out5
+                _, inp5, _ = config_inputs(c5, 32, 0, dev)
+                for _ in range(2):
+                    run_forward(net, inp5, c5["D"])
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    run_forward(net, inp5, c5["D"])
+                torch.cuda.synchronize()
+                entry["config5_B=32_depthmaps_per_s"] = round(32 * 3 / (time.perf_counter() - t1), 1)
+                pmc5 = load_profile_json(FEATURE_TIER_PMC_FILE)
+                if pmc5:
+                    entry["hbm_bytes_of_the_regulariser_layers"] = {k: v for k, v in pmc5.items() if not k.startswith("_l")}
+                line["bf16_feature_tier"].update(entry)
+                del inp5
+                torch.cuda.empty_cache()
+            except Exception as exc:   # noqa: BLE001
+                line["bf16_feature_tier"]["config5"] = {"error": f"{type(exc).__name__}: {exc}"}
             eng.conv_precision = "fp32"
         if not args.no_cpu_baseline:
             # rank 0's host cores, once per job whatever N is (a bounded sample: shorter beside a multi-GPU run,

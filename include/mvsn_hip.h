@@ -221,6 +221,17 @@ typedef struct {
 #define MVSN_CONV_FP32_WINO 2
 #define MVSN_CONV_BF16 3
 int mvsn_conv_bf16x3_supported(const mvsn_conv_desc *desc);
+/* bf16 STORAGE on top of MVSN_CONV_BF16 (ABI 4; BASELINE config 5's "bf16 features" for the 3x3x3 regulariser layers,
+ * multi_view_stereonet.py:341-353): `in` and / or `out` hold bf16 (same NCDHW element order, two bytes per element) instead
+ * of fp32 -- `in_is_bf16` / `out_is_bf16`, at least one set.  Products on the bf16 matrix cores with fp32 accumulation,
+ * the biased accumulators rounded to bf16 (RNE) by the storing epilogue; `out_partials` (GroupNorm records) and
+ * `in_stats` stay fp32 and are formed from the unrounded accumulators.  desc: kd = 3, precision MVSN_CONV_BF16;
+ * weight_packed as for MVSN_CONV_BF16.  A speed tier outside the 1e-3 parity contract (its own asserted budget:
+ * tests/test_hip_parity.py); never part of the default path. */
+int mvsn_conv_forward_bf16_storage(const mvsn_conv_desc *desc, const void *in, int in_is_bf16,
+                                   const float *weight_packed, const float *bias, const float *in_stats,
+                                   const float *in_gamma, const float *in_beta, void *out, int out_is_bf16,
+                                   float *out_partials, mvsn_stream_t stream);
 int mvsn_conv_winograd_supported(const mvsn_conv_desc *desc);
 
 size_t mvsn_conv_packed_floats(const mvsn_conv_desc *desc);

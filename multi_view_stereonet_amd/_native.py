@@ -62,6 +62,8 @@ SIGNATURES = {
     "mvsn_incremental_cost_volume_guarded": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 4 +
                                              [c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "mvsn_conv_bf16x3_supported": (c_int, [POINTER(ConvDesc)]),
+    "mvsn_conv_forward_bf16_storage": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_int, c_void_p, c_void_p]),
     "mvsn_conv_winograd_supported": (c_int, [POINTER(ConvDesc)]),
     "mvsn_conv_packed_floats": (c_size_t, [POINTER(ConvDesc)]),
     "mvsn_conv_pack_weights": (c_int, [POINTER(ConvDesc), c_void_p, c_void_p, c_void_p]),

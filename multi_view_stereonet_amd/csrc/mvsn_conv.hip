@@ -1050,6 +1050,25 @@ extern "C" int mvsn_conv_bf16x3_supported(const mvsn_conv_desc *desc) {
   return mvsn::bf16x3_geom(desc, &g) ? 1 : 0;
 }
 
+extern "C" int mvsn_conv_forward_bf16_storage(const mvsn_conv_desc *desc, const void *in, int in_is_bf16,
+                                              const float *weight_packed, const float *bias, const float *in_stats,
+                                              const float *in_gamma, const float *in_beta, void *out, int out_is_bf16,
+                                              float *out_partials, mvsn_stream_t stream) {
+  using namespace mvsn;
+  MVSN_REQUIRE(desc && in && weight_packed && out, MVSN_E_BADARG, "mvsn_conv_forward_bf16_storage: null pointer");
+  MVSN_REQUIRE(desc->precision == MVSN_CONV_BF16 && desc->kd == 3, MVSN_E_BADARG,
+               "mvsn_conv_forward_bf16_storage: 3x3x3 layers with desc.precision = MVSN_CONV_BF16");
+  Bf16x3Geom bg;
+  MVSN_REQUIRE(bf16x3_geom(desc, &bg), MVSN_E_BADARG, "mvsn_conv_forward_bf16_storage: layer has no bf16 form");
+  MVSN_REQUIRE(!in_stats || (in_gamma && in_beta), MVSN_E_BADARG, "mvsn_conv_forward_bf16_storage: input transform needs gamma/beta");
+  MVSN_REQUIRE(bg.n <= 65535, MVSN_E_TOOLARGE, "mvsn_conv_forward_bf16_storage: batch too large for one launch");
+  MVSN_REQUIRE(((size_t)in & 3) == 0 && ((size_t)out & 7) == 0, MVSN_E_BADARG, "mvsn_conv_forward_bf16_storage: alignment");
+  MVSN_REQUIRE(!in_is_bf16 || (desc->cols & 1) == 0, MVSN_E_BADARG,
+               "mvsn_conv_forward_bf16_storage: a bf16 input needs an even number of columns (aligned two-element loads)");
+  return bf16_storage_launch(bg, in, in_is_bf16 != 0, weight_packed, bias, in_stats, in_gamma, in_beta, out,
+                             out_is_bf16 != 0, out_partials, (hipStream_t)stream);
+}
+
 extern "C" int mvsn_conv_winograd_supported(const mvsn_conv_desc *desc) {
   mvsn::WinoGeom g;
   return mvsn::wino_geom(desc, &g) ? 1 : 0;

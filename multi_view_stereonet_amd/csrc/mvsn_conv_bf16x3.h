@@ -20,6 +20,9 @@ bool bf16x3_geom(const mvsn_conv_desc *d, Bf16x3Geom *g);
 int bf16x3_pack(const mvsn_conv_desc *d, const float *weight, void *packed, hipStream_t stream);
 int bf16x3_launch(const Bf16x3Geom &g, const float *in, const void *wpk, const float *bias, const float *in_stats,
                   const float *in_gamma, const float *in_beta, float *out, float *out_partials, hipStream_t stream);
+int bf16_storage_launch(const Bf16x3Geom &g, const void *in, bool in16, const void *wpk, const float *bias,
+                        const float *in_stats, const float *in_gamma, const float *in_beta, void *out, bool out16,
+                        float *out_partials, hipStream_t stream);
 int bf16_selftest(hipStream_t stream, int *dbad);
 
 }  // namespace mvsn

@@ -63,7 +63,11 @@ __global__ void conv_bf16x3_pack_kernel(const float *__restrict__ w, int ntaps, 
 // DIL  dilation as a compile-time constant: the tap offsets become ds_read immediates (no address VALU)
 // NPROD  3: a*b ~= ah*bh + ah*bl + al*bh (fp32-equivalent split); 1: ah*bh only = plain bf16 operands with fp32
 //        accumulation (MVSN_CONV_BF16: BASELINE config 5's speed tier, outside the 1e-3 parity contract)
-template <int KD, int TZO, int TY, int TPW, int NIT, int MODE, int DIL, int NPROD>
+// IN16 / OUT16  (bf16 STORAGE, mvsn_conv_forward_bf16_storage: BASELINE config 5's "bf16 features") the input / output
+//        tensor holds bf16 instead of fp32 -- the same element order, half the bytes: the fetch widens 2-byte loads (a bf16
+//        IS the hi operand, exactly), the epilogue rounds the biased fp32 accumulators to bf16 (RNE) as it stores them.
+//        The GroupNorm partials are formed from the unrounded accumulators, statistics stay fp32.  NPROD = 1 only.
+template <int KD, int TZO, int TY, int TPW, int NIT, int MODE, int DIL, int NPROD, bool IN16 = false, bool OUT16 = false>
 __global__ __launch_bounds__(BX_THREADS, 2) void conv_bf16x3_kernel(Bf16x3Geom g, const float *__restrict__ in,
                                                                     const uintx4 *__restrict__ wpk,
                                                                     const float *__restrict__ bias,
@@ -94,8 +98,11 @@ __global__ __launch_bounds__(BX_THREADS, 2) void conv_bf16x3_kernel(Bf16x3Geom g
   const int tw = wave & 1, half = wave >> 1;
   const int n = blockIdx.y;
   const size_t in_plane = (size_t)g.H * g.W, in_chan = (size_t)g.D * in_plane;
-  const float *inn = in + (size_t)n * 32 * in_chan;
+  static_assert(!(IN16 || OUT16) || NPROD == 1, "bf16 storage: plain bf16 operands");
+  const float *inn = in + (size_t)n * 32 * in_chan;                       // (fp32 storage)
   float *outn = out + (size_t)n * 32 * in_chan;
+  const unsigned short *inn16 = reinterpret_cast<const unsigned short *>(in) + (size_t)n * 32 * in_chan;   // (bf16 storage)
+  unsigned short *outn16 = reinterpret_cast<unsigned short *>(out) + (size_t)n * 32 * in_chan;
 
   if (MODE == 1 && tid < 32) {
     const int grp = tid >> 3;
@@ -145,25 +152,96 @@ __global__ __launch_bounds__(BX_THREADS, 2) void conv_bf16x3_kernel(Bf16x3Geom g
     igrp[k] = (short)grp;
   }
 
-  float raw[NIT][8];
+  // bf16 storage: an item is one ALIGNED 4-byte word of 8 channels = two x-adjacent positions per load (2-byte loads, one
+  // position each, made the bf16-input layer 1.7x slower than the fp32-input one, and 4-byte loads at odd element
+  // offsets 2.3x: sub-word and misaligned accesses are the slow path of the vector memory pipe).  The tile's columns
+  // start at the odd element x0 - DIL (DIL = 1, x0 a multiple of 32, W even), so word j of a row holds the positions
+  // ix = 2j - 1 and 2j: HX / 2 + 1 words per row, the first and the last contributing one position each.
+  constexpr int HXP = HX / 2 + 1, NPAIRS = HY * HXP * 4, NITP = (NPAIRS + BX_THREADS - 1) / BX_THREADS;
+  static_assert(!IN16 || (HX % 2 == 0 && DIL == 1), "aligned words of two positions");
+  int ppos[IN16 ? NITP : 1];      // record index of the word's SECOND position (ix = 2j); the first is the record before
+  short py[IN16 ? NITP : 1], px[IN16 ? NITP : 1], pgrp[IN16 ? NITP : 1];
+  if constexpr (IN16) {
+#pragma unroll
+    for (int k = 0; k < NITP; ++k) {
+      const int it = tid + k * BX_THREADS;
+      const int grp = it / (HY * HXP), pp = it - grp * (HY * HXP);
+      const int yy = pp / HXP, j = pp - yy * HXP;
+      ppos[k] = it < NPAIRS ? yy * HX + 2 * j : -1;
+      py[k] = (short)yy, px[k] = (short)(2 * j - 1), pgrp[k] = (short)grp;   // px: ix of the first position (-1 .. HX - 1)
+    }
+  }
+  unsigned rawp[IN16 ? NITP : 1][8];
+  float raw[IN16 ? 1 : NIT][8];
   unsigned okmask = 0;
   auto fetch = [&](int s) {
     int z0, y0, x0;
     origin(tile_of(s), z0, y0, x0);
     const int gz = KD == 3 ? z0 - 1 + s : 0;
     okmask = 0;
+    if constexpr (IN16) {
+#pragma unroll
+      for (int k = 0; k < NITP; ++k) {
+        const int gy = y0 - DIL + py[k], gx = x0 - DIL + px[k];   // gx even: the word (gx, gx + 1) is 4-byte aligned
+        const bool rowok = ppos[k] >= 0 && gy >= 0 && gy < g.H;
+        // a position counts if it belongs to the tile (ix in 0 .. HX - 1) and to the image
+        const bool ok0 = rowok && px[k] >= 0 && gx >= 0 && gx < g.W;
+        const bool ok1 = rowok && px[k] + 1 < HX && gx + 1 >= 0 && gx + 1 < g.W;
+        okmask |= ((ok0 ? 1u : 0u) | (ok1 ? 2u : 0u)) << (2 * k);
+        // (W even and gx even: when either position is inside the image, the whole word is)
+        const bool any = ok0 || ok1;
+        const unsigned int *src = reinterpret_cast<const unsigned int *>(
+            inn16 + (size_t)(pgrp[k] * 8) * in_chan + (size_t)gz * in_plane + (size_t)(any ? gy : 0) * g.W + (any ? gx : 0));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const unsigned w = any ? src[((size_t)e * in_chan) >> 1] : 0u;
+          rawp[k][e] = (ok0 ? w & 0xffffu : 0u) | (ok1 ? w & 0xffff0000u : 0u);
+        }
+      }
+    } else {
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       const int gy = y0 - DIL + iy[k], gx = x0 - DIL + ix[k];
       const bool ok = ipos[k] >= 0 && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W;
       if (ok) okmask |= 1u << k;
-      const float *src = inn + (size_t)(igrp[k] * 8) * in_chan + (size_t)gz * in_plane + (size_t)(ok ? gy : 0) * g.W +
-                         (ok ? gx : 0);
+      const size_t soff = (size_t)(igrp[k] * 8) * in_chan + (size_t)gz * in_plane + (size_t)(ok ? gy : 0) * g.W + (ok ? gx : 0);
+      if constexpr (!IN16) {
+        const float *src = inn + soff;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) raw[k][e] = ok ? src[(size_t)e * in_chan] : 0.0f;
+        for (int e = 0; e < 8; ++e) raw[k][e] = ok ? src[(size_t)e * in_chan] : 0.0f;
+      }
+    }
     }
   };
   auto commit = [&]() {
+    if constexpr (IN16) {
+#pragma unroll
+      for (int k = 0; k < NITP; ++k) {
+        if (ppos[k] < 0) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          uintx4 hi;
+          if (MODE == 1 && ((okmask >> (2 * k + h)) & 1u)) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float x = __uint_as_float(h ? rawp[k][e] & 0xffff0000u : rawp[k][e] << 16);
+              v[e] = lrelu02(x * scsh[pgrp[k] * 8 + e] + scsh[32 + pgrp[k] * 8 + e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hi[e] = pack_bf16_pair(v[2 * e], v[2 * e + 1]);
+          } else {   // the stored bf16 values ARE the operands
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              hi[e] = h ? (rawp[k][2 * e] >> 16) | (rawp[k][2 * e + 1] & 0xffff0000u)
+                        : (rawp[k][2 * e] & 0xffffu) | (rawp[k][2 * e + 1] << 16);
+          }
+          // (the word's first position is the record before ppos; the row's first / last word have only one in the tile)
+          if (h ? px[k] + 1 < HX : px[k] >= 0)
+            *reinterpret_cast<uintx4 *>(plane + (size_t)(ppos[k] - 1 + h) * BX_REC + pgrp[k] * 4) = hi;
+        }
+      }
+    } else {
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       if (ipos[k] < 0) continue;
@@ -184,6 +262,7 @@ __global__ __launch_bounds__(BX_THREADS, 2) void conv_bf16x3_kernel(Bf16x3Geom g
       unsigned int *rec = plane + (size_t)ipos[k] * BX_REC + igrp[k] * 4;
       *reinterpret_cast<uintx4 *>(rec) = hi;
       *reinterpret_cast<uintx4 *>(rec + 16) = lo;
+    }
     }
   };
 
@@ -227,7 +306,20 @@ __global__ __launch_bounds__(BX_THREADS, 2) void conv_bf16x3_kernel(Bf16x3Geom g
           acc[zo][j][r] = r < nv ? v : 0.0f;
           if (r < nv) s += v;
         }
-        if ((g.W & 3) == 0) {   // the four pixels are all inside or all outside, and 16-byte aligned
+        if constexpr (OUT16) {
+          if ((g.W & 3) == 0) {   // four pixels = 8 bytes, aligned
+            if (nv == 4) {
+              typedef unsigned int bx_u2 __attribute__((ext_vector_type(2)));
+              bx_u2 pk;
+              pk[0] = pack_bf16_pair(acc[zo][j][0], acc[zo][j][1]), pk[1] = pack_bf16_pair(acc[zo][j][2], acc[zo][j][3]);
+              *reinterpret_cast<bx_u2 *>(outn16 + (size_t)c * in_chan + pos) = pk;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (r < nv) outn16[(size_t)c * in_chan + pos + r] = (unsigned short)(pack_bf16_pair(acc[zo][j][r], 0.0f) & 0xffffu);
+          }
+        } else if ((g.W & 3) == 0) {   // the four pixels are all inside or all outside, and 16-byte aligned
           if (nv == 4) *reinterpret_cast<floatx4 *>(outn + (size_t)c * in_chan + pos) = acc[zo][j];
         } else {
 #pragma unroll
@@ -423,6 +515,36 @@ int bf16x3_pack(const mvsn_conv_desc *d, const float *weight, void *packed, hipS
 #ifdef MVSN_BX_STAMPS
 static unsigned long long *g_bx_stamps = nullptr;
 #endif
+
+// bf16 storage (volume form, plain bf16 operands): `in` / `out` hold bf16 where in16 / out16 say so
+int bf16_storage_launch(const Bf16x3Geom &g, const void *in, bool in16, const void *wpk, const float *bias,
+                        const float *in_stats, const float *in_gamma, const float *in_beta, void *out, bool out16,
+                        float *out_partials, hipStream_t stream) {
+  if (g.kd != 3 || g.nprod != 1 || !(in16 || out16)) {
+    set_error("mvsn_conv_forward_bf16_storage: 3x3x3 layers with plain bf16 operands and a bf16 input or output");
+    return MVSN_E_BADARG;
+  }
+  const bool xf = in_stats != nullptr;
+  const dim3 grid(g.tiles, g.n);
+#define MVSN_BS_LAUNCH(M, I, O)                                                                                     \
+  do {                                                                                                              \
+    auto kern = conv_bf16x3_kernel<3, 4, 4, 1, 4, M, 1, 1, I, O>;                                                   \
+    static LdsOptIn opt;                                                                                            \
+    if (int rc = ensure_lds(opt, (const void *)kern, g.lds_bytes, "mvsn_conv_forward_bf16_storage")) return rc;    \
+    hipLaunchKernelGGL(kern, grid, dim3(BX_THREADS), g.lds_bytes, stream, g, (const float *)in, (const uintx4 *)wpk, \
+                       bias, in_stats, in_gamma, in_beta, (float *)out, out_partials, (unsigned long long *)nullptr); \
+  } while (0)
+#define MVSN_BS_IO(M)                                        \
+  do {                                                       \
+    if (in16 && out16) MVSN_BS_LAUNCH(M, true, true);        \
+    else if (in16) MVSN_BS_LAUNCH(M, true, false);           \
+    else MVSN_BS_LAUNCH(M, false, true);                     \
+  } while (0)
+  if (xf) MVSN_BS_IO(1); else MVSN_BS_IO(0);
+#undef MVSN_BS_IO
+#undef MVSN_BS_LAUNCH
+  return check_launch("mvsn_conv_forward_bf16_storage");
+}
 
 int bf16x3_launch(const Bf16x3Geom &g, const float *in, const void *wpk, const float *bias, const float *in_stats,
                   const float *in_gamma, const float *in_beta, float *out, float *out_partials, hipStream_t stream) {

@@ -97,7 +97,10 @@ class EngineOptions:
         self.fold_residual_blocks = False
         # Arithmetic of the 32 -> 32 channel 3x3 / 3x3x3 layers: "fp32" = exact fp32 MFMA;
         # "bf16x3" = 3 x bf16 split on the bf16 matrix cores (fp32-equivalent to ~2^-16 per product);
-        # "bf16" = plain bf16 operands on the same kernels (BASELINE config 5's speed tier, outside the 1e-3 contract).
+        # "bf16" = plain bf16 operands on the same kernels (BASELINE config 5's speed tier, outside the 1e-3 contract);
+        # "bf16s" = the same plus bf16 STORAGE of the regulariser's intermediate volumes (config 5's "bf16 features":
+        # the first 3x3x3 layer reads the fp32 cost volume and writes bf16, the next two read and write bf16, the fourth
+        # writes fp32 for the 32 -> 1 tail; GroupNorm statistics stay fp32 -- mvsn_conv_forward_bf16_storage).
         self.conv_precision = "fp32"
         # Winograd F(2x2,3x3) form of the 2-D 3x3 dilation-1 layers (fp32 throughout, 2.25x fewer multiplies).
         self.winograd = True
@@ -539,7 +542,7 @@ class PlaneSweepEngine:
         # the other slice's pass beat bf16 kernels followed by a stand-alone pass (15.1 against 17.3 ms per step for
         # the refiner blocks).  Unsliced towers (small batches, small levels, odd shapes) and the extractor keep the
         # bf16 kernels; `bf16_layers` counts the launches that ran on them.
-        if self.conv_precision in ("bf16x3", "bf16") and c.packed_bx is not None and in_residual is None and \
+        if self.conv_precision in ("bf16x3", "bf16", "bf16s") and c.packed_bx is not None and in_residual is None and \
                 not write_staged and carry is None and not prefer_fp32_wino:
             dbx = c.desc(n, depth, rows, cols,
                          _native.CONV_BF16X3 if self.conv_precision == "bf16x3" else _native.CONV_BF16)
@@ -550,7 +553,7 @@ class PlaneSweepEngine:
                 (in_stats is None or self.winograd_with_input_transform) and \
                 (c.dims == 2 or self.winograd_volume) and \
                 (c.stride == 1 or (self.winograd_stride2 and in_stats is None and not want_stats and carry is None and
-                                   self.conv_precision != "bf16")):
+                                   self.conv_precision not in ("bf16", "bf16s"))):
             # (the plain-bf16 tier keeps the direct extractor its error budget was measured with: its per-pixel p99.9 on
             # config 5 sits at the budget -- 1.9e-2 / 2.1e-2 of 2e-2 with the direct / phase-Winograd extractor, whose
             # features differ by fp32 rounding only)
@@ -867,6 +870,10 @@ class PlaneSweepEngine:
                 self.conv_precision == "fp32" and to1 and n >= 2 and (depth * rows * cols) % 256 == 0 and
                 (n // 2) * 128 * depth * rows * cols >= self.carry_min_bytes):
             return self.cost_volume_filter_sliced(cost)
+        if self.conv_precision == "bf16s":
+            out = self.cost_volume_filter_bf16_storage(cost, to1)
+            if out is not None:
+                return out
         mat = self.volume_materialise and self.winograd and self.winograd_volume and self.conv_precision == "fp32"
         x, st = self.conv(self.vf_convs[0], cost, want_stats=True, lazy_stats=mat)
         for i in range(1, 4):
@@ -882,6 +889,36 @@ class PlaneSweepEngine:
             return self.conv_to1_volume_norm(last, x, st, self.vf_norms[3])
         out, _ = self.conv(last, x, in_stats=st, in_norm=self.vf_norms[3])
         return out[:, 0]
+
+    def cost_volume_filter_bf16_storage(self, cost: torch.Tensor, to1: bool) -> Optional[torch.Tensor]:
+        """The regulariser with its intermediate volumes stored as bf16 (`conv_precision = "bf16s"`, BASELINE config 5's
+        "bf16 features", reference: multi_view_stereonet.py:341-353): layer 0 fp32 -> bf16, layers 1, 2 bf16 -> bf16 with the
+        previous layer's LeakyReLU(GroupNorm(.)) applied on load, layer 3 bf16 -> fp32, then the usual 32 -> 1 tail.  21.5
+        instead of 34.4 bytes per voxel and channel move through HBM; statistics are fp32 from the unrounded accumulators.
+        None when a layer has no bf16 kernel for this shape (the caller falls back to the bf16-operand path)."""
+        n, _, depth, rows, cols = cost.shape
+        lib = self.lib
+        convs = self.vf_convs[:4]
+        d = convs[0].desc(n, depth, rows, cols, _native.CONV_BF16)
+        if any(c.packed_bx is None for c in convs) or not lib.mvsn_conv_bf16x3_supported(ctypes.byref(d)) or not to1:
+            return None
+        tiles = lib.mvsn_conv_num_tiles(ctypes.byref(d))
+        x, st = cost, None
+        for i, c in enumerate(convs):
+            out16 = i < 3
+            out = self.empty((n, 32, depth, rows, cols), dtype=torch.bfloat16 if out16 else torch.float32, device=cost.device)
+            partials = self.empty((n, tiles, 4, 3), dtype=torch.float32, device=cost.device)
+            nrm = self.vf_norms[i - 1] if i else None
+            self._call("mvsn_conv_forward[conv3d k3 32->32 bf16 storage]", lib.mvsn_conv_forward_bf16_storage, ctypes.byref(d),
+                       _native.ptr(x), 1 if i else 0, _native.ptr(c.packed_bx), _native.ptr(c.bias), _native.ptr(st),
+                       _native.ptr(nrm.gamma) if nrm else None, _native.ptr(nrm.beta) if nrm else None, _native.ptr(out),
+                       1 if out16 else 0, _native.ptr(partials), _native.stream(),
+                       flops=2.0 * 32 * 27 * 32 * out[:, 0].numel(),
+                       nbytes=float(x.numel() * x.element_size() + out.numel() * out.element_size()))
+            self.bf16_layers += 1
+            st = self.finalize_stats(partials)
+            x = out
+        return self.conv_to1_volume_norm(self.vf_convs[4], x, st, self.vf_norms[3])
 
     def conv_to1_volume_norm(self, last: _Conv, x, st, nrm: _Norm, out=None):
         """The HBM-bound 32 -> 1 pass; applies LReLU(GN(.)) of the fourth layer while it loads the raw volume."""

@@ -1700,6 +1700,103 @@ def test_forward_config5_bf16_operand_tier_reported():
     _check_mask4(name, out, fix)
 
 
+# ... and with bf16 STORAGE of the regulariser's intermediate volumes on top (config 5's "bf16 features", `bf16s`): its
+# own, wider budget -- every voxel of three of the four layers' outputs is rounded to 8 mantissa bits once more (measured on
+# config 5: mean-rel 8.7e-3, per-pixel p99.9 2.6e-2, max 3.1e-2; headline shapes: see the test's printout)
+BF16_FEATURE_TIER_BUDGET = {"mean_rel": 1.5e-2, "p999_rel_per_pixel": 4e-2, "max_rel_per_pixel": 8e-2}
+
+
+@pytest.mark.parametrize("name,wname", [("gc5_gta_1024x512_d128_s4.npz", "gta_sfm_150epochs"),
+                                        ("g2_gta_512x256_d64_s2.npz", "gta_sfm_150epochs")])
+def test_forward_bf16_feature_tier_reported(name, wname):
+    """BASELINE config 5's tier as written -- bf16 FEATURES: the regulariser's intermediate volumes stored as bf16
+    (`conv_precision = "bf16s"`: mvsn_conv_forward_bf16_storage; fp32 accumulation and GroupNorm statistics), on top of
+    the bf16-operand kernels.  Outside the 1e-3 contract like the operand tier: reported, bounded by its own budget;
+    the masks do not depend on the tier and stay bit-exact; the storage layers did run."""
+    fix = load_golden(name)
+    net = net_for(wname)
+    net.options.conv_precision = "bf16s"
+    try:
+        eng = net.engine()
+        eng.timeline = []
+        out = _forward(net, fix)
+        torch.cuda.synchronize()
+        ran = [t[0] for t in eng.timeline]
+        eng.timeline = None
+    finally:
+        net.options.conv_precision = "fp32"
+    S = int(fix["meta"][3])
+    assert sum("bf16 storage" in k for k in ran) == 4, ran[:40]          # (all S sources run as one batch of chains)
+    mean_rel, max_rel = rel_err(out["left_idepthmap_pyr"][0].cpu(), fix["idepth_0"])
+    mx, p999 = rel_err_per_pixel(out["left_idepthmap_pyr"][0].cpu(), fix["idepth_0"])
+    print(f"{name} [bf16 features, S={S}] level 0: mean-rel {mean_rel:.3e} max-rel {max_rel:.3e} per-pixel max {mx:.3e} "
+          f"p99.9 {p999:.3e} (the tier's own budget: {BF16_FEATURE_TIER_BUDGET})")
+    assert mean_rel < BF16_FEATURE_TIER_BUDGET["mean_rel"] and p999 < BF16_FEATURE_TIER_BUDGET["p999_rel_per_pixel"] and \
+        mx < BF16_FEATURE_TIER_BUDGET["max_rel_per_pixel"], (mean_rel, p999, mx)
+    _check_mask4(name, out, fix)
+
+
+@pytest.mark.parametrize("n,depth,rows,cols", [(2, 8, 16, 32), (1, 5, 9, 36), (3, 6, 30, 40), (1, 4, 17, 30)])
+def test_conv3d_bf16_storage_is_the_bf16_kernel_with_rounded_tensors(n, depth, rows, cols):
+    """mvsn_conv_forward_bf16_storage against the bf16-operand kernel it extends (MVSN_CONV_BF16, fp32 tensors), bit for
+    bit: a bf16 INPUT tensor gives what the fp32 kernel gives on the same values widened; a bf16 OUTPUT tensor is the
+    fp32 kernel's output rounded to nearest-even; the GroupNorm records are those of the unrounded accumulators; with
+    and without the previous layer's LeakyReLU(GroupNorm(.)) applied on load.  And against ATen on the rounded operands."""
+    from multi_view_stereonet_amd.multi_view_stereonet import _Conv
+    eng = net_for("gta_sfm_150epochs").engine()
+    lib = eng.lib
+    g = torch.Generator().manual_seed(depth * 31 + cols)
+    w = torch.randn(32, 32, 3, 3, 3, generator=g) * 0.06
+    b = torch.randn(32, generator=g) * 0.1
+    x = torch.randn(n, 32, depth, rows, cols, generator=g)
+    c = _Conv(lib, w.to(DEV), b.to(DEV))
+    assert c.packed_bx is not None
+    d = c.desc(n, depth, rows, cols, _native.CONV_BF16)
+    assert lib.mvsn_conv_bf16x3_supported(ctypes.byref(d))
+    tiles = lib.mvsn_conv_num_tiles(ctypes.byref(d))
+    x16 = x.to(DEV).to(torch.bfloat16).contiguous()
+    xw = x16.float().contiguous()                       # the same values, fp32 storage
+    gamma, beta = (torch.rand(32, generator=g) + 0.5).to(DEV), (torch.randn(32, generator=g) * 0.1).to(DEV)
+    xg = xw.reshape(n, 4, -1).double()
+    st = torch.stack([xg.mean(2), 1.0 / (xg.var(2, unbiased=False) + 1e-5).sqrt()], 2).float().contiguous()
+
+    def plain(inp, stats):
+        out = torch.empty(n, 32, depth, rows, cols, device=DEV)
+        part = torch.empty(n, tiles, 4, 3, device=DEV)
+        rc = lib.mvsn_conv_forward(ctypes.byref(d), _native.ptr(inp), _native.ptr(c.packed_bx), _native.ptr(c.bias),
+                                   _native.ptr(stats), _native.ptr(gamma) if stats is not None else None,
+                                   _native.ptr(beta) if stats is not None else None, None, None, _native.ptr(out),
+                                   _native.ptr(part), _native.stream())
+        assert rc == 0, lib.mvsn_last_error()
+        return out, part
+
+    def storage(inp, in16, out16, stats):
+        out = torch.empty(n, 32, depth, rows, cols, device=DEV, dtype=torch.bfloat16 if out16 else torch.float32)
+        part = torch.empty(n, tiles, 4, 3, device=DEV)
+        rc = lib.mvsn_conv_forward_bf16_storage(ctypes.byref(d), _native.ptr(inp), int(in16), _native.ptr(c.packed_bx),
+                                                _native.ptr(c.bias), _native.ptr(stats),
+                                                _native.ptr(gamma) if stats is not None else None,
+                                                _native.ptr(beta) if stats is not None else None, _native.ptr(out),
+                                                int(out16), _native.ptr(part), _native.stream())
+        assert rc == 0, lib.mvsn_last_error()
+        return out, part
+
+    for stats in (None, st):
+        ref, ref_part = plain(xw, stats)
+        for in16, out16 in ((False, True), (True, True), (True, False)):
+            got, part = storage(x16 if in16 else xw, in16, out16, stats)
+            want = ref.to(torch.bfloat16) if out16 else ref
+            assert torch.equal(got, want), (in16, out16, stats is not None, float((got.float() - want.float()).abs().max()))
+            assert torch.equal(part, ref_part), (in16, out16)
+    a = xw.cpu()
+    aten = F.conv3d(a.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), b, padding=1)
+    close(plain(xw, None)[0], aten, rtol=2e-3, atol=2e-3)
+    # rejected: neither tensor bf16; a 2-D layer
+    rc = lib.mvsn_conv_forward_bf16_storage(ctypes.byref(d), _native.ptr(xw), 0, _native.ptr(c.packed_bx), _native.ptr(c.bias),
+                                            None, None, None, _native.ptr(ref), 0, None, _native.stream())
+    assert rc != 0
+
+
 def test_forward_flag_variants_golden():
     fix = load_golden("g6_flags_128x64.npz")
     net = net_for("gta_sfm_150epochs")

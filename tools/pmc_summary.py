@@ -9,7 +9,7 @@ calls = defaultdict(set)
 for path in sys.argv[1:]:
     with open(path) as f:
         for row in csv.DictReader(f):
-            k = row["Kernel_Name"].split("(")[0][:60]
+            k = row["Kernel_Name"].split("(")[0][:100]
             agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
             calls[k].add(row["Dispatch_Id"])
 names = sorted({c for v in agg.values() for c in v})
