@@ -111,7 +111,8 @@ int mvsn_homography_warp(const float *image, const float *H, int batch, int chan
                                  30x40 / 32x64 beyond one pass of the thin bands (17 / 16 chains on 256 CUs): the SLAB
                                  plan -- 3 bands of 10 rows / 4 bands of 8 rows per chain, each a 512-thread workgroup
                                  that keeps its band's activation planes resident in LDS like the plane-resident
-                                 Winograd kernel (85 / 64 chains per pass, passes of equal size; four hand-offs per
+                                 Winograd kernel (85 / 64 chains per pass; passes of equal size, or full passes + ONE
+                                 thin-band pass for a remainder of at most 17 / 16 chains; four hand-offs per
                                  step; mvsn_incremental_cost_volume_banded_groups tells which plan a call runs).
                                  Needs workspace (..._workspace_bytes_for); the word at
                                  mvsn_incremental_cost_volume_status_offset() inside it is 0 after a clean run. */

@@ -978,22 +978,48 @@ int chain_band_chains_per_pass(int rows, int cols) {
   return 0;
 }
 
-// chains of the largest pass (= of the first one: the passes are of equal size up to the last)
-static int band_ws_chains(const BandPlan &p, int n_chains) {
-  const int cap = device_cus() / p.G;
-  if (cap < 1 || n_chains <= cap) return n_chains;
-  const int passes = (n_chains + cap - 1) / cap;
-  return (n_chains + passes - 1) / passes;
+// How a call's chains are dealt to passes.  Every workgroup of a pass must be co-resident (one per CU): `per` chains per
+// pass of the main plan, equal passes -- 85 + 85 + 85 + 1 chains would cost a whole pass for the last one.  Exception
+// (slab plans): a remainder small enough for ONE pass of the thin-band plan (256 chains on 30x40: 3 x 85 slabs + 1 chain
+// on 15 thin bands, 13.1 + 2.5 ms, against 4 passes of 64 = 17.5 ms) runs as that thin pass behind the full slab passes.
+// The thin pass's granules lie at the END of the main plan's workspace, so that both plans find the status block at
+// workspace + ws_chains * CHAIN_U64 (their own ws_chains, their own CHAIN_U64).  Debug flag 16 (slab pinned) keeps the
+// equal passes (A/B, tests).
+struct BandSchedule {
+  BandPlan main, tail;
+  int per, n_main, n_tail;       // chains per main pass; chains of the main passes / of the thin tail pass
+  size_t status_u64, tail_u64;   // offset of the status block / of the tail pass's granules (u64 units)
+};
+
+static bool band_schedule(int rows, int cols, int n_chains, BandSchedule *s) {
+  if (!band_plan(rows, cols, n_chains, &s->main)) return false;
+  const int cap = device_cus() / s->main.G;
+  s->n_main = n_chains, s->n_tail = 0, s->per = n_chains, s->tail_u64 = 0;
+  if (cap >= 1 && n_chains > cap) {
+    const int passes = (n_chains + cap - 1) / cap;
+    s->per = (n_chains + passes - 1) / passes;
+    const int thin_g = rows == 16 ? 0 : (rows == 30 ? Band30x40::G : Band32x64::G);
+    const int rem = n_chains % cap;
+    if (thin_g && s->main.G < thin_g && !(g_band_debug_flags & 16) && rem > 0 && rem <= device_cus() / thin_g) {
+      const BandPlan thin = rows == 30 ? band_plan_of<Band30x40>(1) : band_plan_of<Band32x64>(2);
+      const size_t main_u64 = (size_t)cap * s->main.chain_u64, tail_need = (size_t)rem * thin.chain_u64;
+      if (tail_need <= main_u64 && ((main_u64 - tail_need) & 1) == 0) {   // (16-byte publishes: an even u64 offset)
+        s->tail = thin, s->per = cap, s->n_main = n_chains - rem, s->n_tail = rem, s->tail_u64 = main_u64 - tail_need;
+      }
+    }
+  }
+  s->status_u64 = (size_t)s->per * s->main.chain_u64;
+  return true;
 }
 
 size_t chain_band_workspace_bytes(int n_chains, int rows, int cols) {
-  BandPlan p;
-  return band_plan(rows, cols, n_chains, &p) ? ((size_t)band_ws_chains(p, n_chains) * p.chain_u64 + 8) * sizeof(u64) : 0;
+  BandSchedule s;
+  return band_schedule(rows, cols, n_chains, &s) ? (s.status_u64 + 8) * sizeof(u64) : 0;
 }
 
 size_t chain_band_status_offset(int n_chains, int rows, int cols) {
-  BandPlan p;
-  return band_plan(rows, cols, n_chains, &p) ? (size_t)band_ws_chains(p, n_chains) * p.chain_u64 * sizeof(u64) : 0;
+  BandSchedule s;
+  return band_schedule(rows, cols, n_chains, &s) ? s.status_u64 * sizeof(u64) : 0;
 }
 
 // status word behind the granules: 0 = every hand-off completed; otherwise the code of the hand-off that timed out.
@@ -1002,38 +1028,41 @@ size_t chain_band_status_offset(int n_chains, int rows, int cols) {
 int chain_band_launch(const ChainArgs &a, int n_chains, void *workspace, size_t workspace_bytes, int flags,
                       hipStream_t stream) {
   flags |= g_band_debug_flags;
-  BandPlan p;
-  MVSN_REQUIRE(band_plan(a.rows, a.cols, n_chains, &p), MVSN_E_TOOLARGE,
+  BandSchedule s;
+  MVSN_REQUIRE(band_schedule(a.rows, a.cols, n_chains, &s), MVSN_E_TOOLARGE,
                "mvsn_incremental_cost_volume(banded): no plan for a %dx%d coarse grid", a.rows, a.cols);
-  const size_t need = chain_band_workspace_bytes(n_chains, a.rows, a.cols);
+  const size_t need = (s.status_u64 + 8) * sizeof(u64);
   MVSN_REQUIRE(workspace && workspace_bytes >= need, MVSN_E_WORKSPACE,
                "mvsn_incremental_cost_volume(banded): workspace of %zu bytes required", need);
-  const int cap = device_cus() / p.G, wsn = band_ws_chains(p, n_chains);
-  MVSN_REQUIRE(cap >= 1, MVSN_E_TOOLARGE, "mvsn_incremental_cost_volume(banded): %d bands exceed the %d CUs", p.G,
-               device_cus());
+  MVSN_REQUIRE(device_cus() / s.main.G >= 1, MVSN_E_TOOLARGE,
+               "mvsn_incremental_cost_volume(banded): %d bands exceed the %d CUs", s.main.G, device_cus());
   static LdsOptIn opt[7];
-  if (int rc = ensure_lds(opt[p.slot], (const void *)p.kernel, p.lds_bytes, "mvsn_incremental_cost_volume(banded)")) return rc;
-  // passes of equal size (85 + 85 + 85 + 1 chains would cost a whole pass for the last one)
-  const int passes = (n_chains + cap - 1) / cap, per = (n_chains + passes - 1) / passes;
-  for (int n0 = 0; n0 < n_chains; n0 += per) {
-    const int nn = n_chains - n0 < per ? n_chains - n0 : per;
+  auto run_pass = [&](const BandPlan &p, int n0, int nn, u64 *ws, int ws_chains, bool with_status) -> int {
+    if (int rc = ensure_lds(opt[p.slot], (const void *)p.kernel, p.lds_bytes, "mvsn_incremental_cost_volume(banded)")) return rc;
     // every polled word starts from tag 0 (no step carries it): zeroed ahead of each pass -- with the first pass (which
-    // fills the workspace: nn == wsn) also the status block behind the granules, so that a later pass keeps what an
-    // earlier one reported
-    const size_t words = (size_t)nn * p.chain_u64 + (n0 == 0 ? 8 : 0);
+    // fills the workspace) also the status block behind the granules, so that a later pass keeps what an earlier one
+    // reported
+    const size_t words = (size_t)nn * p.chain_u64 + (with_status ? 8 : 0);
     const unsigned blocks = (unsigned)((words + 1023) / 1024 < 1024 ? (words + 1023) / 1024 : 1024);
-    hipLaunchKernelGGL(band_zero_kernel, dim3(blocks), dim3(256), 0, stream, (u64 *)workspace, words);
+    hipLaunchKernelGGL(band_zero_kernel, dim3(blocks), dim3(256), 0, stream, ws, words);
     ChainArgs b = a;
-    b.workspace = (float *)workspace;
+    b.workspace = (float *)ws;
     b.chain0 = n0;
-    b.ws_chains = wsn;
+    b.ws_chains = ws_chains;
 #ifdef MVSN_BAND_HIDE_PTRS   // A/B aid (see MVSN_VIS10): the buffers reach the kernel through the by-value struct only
     const ChainArgs hidden{};
     hipLaunchKernelGGL(p.kernel, dim3(nn * p.G), dim3(p.threads), p.lds_bytes, stream, b, flags, CHAIN_VISIBLE(hidden));
 #else
     hipLaunchKernelGGL(p.kernel, dim3(nn * p.G), dim3(p.threads), p.lds_bytes, stream, b, flags, CHAIN_VISIBLE(b));
 #endif
+    return 0;
+  };
+  for (int n0 = 0; n0 < s.n_main; n0 += s.per) {
+    const int nn = s.n_main - n0 < s.per ? s.n_main - n0 : s.per;   // (the first pass fills the workspace: nn == per)
+    if (int rc = run_pass(s.main, n0, nn, (u64 *)workspace, s.per, n0 == 0)) return rc;
   }
+  if (s.n_tail)
+    if (int rc = run_pass(s.tail, s.n_main, s.n_tail, (u64 *)workspace + s.tail_u64, s.n_tail, false)) return rc;
   return check_launch("mvsn_incremental_cost_volume(banded)");
 }
 

@@ -93,7 +93,8 @@ def test_conv_planning_is_host_side_and_validates():
 
 def test_banded_plan_selection_host_logic():
     """Which plan a banded call runs, and what it needs, from the host side alone (no device: the library assumes 256
-    CUs): thin bands while the chains fit one of their passes, slabs beyond (mvsn_chain_slab.hip); passes of equal size;
+    CUs): thin bands while the chains fit one of their passes, slabs beyond (mvsn_chain_slab.hip); passes of equal size, or
+    full slab passes + one thin pass for a small remainder;
     the status word behind the granules of the largest pass."""
     lib = _native.load()
     groups = lib.mvsn_incremental_cost_volume_banded_groups
@@ -111,10 +112,15 @@ def test_banded_plan_selection_host_logic():
         # one pass: the workspace grows with the chains; several passes: it is the largest pass's (equal sizes)
         b18, b19 = ws(18, 96, rows, cols, _native.CHAIN_BANDED), ws(19, 96, rows, cols, _native.CHAIN_BANDED)
         assert 0 < b18 < b19 and off(18, rows, cols) + 64 == b18
-        n = 2 * cap + 2                       # three passes of (n + 2) // 3 chains
+        n = 2 * cap + 40                      # three passes of (n + 2) // 3 chains
         per = -(-n // 3)
         assert ws(n, 96, rows, cols, _native.CHAIN_BANDED) == ws(per, 96, rows, cols, _native.CHAIN_BANDED)
         assert off(n, rows, cols) == off(per, rows, cols)
+        # a remainder that fits ONE thin-band pass: full slab passes + that thin pass, its granules inside the slab
+        # passes' workspace (status block where a full pass has it)
+        n = 2 * cap + 2
+        assert ws(n, 96, rows, cols, _native.CHAIN_BANDED) == ws(cap, 96, rows, cols, _native.CHAIN_BANDED)
+        assert off(n, rows, cols) == off(cap, rows, cols) and groups(n, rows, cols) == groups(1000, rows, cols)
 
 
 def test_forward_refuses_cpu_tensors():

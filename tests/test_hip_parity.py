@@ -1003,15 +1003,22 @@ def test_slab_chain_selected_for_many_chains_and_in_passes(grid, N, D):
     cost, mask, fvol = eng.incremental_cost_volume(*dev, want_features=True)
     torch.cuda.synchronize()
     assert eng.last_chain_form == _native.CHAIN_BANDED and eng.chain_status() == 0
+    # (a remainder of at most one thin-band pass behind full slab passes runs as that thin pass: 90 = 85 + 5 on 30x40)
+    cap = 256 // eng.lib.mvsn_incremental_cost_volume_banded_groups(1000, r4, c4)
+    thin_cap = 256 // eng.lib.mvsn_incremental_cost_volume_banded_groups(1, r4, c4)
+    n_slab = N - N % cap if N > cap and 0 < N % cap <= thin_cap else N
     try:
         net.options.chain_form = "banded"
-        eng.lib.mvsn_debug_set_band_flags(SLAB)
         for a in range(0, N, 7):
-            sl = slice(a, min(a + 3, N))
-            c1, m1, f1 = eng.incremental_cost_volume(*[x[sl].contiguous() for x in dev], want_features=True)
-            torch.cuda.synchronize()
-            assert eng.chain_status() == 0
-            assert torch.equal(c1, cost[sl]) and torch.equal(m1, mask[sl]) and torch.equal(f1, fvol[sl]), a
+            for lo, hi, flag in ((a, min(a + 3, n_slab), SLAB), (max(a, n_slab), min(a + 3, N), 32)):
+                if lo >= hi:
+                    continue
+                eng.lib.mvsn_debug_set_band_flags(flag)
+                sl = slice(lo, hi)
+                c1, m1, f1 = eng.incremental_cost_volume(*[x[sl].contiguous() for x in dev], want_features=True)
+                torch.cuda.synchronize()
+                assert eng.chain_status() == 0
+                assert torch.equal(c1, cost[sl]) and torch.equal(m1, mask[sl]) and torch.equal(f1, fvol[sl]), (lo, hi)
     finally:
         eng.lib.mvsn_debug_set_band_flags(0)
         net.options.chain_form = "auto"
@@ -1262,6 +1269,48 @@ def test_banded_chain_in_passes(grid, N, D):
             assert mean_rel < 1e-5 and max_rel < 2e-4, (name, mean_rel, max_rel)
     finally:
         eng.lib.mvsn_debug_set_band_flags(0)
+        net.options.chain_form = "auto"
+
+
+@pytest.mark.parametrize("grid,extra,D", [((30, 40), 1, 3), ((30, 40), 17, 2), ((32, 64), 2, 3)])
+def test_banded_chain_slab_passes_with_thin_tail(grid, extra, D):
+    """A call of k x (chains per slab pass) + a few chains runs full slab passes and ONE thin-band pass for the remainder
+    (256 chains on 30x40: 85 + 85 + 85 on 3 slabs each, 1 on 15 thin bands) over one workspace with one status block.
+    The slab chains must equal a call of their own (slab plan, one pass), the remainder a call of its own (thin plan),
+    word for word; status 0; the call as a whole agrees with another form."""
+    net = net_for("gta_sfm_150epochs")
+    eng = net.engine()
+    lib = eng.lib
+    r4, c4 = grid
+    cap = 256 // lib.mvsn_incremental_cost_volume_banded_groups(1000, r4, c4)
+    N, B = cap + extra, 5
+    assert lib.mvsn_incremental_cost_volume_status_offset(N, r4, c4) == lib.mvsn_incremental_cost_volume_status_offset(cap, r4, c4)
+    g = torch.Generator().manual_seed(31)
+    H, Hinc = _motion_family(N, D, "mixed", seed=8)
+    src4 = torch.rand(N, 3, r4, c4, generator=g) * 2 - 1
+    F0, FL = torch.randn(N, 32, r4, c4, generator=g), torch.randn(B, 32, r4, c4, generator=g)
+    dev = [x.to(DEV) for x in (src4, H, Hinc, F0, FL)]
+    net.options.chain_form = "banded"
+    try:
+        cost, mask, fvol = eng.incremental_cost_volume(*dev, want_features=True)
+        torch.cuda.synchronize()
+        assert eng.chain_status() == 0
+        c1, m1, f1 = eng.incremental_cost_volume(dev[0][:cap], dev[1][:cap], dev[2][:cap], dev[3][:cap], dev[4],
+                                                 want_features=True)
+        assert eng.chain_status() == 0
+        assert torch.equal(cost[:cap], c1) and torch.equal(mask[:cap], m1) and torch.equal(fvol[:cap], f1)
+        idx = torch.tensor([n % B for n in range(cap, N)])
+        c2, m2, f2 = eng.incremental_cost_volume(dev[0][cap:], dev[1][cap:], dev[2][cap:], dev[3][cap:],
+                                                 FL[idx].to(DEV), want_features=True)
+        assert eng.chain_status() == 0
+        assert torch.equal(cost[cap:], c2) and torch.equal(mask[cap:], m2) and torch.equal(fvol[cap:], f2)
+        net.options.chain_form = "stepwise"
+        c3, m3, f3 = eng.incremental_cost_volume(*dev, want_features=True)
+        assert torch.equal(mask, m3)
+        for name, a, b in (("features", fvol, f3), ("cost", cost, c3)):
+            mean_rel, max_rel = rel_err(a.cpu(), b.cpu())
+            assert mean_rel < 1e-5 and max_rel < 2e-4, (name, mean_rel, max_rel)
+    finally:
         net.options.chain_form = "auto"
 
 

@@ -20,12 +20,17 @@ for N in [int(a) for a in sys.argv[1:]] or [2, 256]:
     Hinc = torch.eye(3).repeat(N, D, 1, 1); Hinc[:, 1:, 0, 2] = 12.0 / (D - 1)
     F0 = torch.randn(N, 32, rows, cols, generator=g).cuda(); FL = torch.randn(B, 32, rows, cols, generator=g).cuda()
     H, Hinc = H.cuda(), Hinc.cuda()
-    for form in ("direct", "winograd", "stepwise", "banded", "banded4", "slab", "banded-x"):
+    for form in ("direct", "winograd", "stepwise", "banded", "banded4", "slab", "banded-auto", "banded-x"):
         if form == "banded-x":        # banded with MVSN_BAND_FLAGS (A/B switches of the kernel, e.g. 8 = no pre-spin)
             if "MVSN_BAND_FLAGS" not in os.environ:
                 continue
             eng.lib.mvsn_debug_set_band_flags(int(os.environ["MVSN_BAND_FLAGS"]))
             form, tag = "banded", "banded-x"
+        elif form == "banded-auto":     # the banded form's own choice (thin bands / slabs / slab passes + a thin tail pass)
+            if (rows, cols) == (16, 32):
+                continue
+            eng.lib.mvsn_debug_set_band_flags(0)
+            form, tag = "banded", "banded-auto"
         elif form == "slab":            # the slab plan of the banded form pinned (debug flag 16): few fat bands per chain
             eng.lib.mvsn_debug_set_band_flags(16)
             form, tag = "banded", "slab"
@@ -59,5 +64,5 @@ for N in [int(a) for a in sys.argv[1:]] or [2, 256]:
         nbytes = N * (4.0 * 67 * P + 128.0 * D * P + D * P)
         status = eng.chain_status()
         eng.lib.mvsn_debug_set_band_flags(0)
-        print(f"N={N:4d} {tag:8s}: {ms:7.3f} ms/launch  {ms * 1e3 / (D - 1):6.1f} us/step  "
+        print(f"N={N:4d} {tag:11s}: {ms:7.3f} ms/launch  {ms * 1e3 / (D - 1):6.1f} us/step  "
               f"{flops / ms / 1e9:6.1f} direct-form TFLOP/s  {nbytes / ms / 1e6:7.1f} GB/s algorithmic  status {status}")
