@@ -20,4 +20,5 @@ MVSN_GRID=30,40,96 python tools/chain_bench.py 128 256 > $OUT/chain_bench_30x40.
 MVSN_GRID=32,64,128 python tools/chain_bench.py 128 256 > $OUT/chain_bench_32x64.txt 2>&1
 python tools/chain_bench.py 256 512 > $OUT/chain_bench_16x32.txt 2>&1
 rm -f $OUT/*agent_info.csv $OUT/*.log
+TAG=r05_bf16s bash tools/prof_feature_tier.sh > /dev/null 2>&1
 ls $OUT gpurun_out/${TAG}_levels
