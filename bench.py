@@ -110,7 +110,7 @@ def l1_against(ref0, got0, golden=None):
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 dense peak
 PEAK_HBM_GBS = 8000.0
 PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"   # FETCH_SIZE / WRITE_SIZE passes of the bench command (tools/prof_round.sh)
-FEATURE_TIER_PMC_FILE = "r05_bf16_feature_tier_pmc.json"   # FETCH / WRITE of the regulariser's layers per tier (tools/vol_tiers.py)
+FEATURE_TIER_PMC_FILE = "r05_bf16_feature_tier_pmc.json"   # FETCH / WRITE of the chain and the regulariser's layers per tier (tools/prof_feature_tier.sh)
 LEVEL_PMC_FILE = "r05_level_pmc.json"       # ... of the refiner towers level by level (tools/level_profile.py)
 
 
@@ -794,7 +794,7 @@ def main():
                 entry["config5_B=32_depthmaps_per_s"] = round(32 * 3 / (time.perf_counter() - t1), 1)
                 pmc5 = load_profile_json(FEATURE_TIER_PMC_FILE)
                 if pmc5:
-                    entry["hbm_bytes_of_the_regulariser_layers"] = {k: v for k, v in pmc5.items() if not k.startswith("_l")}
+                    entry["hbm_bytes_of_the_converted_launches"] = {k: v for k, v in pmc5.items() if not k.startswith("_l")}
                 line["bf16_feature_tier"].update(entry)
                 del inp5
                 torch.cuda.empty_cache()

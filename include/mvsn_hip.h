@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVSN_ABI_VERSION 4
+#define MVSN_ABI_VERSION 5
 
 #define MVSN_E_BADARG (-1)      /* null pointer, non-positive size, unsupported channel count */
 #define MVSN_E_TOOLARGE (-2)    /* shape exceeds what the kernel's LDS/global plan supports */
@@ -162,6 +162,21 @@ int mvsn_incremental_cost_volume_guarded(const float *src_image_lvl4, const floa
                                          const float *plane0_features, const float *left_features,
                                          const float *refiner_packed, int n_chains, int batch,
                                          int num_idepth_samples, int rows, int cols, float *cost_volume,
+                                         uint8_t *mask_volume, float *feature_volume, void *workspace,
+                                         size_t workspace_bytes, int form, void *repair_workspace,
+                                         size_t repair_workspace_bytes, unsigned *sticky_status, mvsn_stream_t stream);
+/* bf16 FEATURE tier (BASELINE config 5's "bf16 features"; reported, never the parity path; ABI 5): the guarded call with
+ * the cost volume STORED as bf16 -- `cost_volume_bf16` is (n_chains, 32, D, rows, cols) 2-byte elements, the values the
+ * fp32 call writes rounded to nearest-even (v_cvt_pk_bf16_f32): Kernel A's dominant HBM stream halves (SURVEY 8d:
+ * config 5 137.5 MB -> ~69 MB per depth map).  mask_volume / feature_volume / workspaces / status as in the guarded
+ * call; every form but MVSN_CHAIN_STEPWISE has the variant (MVSN_E_BADARG there: run the fp32 call and convert).
+ * Consumer: mvsn_conv_forward_bf16_storage(in_is_bf16 = 1), whose bf16 operand conversion of an fp32 volume yields the
+ * same bits -- the stored volume costs the regulariser no accuracy beyond the bf16-operand tier's.
+ * Replaces: the cost volume of multi_view_stereonet.py:553,587-592 at config 5's storage precision. */
+int mvsn_incremental_cost_volume_bf16(const float *src_image_lvl4, const float *H_lvl4, const float *H_inc,
+                                         const float *plane0_features, const float *left_features,
+                                         const float *refiner_packed, int n_chains, int batch,
+                                         int num_idepth_samples, int rows, int cols, void *cost_volume_bf16,
                                          uint8_t *mask_volume, float *feature_volume, void *workspace,
                                          size_t workspace_bytes, int form, void *repair_workspace,
                                          size_t repair_workspace_bytes, unsigned *sticky_status, mvsn_stream_t stream);

@@ -38,7 +38,7 @@ class TowerDesc(Structure):
 
 CONV_FP32, CONV_BF16X3, CONV_FP32_WINO, CONV_BF16 = 0, 1, 2, 3
 CHAIN_AUTO, CHAIN_DIRECT, CHAIN_WINOGRAD, CHAIN_STEPWISE, CHAIN_BANDED = 0, 1, 2, 3, 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 # name -> (restype, argtypes); mirrors include/mvsn_hip.h one to one
@@ -61,6 +61,8 @@ SIGNATURES = {
     "mvsn_incremental_cost_volume_repair_workspace_bytes": (c_size_t, [c_int] * 3),
     "mvsn_incremental_cost_volume_guarded": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 4 +
                                              [c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "mvsn_incremental_cost_volume_bf16": (c_int, [c_void_p] * 6 + [c_int] * 5 + [c_void_p] * 4 +
+                                          [c_size_t, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "mvsn_conv_bf16x3_supported": (c_int, [POINTER(ConvDesc)]),
     "mvsn_conv_forward_bf16_storage": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_int, c_void_p, c_void_p]),

@@ -43,7 +43,42 @@ struct ChainArgs {
   // (one writer per launch; not atomic across concurrent streams -- a lost count still leaves a changed word).
   const unsigned *gate;
   unsigned *sticky;
+  // bf16 feature tier (BASELINE config 5; never the parity path): `cost` points at (N,32,D,P) bf16 elements and the
+  // kernels store the same cost values rounded to nearest-even (template C16 of the kernels that have the variant)
+  int cost_bf16;
 };
+
+// ---- cost-volume stores, by element type of the volume (float: the contract; uint16_t: bf16 bits, C16 kernels) ----
+typedef float chain_f2 __attribute__((ext_vector_type(2)));
+typedef float chain_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned chain_u2 __attribute__((ext_vector_type(2)));
+template <bool C16> struct ChainCost { typedef float type; };
+template <> struct ChainCost<true> { typedef uint16_t type; };
+__device__ __forceinline__ unsigned chain_bf16_pair(float a, float b) {   // two RNE conversions: one v_cvt_pk_bf16_f32
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 p;
+  p[0] = (__bf16)a;
+  p[1] = (__bf16)b;
+  return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ void chain_cost_nt(float *p, chain_f2 v) { __builtin_nontemporal_store(v, reinterpret_cast<chain_f2 *>(p)); }
+__device__ __forceinline__ void chain_cost_nt(uint16_t *p, chain_f2 v) {
+  __builtin_nontemporal_store(chain_bf16_pair(v.x, v.y), reinterpret_cast<unsigned *>(p));
+}
+__device__ __forceinline__ void chain_cost_nt(float *p, chain_f4 v) { __builtin_nontemporal_store(v, reinterpret_cast<chain_f4 *>(p)); }
+__device__ __forceinline__ void chain_cost_nt(uint16_t *p, chain_f4 v) {
+  chain_u2 q;
+  q.x = chain_bf16_pair(v.x, v.y), q.y = chain_bf16_pair(v.z, v.w);
+  __builtin_nontemporal_store(q, reinterpret_cast<chain_u2 *>(p));
+}
+__device__ __forceinline__ void chain_cost_st(float *p, chain_f4 v) { *reinterpret_cast<chain_f4 *>(p) = v; }
+__device__ __forceinline__ void chain_cost_st(uint16_t *p, chain_f4 v) {
+  chain_u2 q;
+  q.x = chain_bf16_pair(v.x, v.y), q.y = chain_bf16_pair(v.z, v.w);
+  *reinterpret_cast<chain_u2 *>(p) = q;
+}
+__device__ __forceinline__ void chain_cost_st(float *p, float v) { *p = v; }
+__device__ __forceinline__ void chain_cost_st(uint16_t *p, float v) { *p = (uint16_t)(chain_bf16_pair(v, 0.0f) & 0xffffu); }
 
 // First statement of a kernel that may be launched as a repair: true = nothing to repair, the workgroup returns.
 // (The status word is read past L1 -- the launch boundary published it, a stale line of an earlier forward must not
@@ -102,6 +137,8 @@ struct SlabPlan {
   size_t chain_u64, lds_bytes;
   void (*kernel)(ChainArgs, int, const void *, const void *, const void *, const void *, const void *, const void *,
                  const void *, const void *, const void *, const void *);
+  void (*kernel16)(ChainArgs, int, const void *, const void *, const void *, const void *, const void *, const void *,
+                   const void *, const void *, const void *, const void *);   // ... storing the cost volume as bf16
 };
 bool chain_slab_plan(int rows, int cols, SlabPlan *p);
 

@@ -269,7 +269,7 @@ __device__ __forceinline__ void store_weights_to_lds(float *wbuf, const floatx4 
   }
 }
 
-template <int TP, bool LDS_ACT>
+template <int TP, bool LDS_ACT, bool C16 = false>   // C16: cost volume stored as bf16 (ChainArgs::cost_bf16, bf16 feature tier)
 __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a, MVSN_VIS10) {   // (MVSN_VIS10: mvsn_common.h)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (chain_gate_closed(a)) return;   // repair launch with nothing to repair (mvsn_chain.h)
@@ -339,7 +339,8 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a, MVSN_VIS
   const float *Hin = a.Hinc + (size_t)n * D * 9;
   const float *src = a.src + (size_t)n * 3 * P;
   uint8_t *maskg = a.mask + (size_t)n * D * P;
-  float *costg = a.cost + (size_t)n * 32 * D * P;
+  typedef typename ChainCost<C16>::type cost_t;
+  cost_t *costg = reinterpret_cast<cost_t *>(a.cost) + (size_t)n * 32 * D * P;
   float *fvolg = a.fvol ? a.fvol + (size_t)n * 32 * D * P : nullptr;
 
   // ---- plane 0: mask and cost from the extractor's features ---------------------------------
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a, MVSN_VIS
           cst[k] = m[k] != 0.0f ? 0.0f : fabsf(l[k] - f);
           ftr[k] = m[k] != 0.0f ? 0.0f : f;
         }
-        *reinterpret_cast<floatx4 *>(costg + ((size_t)c * D + dd) * P + p4) = cst;
+        chain_cost_st(costg + ((size_t)c * D + dd) * P + p4, cst);
         if (fvolg) *reinterpret_cast<floatx4 *>(fvolg + ((size_t)c * D + dd) * P + p4) = ftr;
       }
     } else {
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(CH_THREADS) void chain_kernel(ChainArgs a, MVSN_VIS
         const int c = i / P, p = i - c * P;
         const float f = act[(3 + c) * CS + (p / cols) * RS + (p % cols)];
         const bool out = maskb[p] != 0.0f;
-        costg[((size_t)c * D + dd) * P + p] = out ? 0.0f : fabsf(flp[(size_t)c * P + p] - f);
+        chain_cost_st(costg + ((size_t)c * D + dd) * P + p, out ? 0.0f : fabsf(flp[(size_t)c * P + p] - f));
         if (fvolg) fvolg[((size_t)c * D + dd) * P + p] = out ? 0.0f : f;
       }
     }
@@ -668,7 +669,7 @@ static int chain_run(const float *src_image_lvl4, const float *H_lvl4, const flo
                      const float *left_features, const float *refiner_packed, int n_chains, int batch,
                      int num_idepth_samples, int rows, int cols, float *cost_volume, uint8_t *mask_volume,
                      float *feature_volume, void *workspace, size_t workspace_bytes, int form, const unsigned *gate,
-                     unsigned *sticky, mvsn_stream_t stream) {
+                     unsigned *sticky, mvsn_stream_t stream, int cost_bf16 = 0) {
   using namespace mvsn;
   MVSN_REQUIRE(src_image_lvl4 && H_lvl4 && H_inc && plane0_features && left_features && refiner_packed &&
                    cost_volume && mask_volume,
@@ -689,7 +690,10 @@ static int chain_run(const float *src_image_lvl4, const float *H_lvl4, const flo
                "mvsn_incremental_cost_volume: %dx%d coarse grid (%d px) exceeds the 2048 px plan", rows, cols, P);
   MVSN_REQUIRE(gate == nullptr || wino || form == MVSN_CHAIN_DIRECT, MVSN_E_BADARG,
                "mvsn_incremental_cost_volume: a repair launch runs the Winograd or the direct form");
+  MVSN_REQUIRE(!cost_bf16 || form != MVSN_CHAIN_STEPWISE, MVSN_E_BADARG,
+               "mvsn_incremental_cost_volume_bf16: the stepwise form has no bf16 cost-volume variant");
   ChainArgs a;
+  a.cost_bf16 = cost_bf16 ? 1 : 0;
   a.chain0 = 0;
   a.ws_chains = 0;
   a.gate = gate;
@@ -734,7 +738,14 @@ static int chain_run(const float *src_image_lvl4, const float *H_lvl4, const flo
 
 #define MVSN_CHAIN_LAUNCH(TPV, LDSV)                                                                           \
   do {                                                                                                         \
-    auto kern = chain_kernel<TPV, LDSV>;                                                                       \
+    if (a.cost_bf16) {   /* (bf16 feature tier: its own instantiation and LDS opt-in) */                        \
+      auto kern16 = chain_kernel<TPV, LDSV, true>;                                                             \
+      static LdsOptIn opt16;                                                                                   \
+      if (int rc = ensure_lds(opt16, (const void *)kern16, lds, "mvsn_incremental_cost_volume")) return rc;    \
+      hipLaunchKernelGGL(kern16, dim3(n_chains), dim3(CH_THREADS), lds, (hipStream_t)stream, a, CHAIN_VISIBLE_G(a)); \
+      break;                                                                                                   \
+    }                                                                                                          \
+    auto kern = chain_kernel<TPV, LDSV, false>;                                                                \
     static LdsOptIn opt;                                                                                       \
     if (int rc = ensure_lds(opt, (const void *)kern, lds, "mvsn_incremental_cost_volume")) return rc;          \
     hipLaunchKernelGGL(kern, dim3(n_chains), dim3(CH_THREADS), lds, (hipStream_t)stream, a, CHAIN_VISIBLE_G(a));    \
@@ -814,4 +825,35 @@ extern "C" int mvsn_incremental_cost_volume_guarded(const float *src_image_lvl4,
   return chain_run(src_image_lvl4, H_lvl4, H_inc, plane0_features, left_features, refiner_packed, n_chains, batch,
                    num_idepth_samples, rows, cols, cost_volume, mask_volume, feature_volume, repair_workspace,
                    repair_workspace_bytes, chain_repair_form(rows, cols), gate, sticky_status, stream);
+}
+
+// The guarded call with the cost volume stored as bf16 (the bf16 feature tier, BASELINE config 5; include/mvsn_hip.h).
+extern "C" int mvsn_incremental_cost_volume_bf16(const float *src_image_lvl4, const float *H_lvl4, const float *H_inc,
+                                                    const float *plane0_features, const float *left_features,
+                                                    const float *refiner_packed, int n_chains, int batch,
+                                                    int num_idepth_samples, int rows, int cols, void *cost_volume_bf16,
+                                                    uint8_t *mask_volume, float *feature_volume, void *workspace,
+                                                    size_t workspace_bytes, int form, void *repair_workspace,
+                                                    size_t repair_workspace_bytes, unsigned *sticky_status,
+                                                    mvsn_stream_t stream) {
+  using namespace mvsn;
+  if (form == MVSN_CHAIN_AUTO && n_chains > 0 && rows > 0 && cols > 0) form = chain_auto_form(n_chains, rows, cols);
+  // everything the repair launch needs is validated BEFORE the banded launch is enqueued: an error return must not
+  // leave an unrepaired banded chain (NaN on a time-out) behind on the stream
+  size_t need = 0;
+  if (form == MVSN_CHAIN_BANDED && n_chains > 0 && rows > 0 && cols > 0) {
+    need = mvsn_incremental_cost_volume_repair_workspace_bytes(n_chains, rows, cols);
+    MVSN_REQUIRE(need == 0 || (repair_workspace && repair_workspace_bytes >= need), MVSN_E_WORKSPACE,
+                 "mvsn_incremental_cost_volume_bf16: repair workspace of %zu bytes required", need);
+  }
+  if (int rc = chain_run(src_image_lvl4, H_lvl4, H_inc, plane0_features, left_features, refiner_packed, n_chains, batch,
+                         num_idepth_samples, rows, cols, (float *)cost_volume_bf16, mask_volume, feature_volume, workspace,
+                         workspace_bytes, form, nullptr, nullptr, stream, 1))
+    return rc;
+  if (form != MVSN_CHAIN_BANDED) return 0;   // the other forms have no inter-workgroup hand-offs to time out
+  const unsigned *gate = reinterpret_cast<const unsigned *>(static_cast<const char *>(workspace) +
+                                                            chain_band_status_offset(n_chains, rows, cols));
+  return chain_run(src_image_lvl4, H_lvl4, H_inc, plane0_features, left_features, refiner_packed, n_chains, batch,
+                   num_idepth_samples, rows, cols, (float *)cost_volume_bf16, mask_volume, feature_volume, repair_workspace,
+                   repair_workspace_bytes, chain_repair_form(rows, cols), gate, sticky_status, stream, 1);
 }

@@ -260,7 +260,7 @@ __device__ __forceinline__ void cb_wave_minmax(int &lo, int &hi) {
            max(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(hi, 48)));
 }
 
-template <class GEO>
+template <class GEO, bool C16 = false>   // C16: the cost volume stored as bf16 (ChainArgs::cost_bf16, the bf16 feature tier)
 __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int flags, MVSN_VIS10) {   // (mvsn_common.h)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int rows = GEO::rows, cols = GEO::cols, P = GEO::P, RS = GEO::RS, BR = GEO::BR, G = GEO::G, W = GEO::W;
@@ -362,7 +362,8 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
   const float *Hin = a.Hinc + (size_t)n * D * 9;
   const float *src = a.src + (size_t)n * 3 * P;
   uint8_t *maskg = a.mask + (size_t)n * D * P;
-  float *costg = a.cost + (size_t)n * 32 * D * P;
+  typedef typename ChainCost<C16>::type cost_t;
+  cost_t *costg = reinterpret_cast<cost_t *>(a.cost) + (size_t)n * 32 * D * P;
   float *fvolg = a.fvol ? a.fvol + (size_t)n * 32 * D * P : nullptr;
   const float *flp = a.fl + (size_t)(n % a.B) * 32 * P;
   const float *fl_lane = flp + (size_t)cbase * P + py0 * cols + px0;
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
     const float2 m0 = *reinterpret_cast<const float2 *>(maskb + (2 * prow) * cols + px0);
     const float2 m1 = *reinterpret_cast<const float2 *>(maskb + (2 * prow + 1) * cols + px0);
     const bool out[4] = {m0.x != 0.0f, m0.y != 0.0f, m1.x != 0.0f, m1.y != 0.0f};
-    float *cd = costg + (size_t)d * P;
+    cost_t *cd = costg + (size_t)d * P;
     float *fd = fvolg ? fvolg + (size_t)d * P : nullptr;
     // the granules first: the other bands wait for them, everything else of the epilogue travels meanwhile
     if (d + 1 < D) {
@@ -391,14 +392,14 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
       float *dst = win + (cbase + r) * CSW + (W + 2 * prow) * RS + px0 + 1;
       if (row0) dst[0] = f[r][0], dst[1] = f[r][1];
       if (row1) dst[RS] = f[r][2], dst[RS + 1] = f[r][3];
-      float *cdst = cd + (r * D) * P + slice_off;
+      cost_t *cdst = cd + (r * D) * P + slice_off;
 #pragma unroll
       for (int a2 = 0; a2 < 2; ++a2) {
         if (!(a2 ? row1 : row0)) continue;
         float2v c2;
         c2.x = out[a2 * 2] ? 0.0f : fabsf(fl[r][a2].x - f[r][a2 * 2]);
         c2.y = out[a2 * 2 + 1] ? 0.0f : fabsf(fl[r][a2].y - f[r][a2 * 2 + 1]);
-        __builtin_nontemporal_store(c2, reinterpret_cast<float2v *>(cdst + a2 * cols));
+        chain_cost_nt(cdst + a2 * cols, c2);
       }
       if (fd) {
         float *fdst = fd + (r * D) * P + slice_off;
@@ -906,7 +907,7 @@ __global__ __launch_bounds__(CB_THREADS) void chain_band_kernel(ChainArgs a, int
   // wrong numbers behind.  Besides the status word, make that impossible to miss without a host round trip: one NaN in
   // the cost slice turns the regulariser's GroupNorm statistics -- and with them the whole depth map -- into NaN.
   // (written by the thread that owns the element: program order puts it behind the last step's own store)
-  if (__syncthreads_or(dead) && pvalid && row0) costg[(size_t)(D - 1) * P + slice_off] = __builtin_nanf("");
+  if (__syncthreads_or(dead) && pvalid && row0) chain_cost_st(costg + ((size_t)(D - 1) * P + slice_off), __builtin_nanf(""));
 }
 
 // Zero fill of the hand-off workspace (granules + status word) as a plain kernel: inside a captured graph a
@@ -922,11 +923,13 @@ struct BandPlan {
   int G, threads, slot;   // workgroups per chain, threads per workgroup, LDS opt-in slot of the kernel
   size_t chain_u64, lds_bytes;
   void (*kernel)(ChainArgs, int, MVSN_VIS10);
+  void (*kernel16)(ChainArgs, int, MVSN_VIS10);   // ... storing the cost volume as bf16 (ChainArgs::cost_bf16)
 };
 
 template <class GEO>
 static BandPlan band_plan_of(int slot) {
-  return BandPlan{GEO::G, CB_THREADS, slot, GEO::CHAIN_U64, (size_t)GEO::LDS_FLOATS * sizeof(float), chain_band_kernel<GEO>};
+  return BandPlan{GEO::G, CB_THREADS, slot, GEO::CHAIN_U64, (size_t)GEO::LDS_FLOATS * sizeof(float), chain_band_kernel<GEO, false>,
+                  chain_band_kernel<GEO, true>};
 }
 
 static int g_band_debug_flags = 0;
@@ -947,7 +950,7 @@ static bool band_plan(int rows, int cols, int n_chains, BandPlan *p) {
   if (((g_band_debug_flags & 16) || many) && !(g_band_debug_flags & 32)) {
     SlabPlan sp;
     if (chain_slab_plan(rows, cols, &sp)) {
-      *p = BandPlan{sp.G, sp.threads, rows == 16 ? 4 : (rows == 30 ? 5 : 6), sp.chain_u64, sp.lds_bytes, sp.kernel};
+      *p = BandPlan{sp.G, sp.threads, rows == 16 ? 4 : (rows == 30 ? 5 : 6), sp.chain_u64, sp.lds_bytes, sp.kernel, sp.kernel16};
       return true;
     }
   }
@@ -1036,9 +1039,11 @@ int chain_band_launch(const ChainArgs &a, int n_chains, void *workspace, size_t 
                "mvsn_incremental_cost_volume(banded): workspace of %zu bytes required", need);
   MVSN_REQUIRE(device_cus() / s.main.G >= 1, MVSN_E_TOOLARGE,
                "mvsn_incremental_cost_volume(banded): %d bands exceed the %d CUs", s.main.G, device_cus());
-  static LdsOptIn opt[7];
+  static LdsOptIn opt[2][7];
+  const int c16 = a.cost_bf16 ? 1 : 0;
   auto run_pass = [&](const BandPlan &p, int n0, int nn, u64 *ws, int ws_chains, bool with_status) -> int {
-    if (int rc = ensure_lds(opt[p.slot], (const void *)p.kernel, p.lds_bytes, "mvsn_incremental_cost_volume(banded)")) return rc;
+    const auto kern = c16 ? p.kernel16 : p.kernel;
+    if (int rc = ensure_lds(opt[c16][p.slot], (const void *)kern, p.lds_bytes, "mvsn_incremental_cost_volume(banded)")) return rc;
     // every polled word starts from tag 0 (no step carries it): zeroed ahead of each pass -- with the first pass (which
     // fills the workspace) also the status block behind the granules, so that a later pass keeps what an earlier one
     // reported
@@ -1051,9 +1056,9 @@ int chain_band_launch(const ChainArgs &a, int n_chains, void *workspace, size_t 
     b.ws_chains = ws_chains;
 #ifdef MVSN_BAND_HIDE_PTRS   // A/B aid (see MVSN_VIS10): the buffers reach the kernel through the by-value struct only
     const ChainArgs hidden{};
-    hipLaunchKernelGGL(p.kernel, dim3(nn * p.G), dim3(p.threads), p.lds_bytes, stream, b, flags, CHAIN_VISIBLE(hidden));
+    hipLaunchKernelGGL(kern, dim3(nn * p.G), dim3(p.threads), p.lds_bytes, stream, b, flags, CHAIN_VISIBLE(hidden));
 #else
-    hipLaunchKernelGGL(p.kernel, dim3(nn * p.G), dim3(p.threads), p.lds_bytes, stream, b, flags, CHAIN_VISIBLE(b));
+    hipLaunchKernelGGL(kern, dim3(nn * p.G), dim3(p.threads), p.lds_bytes, stream, b, flags, CHAIN_VISIBLE(b));
 #endif
     return 0;
   };

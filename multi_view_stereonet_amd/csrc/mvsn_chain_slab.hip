@@ -253,7 +253,7 @@ __device__ __forceinline__ void sb_half_wave_sums(float (&s)[4]) {
     s[k] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s[k]), 0x142, 0xA, 0xF, false));
 }
 
-template <class GEO>
+template <class GEO, bool C16 = false>   // C16: the cost volume stored as bf16 (ChainArgs::cost_bf16, the bf16 feature tier)
 __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int flags, MVSN_VIS10) {   // (mvsn_common.h)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int rows = GEO::rows, cols = GEO::cols, P = GEO::P, RS = GEO::RS, BR = GEO::BR, NB = GEO::NB, ER = GEO::ER;
@@ -349,7 +349,8 @@ __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int
   const float *Hin = a.Hinc + (size_t)n * D * 9;
   const float *src = a.src + (size_t)n * 3 * P;
   uint8_t *maskg = a.mask + (size_t)n * D * P;
-  float *costg = a.cost + (size_t)n * 32 * D * P;
+  typedef typename ChainCost<C16>::type cost_t;
+  cost_t *costg = reinterpret_cast<cost_t *>(a.cost) + (size_t)n * 32 * D * P;
   float *fvolg = a.fvol ? a.fvol + (size_t)n * 32 * D * P : nullptr;
   const float *flp = a.fl + (size_t)(n % a.B) * 32 * P;
 
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int
         ftr[k] = mm[k] != 0.0f ? 0.0f : f;
       }
       const size_t vo = ((size_t)c * D) * P + (lo + yl) * cols + xx;
-      __builtin_nontemporal_store(cst, reinterpret_cast<floatx4 *>(costg + vo));
+      chain_cost_nt(costg + vo, cst);
       if (fvolg) __builtin_nontemporal_store(ftr, reinterpret_cast<floatx4 *>(fvolg + vo));
     }
     // step 1 on the slow path reads every tap from the granules: plane 0 has to be there (tag 1)
@@ -852,7 +853,7 @@ __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int
         const float2 m0 = *reinterpret_cast<const float2 *>(maskb + (2 * pr) * cols + px0);
         const float2 m1 = *reinterpret_cast<const float2 *>(maskb + (2 * pr + 1) * cols + px0);
         const bool out[4] = {m0.x != 0.0f, m0.y != 0.0f, m1.x != 0.0f, m1.y != 0.0f};
-        float *cd = costg + (size_t)d * P;
+        cost_t *cd = costg + (size_t)d * P;
         float *fd = fvolg ? fvolg + (size_t)d * P : nullptr;
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
@@ -861,13 +862,13 @@ __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int
             const float(&f)[4] = y[ct][r];
             float *dst = act + (3 + ct * 16 + cbase + r) * CSA + ob;
             dst[0] = f[0], dst[1] = f[1], dst[RS] = f[2], dst[RS + 1] = f[3];
-            float *cdst = cd + ((ct * 16 + r) * D) * P + slice_off;
+            cost_t *cdst = cd + ((ct * 16 + r) * D) * P + slice_off;
 #pragma unroll
             for (int a2 = 0; a2 < 2; ++a2) {
               sb_float2v c2;
               c2.x = out[a2 * 2] ? 0.0f : fabsf(fl[ct][r][a2].x - f[a2 * 2]);
               c2.y = out[a2 * 2 + 1] ? 0.0f : fabsf(fl[ct][r][a2].y - f[a2 * 2 + 1]);
-              __builtin_nontemporal_store(c2, reinterpret_cast<sb_float2v *>(cdst + a2 * cols));
+              chain_cost_nt(cdst + a2 * cols, c2);
             }
             if (fd) {
               float *fdst = fd + ((ct * 16 + r) * D) * P + slice_off;
@@ -890,14 +891,15 @@ __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int
   // a hand-off that timed out leaves wrong numbers behind: poison the cost slice (see chain_band_kernel)
   if (__syncthreads_or(dead)) {
     const LaneGeo L = lane_geo();
-    if (L.pvalid) costg[(size_t)(D - 1) * P + (L.cbase * D) * P + L.py0 * cols + L.px0] = __builtin_nanf("");
+    if (L.pvalid) chain_cost_st(costg + ((size_t)(D - 1) * P + (L.cbase * D) * P + L.py0 * cols + L.px0), __builtin_nanf(""));
   }
 }
 
 // ---- host side: the slab plans as seen by the banded form's dispatcher (mvsn_chain_band.hip) -------------------------
 template <class GEO>
 static SlabPlan slab_plan_of() {
-  return SlabPlan{GEO::NB, SB_THREADS, GEO::CHAIN_U64, (size_t)GEO::LDS_FLOATS * sizeof(float), chain_slab_kernel<GEO>};
+  return SlabPlan{GEO::NB, SB_THREADS, GEO::CHAIN_U64, (size_t)GEO::LDS_FLOATS * sizeof(float), chain_slab_kernel<GEO, false>,
+                  chain_slab_kernel<GEO, true>};
 }
 
 bool chain_slab_plan(int rows, int cols, SlabPlan *p) {

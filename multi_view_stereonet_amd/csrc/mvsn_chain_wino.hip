@@ -254,7 +254,8 @@ __device__ __forceinline__ void wino_groupnorm_apply(float (&y)[2][4][4], float 
 
 // ROWS x COLS: the coarse grid as compile-time constants (every LDS access becomes base register + immediate
 // offset: no address registers live across the step loop); 0 x 0 = run-time sizes (same code, any supported grid).
-template <int ROWS, int COLS>
+// C16: the cost volume is stored as bf16 (ChainArgs::cost_bf16; the bf16 feature tier -- never the parity path).
+template <int ROWS, int COLS, bool C16 = false>
 __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a, MVSN_VIS10) {   // (MVSN_VIS10: mvsn_common.h)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (chain_gate_closed(a)) return;   // repair launch with nothing to repair (mvsn_chain.h)
@@ -331,7 +332,8 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a, MVS
   const float *Hin = a.Hinc + (size_t)n * D * 9;
   const float *src = a.src + (size_t)n * 3 * P;
   uint8_t *maskg = a.mask + (size_t)n * D * P;
-  float *costg = a.cost + (size_t)n * 32 * D * P;
+  typedef typename ChainCost<C16>::type cost_t;
+  cost_t *costg = reinterpret_cast<cost_t *>(a.cost) + (size_t)n * 32 * D * P;
   float *fvolg = a.fvol ? a.fvol + (size_t)n * 32 * D * P : nullptr;
 
   // ---- plane 0: mask from the plane's homography ------------------------------------------------
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a, MVS
           cst[k] = m[k] != 0.0f ? 0.0f : fabsf(l[k] - f);
           ftr[k] = m[k] != 0.0f ? 0.0f : f;
         }
-        __builtin_nontemporal_store(cst, reinterpret_cast<floatx4 *>(costg + ((size_t)c * D + dd) * P + p4));
+        chain_cost_nt(costg + ((size_t)c * D + dd) * P + p4, cst);
         if (fvolg) __builtin_nontemporal_store(ftr, reinterpret_cast<floatx4 *>(fvolg + ((size_t)c * D + dd) * P + p4));
       }
     } else {
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a, MVS
         const int yy = p / cols, xx = p - yy * cols;
         const float f = act[(3 + c) * CS + (yy + 1) * RS + xx + 1];
         const bool out = maskb[p] != 0.0f;
-        costg[((size_t)c * D + dd) * P + p] = out ? 0.0f : fabsf(flp[(size_t)c * P + p] - f);
+        chain_cost_st(costg + ((size_t)c * D + dd) * P + p, out ? 0.0f : fabsf(flp[(size_t)c * P + p] - f));
         if (fvolg) fvolg[((size_t)c * D + dd) * P + p] = out ? 0.0f : f;
       }
     }
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a, MVS
       const float2 m0 = *reinterpret_cast<const float2 *>(maskb + (2 * pr) * cols + 2 * pc);
       const float2 m1 = *reinterpret_cast<const float2 *>(maskb + (2 * pr + 1) * cols + 2 * pc);
       const bool out[4] = {m0.x != 0.0f, m0.y != 0.0f, m1.x != 0.0f, m1.y != 0.0f};
-      float *cd = costg + (size_t)d * P;
+      cost_t *cd = costg + (size_t)d * P;
       float *fd = fvolg ? fvolg + (size_t)d * P : nullptr;
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
@@ -587,13 +589,13 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a, MVS
           for (int e = 0; e < 4; ++e) f[e] = fp[ct][r][e] + (y[ct][r][e] + b2);
           float *dst = act + (3 + ct * 16 + cbase + r) * CS + ob;
           dst[0] = f[0], dst[1] = f[1], dst[RS] = f[2], dst[RS + 1] = f[3];
-          float *cdst = cd + ((ct * 16 + r) * D) * P + slice_off;
+          cost_t *cdst = cd + ((ct * 16 + r) * D) * P + slice_off;
 #pragma unroll
           for (int a2 = 0; a2 < 2; ++a2) {
             float2v c2;
             c2.x = out[a2 * 2] ? 0.0f : fabsf(fl[ct][r][a2].x - f[a2 * 2]);
             c2.y = out[a2 * 2 + 1] ? 0.0f : fabsf(fl[ct][r][a2].y - f[a2 * 2 + 1]);
-            __builtin_nontemporal_store(c2, reinterpret_cast<float2v *>(cdst + a2 * cols));
+            chain_cost_nt(cdst + a2 * cols, c2);
           }
           if (fd) {
             float *fdst = fd + ((ct * 16 + r) * D) * P + slice_off;
@@ -618,15 +620,18 @@ __global__ __launch_bounds__(CW_THREADS) void chain_wino_kernel(ChainArgs a, MVS
 
 int chain_wino_launch(const ChainArgs &a, int n_chains, hipStream_t stream) {
   const size_t lds = chain_wino_lds_bytes(a.rows, a.cols);
-#define CW_LAUNCH(R, C)                                                                                              \
+#define CW_LAUNCH(R, C, C16)                                                                                         \
   do {                                                                                                               \
     static LdsOptIn opt;                                                                                             \
-    if (int rc = ensure_lds(opt, (const void *)chain_wino_kernel<R, C>, lds, "mvsn_incremental_cost_volume(winograd)")) \
+    if (int rc = ensure_lds(opt, (const void *)chain_wino_kernel<R, C, C16>, lds, "mvsn_incremental_cost_volume(winograd)")) \
       return rc;                                                                                                     \
-    hipLaunchKernelGGL((chain_wino_kernel<R, C>), dim3(n_chains), dim3(CW_THREADS), lds, stream, a, CHAIN_VISIBLE_G(a)); \
+    hipLaunchKernelGGL((chain_wino_kernel<R, C, C16>), dim3(n_chains), dim3(CW_THREADS), lds, stream, a, CHAIN_VISIBLE_G(a)); \
   } while (0)
-  if (a.rows == 16 && a.cols == 32) CW_LAUNCH(16, 32);   // 512x256 frames (BASELINE configs 2, 3 and the headline)
-  else CW_LAUNCH(0, 0);
+  if (a.cost_bf16) {                                     // (bf16 feature tier)
+    if (a.rows == 16 && a.cols == 32) CW_LAUNCH(16, 32, true);
+    else CW_LAUNCH(0, 0, true);
+  } else if (a.rows == 16 && a.cols == 32) CW_LAUNCH(16, 32, false);   // 512x256 frames (BASELINE configs 2, 3 and the headline)
+  else CW_LAUNCH(0, 0, false);
 #undef CW_LAUNCH
   return check_launch("mvsn_incremental_cost_volume(winograd)");
 }

@@ -296,6 +296,7 @@ class PlaneSweepEngine:
         self.banded_ok = True
         self.net_state = net.__dict__.setdefault("_shared_state", _SharedState())   # survives rebuilds of this object
         self.last_chain_form, self.last_chain_workspace, self.last_chain_shape = None, None, None
+        self.last_cost_dtype = torch.float32        # element type of the last chain call's cost volume (bf16: the "bf16s" tier)
         self.recording: Optional["ForwardPlan"] = None    # the plan a forward is being recorded into
         self.plans: Dict[tuple, Optional[ForwardPlan]] = {}   # shape key -> plan (None: that shape runs eagerly)
         self.replays = 0
@@ -874,6 +875,9 @@ class PlaneSweepEngine:
             out = self.cost_volume_filter_bf16_storage(cost, to1)
             if out is not None:
                 return out
+        if cost.dtype != torch.float32:     # (a bf16 cost volume with no bf16-storage plan for the regulariser)
+            self._aten()
+            cost = cost.float()
         mat = self.volume_materialise and self.winograd and self.winograd_volume and self.conv_precision == "fp32"
         x, st = self.conv(self.vf_convs[0], cost, want_stats=True, lazy_stats=mat)
         for i in range(1, 4):
@@ -890,6 +894,13 @@ class PlaneSweepEngine:
         out, _ = self.conv(last, x, in_stats=st, in_norm=self.vf_norms[3])
         return out[:, 0]
 
+    def bf16_storage_supported(self, n: int, depth: int, rows: int, cols: int) -> bool:
+        """Do the regulariser's four 3x3x3 layers have the bf16-storage kernels for this volume shape?"""
+        convs = self.vf_convs[:4]
+        d = convs[0].desc(n, depth, rows, cols, _native.CONV_BF16)
+        return (all(c.packed_bx is not None for c in convs) and bool(self.lib.mvsn_conv_bf16x3_supported(ctypes.byref(d)))
+                and cols % 2 == 0)
+
     def cost_volume_filter_bf16_storage(self, cost: torch.Tensor, to1: bool) -> Optional[torch.Tensor]:
         """The regulariser with its intermediate volumes stored as bf16 (`conv_precision = "bf16s"`, BASELINE config 5's
         "bf16 features", reference: multi_view_stereonet.py:341-353): layer 0 fp32 -> bf16, layers 1, 2 bf16 -> bf16 with the
@@ -900,17 +911,18 @@ class PlaneSweepEngine:
         lib = self.lib
         convs = self.vf_convs[:4]
         d = convs[0].desc(n, depth, rows, cols, _native.CONV_BF16)
-        if any(c.packed_bx is None for c in convs) or not lib.mvsn_conv_bf16x3_supported(ctypes.byref(d)) or not to1:
+        if not (to1 and self.bf16_storage_supported(n, depth, rows, cols)):
             return None
         tiles = lib.mvsn_conv_num_tiles(ctypes.byref(d))
         x, st = cost, None
+        in16_0 = cost.dtype == torch.bfloat16      # the chain stored the cost volume as bf16 (forward, step 4)
         for i, c in enumerate(convs):
             out16 = i < 3
             out = self.empty((n, 32, depth, rows, cols), dtype=torch.bfloat16 if out16 else torch.float32, device=cost.device)
             partials = self.empty((n, tiles, 4, 3), dtype=torch.float32, device=cost.device)
             nrm = self.vf_norms[i - 1] if i else None
             self._call("mvsn_conv_forward[conv3d k3 32->32 bf16 storage]", lib.mvsn_conv_forward_bf16_storage, ctypes.byref(d),
-                       _native.ptr(x), 1 if i else 0, _native.ptr(c.packed_bx), _native.ptr(c.bias), _native.ptr(st),
+                       _native.ptr(x), 1 if (i or in16_0) else 0, _native.ptr(c.packed_bx), _native.ptr(c.bias), _native.ptr(st),
                        _native.ptr(nrm.gamma) if nrm else None, _native.ptr(nrm.beta) if nrm else None, _native.ptr(out),
                        1 if out16 else 0, _native.ptr(partials), _native.stream(),
                        flops=2.0 * 32 * 27 * 32 * out[:, 0].numel(),
@@ -1059,14 +1071,16 @@ class PlaneSweepEngine:
         if self.recording is not None:
             self.recording.keep.extend(tensors)
 
-    def incremental_cost_volume(self, src4, H4, Hinc, plane0, left_feats, want_features=False):
+    def incremental_cost_volume(self, src4, H4, Hinc, plane0, left_feats, want_features=False, cost_bf16=False):
+        """cost_bf16: the cost volume stored as bf16 (the bf16 feature tier, `conv_precision = "bf16s"`:
+        mvsn_incremental_cost_volume_bf16; the stepwise form has no such variant: fp32 call + conversion)."""
         N, _, rows, cols = src4.shape
         B = left_feats.shape[0]
         D = H4.shape[1]
         dev = src4.device
-        cost = self.empty((N, 32, D, rows, cols), dtype=torch.float32, device=dev)
+        cost = self.empty((N, 32, D, rows, cols), dtype=torch.bfloat16 if cost_bf16 else torch.float32, device=dev)
         mask = self.empty((N, D, rows, cols), dtype=torch.bool, device=dev)
-        fvol = self.empty(cost.shape, cost.dtype, cost.device) if want_features else None
+        fvol = self.empty(cost.shape, torch.float32, cost.device) if want_features else None
         form = {"auto": _native.CHAIN_AUTO, "direct": _native.CHAIN_DIRECT, "winograd": _native.CHAIN_WINOGRAD,
                 "stepwise": _native.CHAIN_STEPWISE, "banded": _native.CHAIN_BANDED}[self.chain_form]
         if form == _native.CHAIN_AUTO:
@@ -1080,16 +1094,29 @@ class PlaneSweepEngine:
             form = _native.CHAIN_DIRECT        # no Winograd plan for this coarse grid
         if form == _native.CHAIN_STEPWISE and cols % 4 != 0:
             form = _native.CHAIN_DIRECT        # the Winograd convolutions of the stepwise form need cols % 4 == 0
+        if cost_bf16 and form == _native.CHAIN_STEPWISE:
+            cost, mask, fvol = self.incremental_cost_volume(src4, H4, Hinc, plane0, left_feats, want_features)
+            self._aten()                    # (an ATen kernel: a forward being recorded is not replayable)
+            self.last_cost_dtype = torch.bfloat16
+            return cost.to(torch.bfloat16), mask, fvol
         ws_bytes = self.lib.mvsn_incremental_cost_volume_workspace_bytes_for(N, D, rows, cols, form)
         ws = self.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
         self.last_chain_form, self.last_chain_workspace, self.last_chain_shape = form, ws, (N, rows, cols)
+        self.last_cost_dtype = cost.dtype
         P = rows * cols
         common = (_native.ptr(src4), _native.ptr(H4), _native.ptr(Hinc), _native.ptr(plane0), _native.ptr(left_feats),
                   _native.ptr(self.refiner_packed), N, B, D, rows, cols, _native.ptr(cost), _native.ptr(mask),
                   _native.ptr(fvol), _native.ptr(ws), ws_bytes, form)
         acct = dict(flops=N * (D - 1) * 2.0 * 9 * 32 * (35 + 32 + 32) * P,
-                    nbytes=N * (4.0 * 67 * P + 128.0 * D * P + D * P))  # Kernel A algorithmic bytes
-        if form == _native.CHAIN_BANDED and self.banded_repair:
+                    nbytes=N * (4.0 * 67 * P + (64.0 if cost_bf16 else 128.0) * D * P + D * P))  # Kernel A algorithmic bytes
+        if cost_bf16:
+            # (always the guarded call: a banded launch is followed by its gated repair launch)
+            rws_bytes = (self.lib.mvsn_incremental_cost_volume_repair_workspace_bytes(N, rows, cols)
+                         if form == _native.CHAIN_BANDED else 0)
+            rws = self.empty(rws_bytes, dtype=torch.uint8, device=dev) if rws_bytes else None
+            self._call("mvsn_incremental_cost_volume", self.lib.mvsn_incremental_cost_volume_bf16, *common,
+                       _native.ptr(rws), rws_bytes, self.net_state.status_ptr(), _native.stream(), **acct)
+        elif form == _native.CHAIN_BANDED and self.banded_repair:
             # followed by the gated single-launch form: valid outputs even if a hand-off times out (EngineOptions)
             rws_bytes = self.lib.mvsn_incremental_cost_volume_repair_workspace_bytes(N, rows, cols)
             rws = self.empty(rws_bytes, dtype=torch.uint8, device=dev) if rws_bytes else None
@@ -1180,8 +1207,11 @@ class PlaneSweepEngine:
 
         # 4. the fused chain
         src4 = self.cat0([p[-1] for p in right_image_pyrs])
+        # (bf16 feature tier: the chain stores the cost volume as bf16 where the regulariser's bf16-storage kernels read it)
+        cost16 = (self.conv_precision == "bf16s" and do_filter and capture is None and
+                  bool(self.lib.mvsn_conv_to1_supported(rows4, cols4)) and self.bf16_storage_supported(S * B, D, rows4, cols4))
         cost, mask, fvol = self.incremental_cost_volume(src4, H4, Hinc, plane0, left_feats[-1],
-                                                        want_features=capture is not None)
+                                                        want_features=capture is not None, cost_bf16=cost16)
         # 5. regularise + soft-argmin
         if do_filter:
             filtered = self.cost_volume_filter(cost)

@@ -51,7 +51,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/mvsn_hip.h but not exported"
     assert declared == set(_native.SIGNATURES), (declared ^ set(_native.SIGNATURES))
     typed = _native.load()
-    assert typed.mvsn_abi_version() == _native.ABI_VERSION == 4
+    assert typed.mvsn_abi_version() == _native.ABI_VERSION == 5
     # direct form + the chain's Winograd U + the same three layers in the convolution kernels' layout (stepwise form)
     assert typed.mvsn_feature_refiner_packed_floats() == (9 * 9 * 128 + 2 * 9 * 8 * 128 + 7 * 32) + 25 * 2048 + 25 * 2048
     assert typed.mvsn_incremental_cost_volume_form(16, 32) == _native.CHAIN_WINOGRAD

@@ -1272,6 +1272,65 @@ def test_banded_chain_in_passes(grid, N, D):
         net.options.chain_form = "auto"
 
 
+@pytest.mark.parametrize("grid,N,D,form,flag", [
+    ((16, 32), 70, 5, "winograd", 0), ((16, 32), 3, 6, "banded", 0), ((16, 32), 40, 4, "banded", 0),
+    ((30, 40), 3, 5, "banded", 0), ((32, 64), 2, 5, "banded", 0), ((30, 40), 20, 4, "banded", 0), ((32, 64), 66, 3, "banded", 0),
+    ((30, 40), 4, 4, "direct", 0), ((12, 20), 5, 6, "winograd", 0), ((9, 14), 3, 5, "direct", 0), ((32, 64), 3, 3, "direct", 0)])
+def test_chain_bf16_cost_volume_is_the_fp32_volume_rounded(grid, N, D, form, flag):
+    """mvsn_incremental_cost_volume_bf16 (the bf16 feature tier's Kernel A: cost volume stored as bf16) in every form that
+    has the variant -- plane-resident Winograd, thin bands, slabs (20 / 66 chains: beyond one thin pass; 66 = one slab
+    pass + a thin tail pass), direct: the bf16 volume is the fp32 call's volume rounded to nearest-even, word for word;
+    masks and the fp32 feature volume are unchanged; status 0.  The stepwise form falls back to fp32 + conversion."""
+    net = net_for("gta_sfm_150epochs")
+    eng = net.engine()
+    r4, c4 = grid
+    B = min(N, 3)
+    g = torch.Generator().manual_seed(41 + N)
+    H, Hinc = _motion_family(N, D, "mixed", seed=3)
+    dev = [x.to(DEV) for x in (torch.rand(N, 3, r4, c4, generator=g) * 2 - 1, H, Hinc,
+                               torch.randn(N, 32, r4, c4, generator=g), torch.randn(B, 32, r4, c4, generator=g))]
+    net.options.chain_form = form
+    try:
+        eng.lib.mvsn_debug_set_band_flags(flag)
+        c32, m32, f32 = eng.incremental_cost_volume(*dev, want_features=True)
+        torch.cuda.synchronize()
+        assert eng.chain_status() == 0
+        c16, m16, f16 = eng.incremental_cost_volume(*dev, want_features=True, cost_bf16=True)
+        torch.cuda.synchronize()
+        assert eng.chain_status() == 0
+        assert c16.dtype == torch.bfloat16 and c16.shape == c32.shape
+        assert torch.equal(c16, c32.to(torch.bfloat16)), float((c16.float() - c32).abs().max())
+        assert torch.equal(m16, m32) and torch.equal(f16, f32)
+        if r4 % 2 == 0 and c4 % 4 == 0 and r4 != 16:
+            net.options.chain_form = "stepwise"      # no bf16 variant: the fp32 call + a conversion
+            c3, m3, _ = eng.incremental_cost_volume(*dev, cost_bf16=True)
+            assert c3.dtype == torch.bfloat16 and torch.equal(m3, m32)
+            mean_rel, max_rel = rel_err(c3.float().cpu(), c32.cpu())
+            assert mean_rel < 3e-3, mean_rel
+    finally:
+        eng.lib.mvsn_debug_set_band_flags(0)
+        net.options.chain_form = "auto"
+
+
+def test_forward_bf16_feature_tier_cost_volume_storage_changes_no_bit():
+    """Under `conv_precision = "bf16s"` the chain stores the cost volume as bf16 and the first regulariser layer reads it
+    as such; with a capture dict the cost volume stays fp32 (the captured tensors are the fp32 ones) and that layer rounds
+    it to bf16 itself: the same bits enter the multiplies, so the two forwards must agree bit for bit."""
+    net = net_for("gta_sfm_150epochs")
+    fix = load_golden("g2_gta_512x256_d64_s2.npz")
+    net.options.conv_precision = "bf16s"
+    try:
+        eng = net.engine()
+        out_a = _forward(net, fix)
+        assert eng.last_cost_dtype == torch.bfloat16
+        out_b = _forward(net, fix, capture={})
+        assert eng.last_cost_dtype == torch.float32
+        for a, b in zip(out_a["left_idepthmap_pyr"], out_b["left_idepthmap_pyr"]):
+            assert torch.equal(a, b)
+    finally:
+        net.options.conv_precision = "fp32"
+
+
 @pytest.mark.parametrize("grid,extra,D", [((30, 40), 1, 3), ((30, 40), 17, 2), ((32, 64), 2, 3)])
 def test_banded_chain_slab_passes_with_thin_tail(grid, extra, D):
     """A call of k x (chains per slab pass) + a few chains runs full slab passes and ONE thin-band pass for the remainder

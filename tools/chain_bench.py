@@ -10,6 +10,8 @@ torch.set_grad_enabled(False)
 net = MultiViewStereoNet(); net.load_state_dict(load_weights("gta_sfm_150epochs")); net = net.cuda().eval()
 eng = net.engine()
 rows, cols, D = [int(v) for v in os.environ.get("MVSN_GRID", "16,32,64").split(",")]
+cost16 = bool(int(os.environ.get("MVSN_COST_BF16", "0")))     # the cost volume stored as bf16 (bf16 feature tier)
+only = [f for f in os.environ.get("MVSN_FORMS", "").split(",") if f]   # restrict to these tags
 P = rows * cols
 g = torch.Generator().manual_seed(0)
 for N in [int(a) for a in sys.argv[1:]] or [2, 256]:
@@ -49,20 +51,22 @@ for N in [int(a) for a in sys.argv[1:]] or [2, 256]:
             continue
         if form == "stepwise" and (rows, cols) == (16, 32):
             continue
+        if (only and tag not in only) or (cost16 and form == "stepwise"):
+            continue
         net.options.chain_form = form
         for _ in range(3):
-            eng.incremental_cost_volume(src4, H, Hinc, F0, FL)
+            eng.incremental_cost_volume(src4, H, Hinc, F0, FL, cost_bf16=cost16)
         torch.cuda.synchronize()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 5 if N >= 32 else 20
         a.record()
         for _ in range(reps):
-            eng.incremental_cost_volume(src4, H, Hinc, F0, FL)
+            eng.incremental_cost_volume(src4, H, Hinc, F0, FL, cost_bf16=cost16)
         b.record(); torch.cuda.synchronize()
         ms = a.elapsed_time(b) / reps
         flops = N * (D - 1) * 2.0 * 9 * 32 * 99 * P
-        nbytes = N * (4.0 * 67 * P + 128.0 * D * P + D * P)
+        nbytes = N * (4.0 * 67 * P + (64.0 if cost16 else 128.0) * D * P + D * P)
         status = eng.chain_status()
         eng.lib.mvsn_debug_set_band_flags(0)
-        print(f"N={N:4d} {tag:11s}: {ms:7.3f} ms/launch  {ms * 1e3 / (D - 1):6.1f} us/step  "
+        print(f"N={N:4d} {tag + ('+bf16cost' if cost16 else ''):11s}: {ms:7.3f} ms/launch  {ms * 1e3 / (D - 1):6.1f} us/step  "
               f"{flops / ms / 1e9:6.1f} direct-form TFLOP/s  {nbytes / ms / 1e6:7.1f} GB/s algorithmic  status {status}")

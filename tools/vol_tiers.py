@@ -16,7 +16,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "json":
     out = {"_library_digest": digest,
            "_comment": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB) of `python tools/vol_tiers.py 128 32 64 128` "
                        "(config 5's regulariser: 128 chains of 32x128x32x64): bytes per launch and chain; FETCH_SIZE as read (the "
-                       "kernels' 2- / 4-byte per-lane loads are not the half-counted 16-byte streaming form)", "kernels": {}}
+                       "kernels' 2- / 4-byte per-lane loads are not the half-counted 16-byte streaming form); `chain`: WRITE_SIZE of "
+                       "`MVSN_GRID=32,64,128 MVSN_FORMS=banded-auto MVSN_COST_BF16=0|1 python tools/chain_bench.py 128` (Kernel A, "
+                       "two slab passes of 64 chains -- their bytes include the four hand-offs' write-through granules, ~50 MB per chain -- and of `MVSN_FORMS=winograd ... chain_bench.py 512`, the headline's plane-resident kernel: cost volume written as fp32 / bf16, <.., false> / <.., true>)", "kernels": {}}
     chains = int(sys.argv[3]) if len(sys.argv) > 3 else 128
     for r in fetch:
         k = r["kernel"]
@@ -26,6 +28,17 @@ if len(sys.argv) > 1 and sys.argv[1] == "json":
         n = float(r["dispatches"])
         out["kernels"][k[:140]] = {"dispatches": int(n), "fetch_bytes_per_chain": round(float(r["FETCH_SIZE"]) * 1024 / n / chains),
                                    "write_bytes_per_chain": round(float(w["WRITE_SIZE"]) * 1024 / float(w["dispatches"]) / chains) if w else None}
+    # Kernel A (the chain) with the cost volume stored as fp32 / bf16: WRITE_SIZE passes of tools/chain_bench.py (prof_feature_tier.sh)
+    for c16 in (0, 1):
+        for stem, per in (("chain_write", 64), ("chainw_write", 512)):   # (32x64: two slab passes of 64; 16x32: one launch of 512)
+            f = os.path.join(d, f"{stem}{c16}_summary.csv")
+            if not os.path.exists(f):
+                continue
+            for r in read_summary(f):
+                if "chain_slab_kernel" in r["kernel"] or "chain_band_kernel" in r["kernel"] or "chain_wino_kernel" in r["kernel"]:
+                    out.setdefault("chain", {})[r["kernel"][:110]] = {
+                        "dispatches": int(float(r["dispatches"])), "chains_per_dispatch": per,
+                        "write_bytes_per_chain": round(float(r["WRITE_SIZE"]) * 1024 / float(r["dispatches"]) / per)}
     print(json.dumps(out, indent=1))
     sys.exit(0)
 import torch
