@@ -98,9 +98,10 @@ class EngineOptions:
         # Arithmetic of the 32 -> 32 channel 3x3 / 3x3x3 layers: "fp32" = exact fp32 MFMA;
         # "bf16x3" = 3 x bf16 split on the bf16 matrix cores (fp32-equivalent to ~2^-16 per product);
         # "bf16" = plain bf16 operands on the same kernels (BASELINE config 5's speed tier, outside the 1e-3 contract);
-        # "bf16s" = the same plus bf16 STORAGE of the regulariser's intermediate volumes (config 5's "bf16 features":
-        # the first 3x3x3 layer reads the fp32 cost volume and writes bf16, the next two read and write bf16, the fourth
-        # writes fp32 for the 32 -> 1 tail; GroupNorm statistics stay fp32 -- mvsn_conv_forward_bf16_storage).
+        # "bf16s" = the same plus bf16 STORAGE of the cost volume and of the regulariser's intermediate volumes (config 5's
+        # "bf16 features": the chain writes the cost volume as bf16 -- mvsn_incremental_cost_volume_bf16 --, the first three
+        # 3x3x3 layers read and write bf16, the fourth writes fp32 for the 32 -> 1 tail; GroupNorm statistics stay fp32 --
+        # mvsn_conv_forward_bf16_storage).
         self.conv_precision = "fp32"
         # Winograd F(2x2,3x3) form of the 2-D 3x3 dilation-1 layers (fp32 throughout, 2.25x fewer multiplies).
         self.winograd = True
@@ -903,7 +904,8 @@ class PlaneSweepEngine:
 
     def cost_volume_filter_bf16_storage(self, cost: torch.Tensor, to1: bool) -> Optional[torch.Tensor]:
         """The regulariser with its intermediate volumes stored as bf16 (`conv_precision = "bf16s"`, BASELINE config 5's
-        "bf16 features", reference: multi_view_stereonet.py:341-353): layer 0 fp32 -> bf16, layers 1, 2 bf16 -> bf16 with the
+        "bf16 features", reference: multi_view_stereonet.py:341-353): layer 0 bf16 (the chain's cost volume; fp32 when a
+        capture dict asks for the fp32 tensors) -> bf16, layers 1, 2 bf16 -> bf16 with the
         previous layer's LeakyReLU(GroupNorm(.)) applied on load, layer 3 bf16 -> fp32, then the usual 32 -> 1 tail.  21.5
         instead of 34.4 bytes per voxel and channel move through HBM; statistics are fp32 from the unrounded accumulators.
         None when a layer has no bf16 kernel for this shape (the caller falls back to the bf16-operand path)."""
