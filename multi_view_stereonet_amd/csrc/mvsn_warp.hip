@@ -15,7 +15,15 @@ __global__ __launch_bounds__(256) void homography_warp_kernel(const float *__res
   const int P = rows * cols;
   // blockIdx.x = pixel block * cgroups + channel group: small launches (one coarse plane of a few chains, the chain's
   // stepwise form) are latency-bound on the per-thread channel loop, so the channels are dealt to several blocks
-  const int cg = SPLIT ? blockIdx.x % cgroups : 0, pb = SPLIT ? blockIdx.x / cgroups : blockIdx.x;
+  // Whole planes (!SPLIT): an output row's lower taps are the next row's upper ones, and consecutive workgroups run on
+  // DIFFERENT XCDs (b % 8), each with its own L2 -- every source row was fetched by two of them (the full-resolution warp
+  // ran at 0.44 of the HBM rate on ~1.45x its algorithmic bytes).  Each XCD takes a contiguous band of rows instead.
+#ifdef MVSN_WARP_NO_XCD_BANDS   // A/B aid
+  const int pbx = blockIdx.x;
+#else
+  const int pbx = xcd_tile_index(blockIdx.x, gridDim.x);
+#endif
+  const int cg = SPLIT ? blockIdx.x % cgroups : 0, pb = SPLIT ? blockIdx.x / cgroups : pbx;
   const int p = pb * blockDim.x + threadIdx.x;
   const int plane = blockIdx.y;
   const int b = blockIdx.z;
