@@ -121,6 +121,30 @@ def test_homography_warp(B, C, n, rows, cols):
     close(vol.cpu()[agree], vref[agree], rtol=1e-4, atol=cols * 2.0 ** -23 * 8)
 
 
+@pytest.mark.parametrize("B,C,n,rows,cols", [(40, 3, 1, 256, 512), (24, 5, 3, 128, 512), (40, 32, 96, 30, 40)])
+def test_homography_warp_many_frames_form_is_bit_identical(B, C, n, rows, cols):
+    """With enough pixels in flight mvsn_homography_warp runs four pixels per thread (16-byte streaming stores, the mask
+    bytes as dwords); the coordinate algebra and the products per pixel are the one-pixel kernel's, so a large call must
+    equal the same frames warped in calls small enough for the one-pixel form, bit for bit -- including borders (pairs
+    shifted at the right edge), NaN / Inf texels and the mask."""
+    eng = net_for("gta_sfm_150epochs").engine()
+    g = torch.Generator().manual_seed(B * 131 + cols)
+    img = torch.rand(B, C, rows, cols, generator=g) * 2 - 1
+    img[0, 0, 3, 5], img[B - 1, C - 1, rows - 1, cols - 1] = float("nan"), float("inf")
+    H = torch.eye(3).repeat(B, n, 1, 1) + 0.04 * (torch.rand(B, n, 3, 3, generator=g) - 0.5)
+    H[..., 0, 2] += (torch.rand(B, n, generator=g) - 0.5) * cols * 0.5
+    H[..., 1, 2] += (torch.rand(B, n, generator=g) - 0.5) * rows * 0.5
+    H[..., 2, :2] *= 0.02
+    img, H = img.to(DEV), H.to(DEV)
+    assert B * n * rows * cols >= 4 * 16 * 64 * 4 * 256      # (the four-pixel form's threshold on 256 CUs)
+    vol, mask = eng.homography_warp(img, H)
+    for b in range(B):       # one frame and one plane at a time: far below the threshold
+        for d in range(0, n, max(1, n // 3)):
+            v1, m1 = eng.homography_warp(img[b:b + 1], H[b:b + 1, d:d + 1].contiguous())
+            assert torch.equal(m1[0, 0], mask[b, d])
+            assert torch.equal(v1[0, :, 0].view(torch.int32), vol[b, :, d].view(torch.int32)), (b, d)
+
+
 def test_homography_warp_golden_units():
     fix = load_golden("g4_units.npz")
     eng = net_for("gta_sfm_150epochs").engine()
