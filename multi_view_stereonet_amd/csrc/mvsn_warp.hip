@@ -74,8 +74,8 @@ __global__ __launch_bounds__(256) void homography_warp_kernel(const float *__res
   float *out = volume + (((size_t)b * C) * n_planes + plane) * P + p;
   if (cols >= 2) {
     // The two taps of a row are neighbours in memory: ONE 8-byte load per row and channel (6 gathers per pixel
-    // instead of 12 -- the kernel is gather-issue-bound, a 4-pixel-per-thread form with 16-byte stores measured
-    // 185 us against 116).  At the right border (x1 clamped onto x0, weight exactly 0) the pair starts one texel
+    // instead of 12 -- with a cache-resident working set the kernel is gather-issue-bound; for many frames see
+    // homography_warp_px_kernel).  At the right border (x1 clamped onto x0, weight exactly 0) the pair starts one texel
     // earlier and the weights move to its second element: the same products, the same sum.
     const int xb = t.x0 < cols - 1 ? t.x0 : cols - 2;
     const bool sh = t.x0 != xb;
