@@ -1080,9 +1080,6 @@ class PlaneSweepEngine:
         B = left_feats.shape[0]
         D = H4.shape[1]
         dev = src4.device
-        cost = self.empty((N, 32, D, rows, cols), dtype=torch.bfloat16 if cost_bf16 else torch.float32, device=dev)
-        mask = self.empty((N, D, rows, cols), dtype=torch.bool, device=dev)
-        fvol = self.empty(cost.shape, torch.float32, cost.device) if want_features else None
         form = {"auto": _native.CHAIN_AUTO, "direct": _native.CHAIN_DIRECT, "winograd": _native.CHAIN_WINOGRAD,
                 "stepwise": _native.CHAIN_STEPWISE, "banded": _native.CHAIN_BANDED}[self.chain_form]
         if form == _native.CHAIN_AUTO:
@@ -1101,6 +1098,9 @@ class PlaneSweepEngine:
             self._aten()                    # (an ATen kernel: a forward being recorded is not replayable)
             self.last_cost_dtype = torch.bfloat16
             return cost.to(torch.bfloat16), mask, fvol
+        cost = self.empty((N, 32, D, rows, cols), dtype=torch.bfloat16 if cost_bf16 else torch.float32, device=dev)
+        mask = self.empty((N, D, rows, cols), dtype=torch.bool, device=dev)
+        fvol = self.empty(cost.shape, torch.float32, dev) if want_features else None      # (the features stay fp32)
         ws_bytes = self.lib.mvsn_incremental_cost_volume_workspace_bytes_for(N, D, rows, cols, form)
         ws = self.empty(ws_bytes, dtype=torch.uint8, device=dev) if ws_bytes else None
         self.last_chain_form, self.last_chain_workspace, self.last_chain_shape = form, ws, (N, rows, cols)
