@@ -8,7 +8,8 @@
 One "step" = one MultiViewStereoNet.forward() over a batch of B synthetic reference images (each
 with 2 source views) already resident in HBM; every rank runs its own B images (weak scaling,
 images are independent -- SURVEY 8e) and the ranks all-gather one metric row per image at the end.
-Rank 0 prints ONE JSON line.  At N=1 it also reports
+Rank 0 prints ONE JSON line, LAST and < 4 KB (`final_line`); the full record (per-kernel rooflines, the other
+configurations, tier legs, latencies) goes to `bench_detail.json` and a `DETAIL <json>` stdout line before it.  It reports
   roofline      the dominant kernel's algorithmic flops / measured launch time (device events on the
                 stream the kernels run on) against the fp32 MFMA peak, plus the fused chain kernel
                 against both peaks,
@@ -109,9 +110,94 @@ def l1_against(ref0, got0, golden=None):
     return res
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 dense peak
 PEAK_HBM_GBS = 8000.0
-PMC_TRAFFIC_FILE = "r05_pmc_traffic.json"   # FETCH_SIZE / WRITE_SIZE passes of the bench command (tools/prof_round.sh)
-FEATURE_TIER_PMC_FILE = "r05_bf16_feature_tier_pmc.json"   # FETCH / WRITE of the chain and the regulariser's layers per tier (tools/prof_feature_tier.sh)
-LEVEL_PMC_FILE = "r05_level_pmc.json"       # ... of the refiner towers level by level (tools/level_profile.py)
+PMC_TRAFFIC_FILE = "r*_pmc_traffic.json"   # FETCH_SIZE / WRITE_SIZE passes of the bench command (tools/prof_round.sh)
+FEATURE_TIER_PMC_FILE = "r*_bf16_feature_tier_pmc.json"   # FETCH / WRITE of the chain and the regulariser's layers per tier (tools/prof_feature_tier.sh)
+LEVEL_PMC_FILE = "r*_level_pmc.json"       # ... of the refiner towers level by level (tools/level_profile.py)
+
+
+FINAL_LINE_LIMIT = 4096      # the driver keeps a bounded tail of stdout: the line it parses must fit well inside it
+DETAIL_FILE = os.path.join(ROOT, "bench_detail.json")
+_ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_per_rank", "traffic", "launches_per_step",
+                  "avg_launch_ms", "share_of_step", "direct_form_equivalent_TFLOPs")
+_CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "cpu_model", "logical_cpus", "physical_cores")
+_TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "world_size", "backend",
+             "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config")
+
+
+def _numbers(d, digits=6):
+    """The numeric leaves of a flat dict (floats to `digits` significant figures); prose stays in the DETAIL record."""
+    out = {}
+    for k, v in (d or {}).items():
+        if isinstance(v, bool) or v is None or isinstance(v, int):
+            out[k] = v
+        elif isinstance(v, float):
+            out[k] = float(f"{v:.{digits}g}")
+        elif isinstance(v, (list, tuple)) and all(isinstance(x, (int, float)) for x in v):
+            out[k] = [float(f"{x:.{digits}g}") if isinstance(x, float) else x for x in v]
+    return out
+
+
+def final_line(full):
+    """The ONE line the driver parses, from the full record: the contract's keys, `roofline` and `cpu_baseline` without
+    prose, the parity figures as numbers.  Everything else (per-kernel rooflines, the other configurations, the tier
+    legs, batch latency, PCIe-inclusive and evaluate rates) is the DETAIL record (`emit`).  VERDICT r5 item 1: the
+    22 KB line of round 5 outgrew the driver's capture and the headline went unparsed."""
+    line = {k: full[k] for k in _TOP_KEYS if k in full}
+    for k in ("value", "ms_per_step"):
+        if isinstance(line.get(k), float):
+            line[k] = float(f"{line[k]:.7g}")
+    if isinstance(full.get("config"), dict):
+        line["config"] = {k: v for k, v in full["config"].items() if not isinstance(v, str) or len(v) <= 160}
+    if isinstance(full.get("l1_vs_ref"), dict):
+        line["l1_vs_ref"] = _numbers(full["l1_vs_ref"]) or full["l1_vs_ref"]
+    if isinstance(full.get("roofline"), dict):
+        r = full["roofline"]
+        line["roofline"] = {k: (float(f"{r[k]:.6g}") if isinstance(r[k], float) else
+                                [float(f"{x:.6g}") for x in r[k]] if isinstance(r[k], list) else r[k])
+                            for k in _ROOFLINE_KEYS if k in r}
+        if r.get("stand_in"):
+            line["roofline"]["stand_in"] = True
+    if isinstance(full.get("chain_kernel"), dict):
+        line["chain_kernel"] = _numbers(full["chain_kernel"]) or full["chain_kernel"]
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = {k: cb[k] for k in _CPU_KEYS if k in cb} or cb
+        if isinstance(line["cpu_baseline"].get("value"), float):
+            line["cpu_baseline"]["value"] = float(f"{cb['value']:.5g}")
+        for k in ("one_thread", "all_physical_cores"):
+            if isinstance(cb.get(k), dict):
+                line["cpu_baseline"][k] = _numbers(cb[k])
+    for k, v in full.items():
+        if k.startswith("l1_vs_oracle"):
+            line[k] = _numbers(v) if isinstance(v, dict) else (float(f"{v:.6g}") if isinstance(v, float) else v)
+    for k in ("per_rank_ms_per_step", "mean_idepth", "rows_gathered", "rank_sum", "selftest", "engine_options_override"):
+        if k in full:
+            line[k] = full[k]
+    line["detail"] = "bench_detail.json + the `DETAIL ` stdout line before this one"
+    text = json.dumps(line)
+    if len(text) >= FINAL_LINE_LIMIT:       # never again an unparsable line: shed optional groups, keep the contract
+        for k in ("chain_kernel", "l1_vs_oracle_last", "l1_vs_oracle_slice_b", "per_rank_ms_per_step"):
+            line.pop(k, None)
+            text = json.dumps(line)
+            if len(text) < FINAL_LINE_LIMIT:
+                break
+    assert len(text) < FINAL_LINE_LIMIT, len(text)
+    return text
+
+
+def emit(full, stream=None):
+    """Full record -> `bench_detail.json` next to this script and a `DETAIL <json>` stdout line; then, LAST, the compact
+    JSON line (`final_line`) -- the only stdout line that starts with `{`."""
+    stream = stream or sys.stdout
+    blob = json.dumps(full)
+    try:
+        with open(DETAIL_FILE, "w") as f:
+            f.write(blob + "\n")
+    except OSError:
+        pass
+    stream.write("DETAIL " + blob + "\n")
+    stream.write(final_line(full) + "\n")
+    stream.flush()
 
 
 def make_inputs(batch, first_seed, device):
@@ -264,15 +350,24 @@ def roofline_by_kernel(agg, total_ms, top=14, wino_names=()):
 
 def load_profile_json(name):
     """A committed counter file under profiles/ -- only if it was taken with THIS library (its `_library_digest` equals
-    multi_view_stereonet_amd/libmvsn_hip.so.sources); a stale file is refused, never scaled."""
+    multi_view_stereonet_amd/libmvsn_hip.so.sources); a stale file is refused, never scaled.  `name` may hold a `*`
+    (round prefix): the newest round's file whose digest matches is the one used."""
+    import glob
     try:
-        with open(os.path.join(ROOT, "profiles", name)) as f:
-            data = json.load(f)
         with open(os.path.join(ROOT, "multi_view_stereonet_amd", "libmvsn_hip.so.sources")) as f:
             digest = f.read().strip()
-    except (OSError, ValueError):
+    except OSError:
         return None
-    return data if data.get("_library_digest") == digest else None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", name)), reverse=True):
+        try:
+            with open(path) as f:
+                data = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if data.get("_library_digest") == digest:
+            data["_file"] = os.path.basename(path)
+            return data
+    return None
 
 
 def cpu_baseline(cfg, budget_s=15.0):
@@ -352,6 +447,12 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def mask_mean(mask):
+    """Per-image fraction of set voxels of a (B, D, H, W) bool volume: an integer sum, no fp32 copy of the volume (at
+    config 5 / B = 32 `.float()` was an 8.6 GB temporary and ~10 % of the traced kernel time -- VERDICT r5)."""
+    return (mask.sum(dim=(1, 2, 3), dtype=torch.int64).to(torch.float64) / (mask[0].numel() or 1)).float()
+
+
 def timed_steps(step, steps, warmup, world, sync, reduce_device):
     """The timing protocol: `warmup` untimed steps, then exactly `steps` steps between barrier + device sync on
     both sides; returns (max over ranks, per-rank list) of the elapsed seconds."""
@@ -406,7 +507,7 @@ def launcher_selftest(args, rank, world):
     fracs = gather_floats(0.5 + rank / 10.0, world, torch.device("cpu"))
     if rank == 0:
         skipped = {"skipped": "launcher self-test: no forward ran"}
-        print(json.dumps({"l1_vs_ref": skipped, "cpu_baseline": skipped, "chain_kernel": skipped,
+        emit({"l1_vs_ref": skipped, "cpu_baseline": skipped, "chain_kernel": skipped,
                           "roofline": {"frac": min(fracs), "frac_per_rank": fracs, "stand_in": True},
                           "metric": "launcher self-test (no forward, not a measurement)", "value": 0.0,
                           "unit": "none", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -414,7 +515,7 @@ def launcher_selftest(args, rank, world):
                           "backend": torch.distributed.get_backend() if world > 1 else "none",
                           "per_rank_ms_per_step": [e / args.steps * 1e3 for e in per_rank],
                           "rows_gathered": int(all_rows.shape[0]), "rank_sum": float(all_rows[:, 0].sum()),
-                          "data": "none"}))
+                          "data": "none"})
     if world > 1:
         torch.distributed.destroy_process_group()
 
@@ -603,7 +704,7 @@ def main():
     # per-image metric rows, all-gathered (the path's only exchange step)
     idepth = out["left_idepthmap_pyr"][0]
     rows = torch.stack([idepth.mean(dim=(1, 2, 3)), (idepth > 0).float().mean(dim=(1, 2, 3)),
-                        out["left_idepthmap_mask_pyr"][0].float().mean(dim=(1, 2, 3))], 1)
+                        mask_mean(out["left_idepthmap_mask_pyr"][0])], 1)
     idx = torch.arange(rank * B, (rank + 1) * B, device=dev)
     all_rows, all_idx = mdist.gather_metric_rows(rows.to(coll_dev), idx.to(coll_dev))
     assert all_rows.shape[0] == B * world and bool(torch.isfinite(all_rows).all())
@@ -659,7 +760,7 @@ def main():
             doubled = t.get("fetch_doubled", t["fetch_bytes_per_chain"] != t.get("fetch_bytes_per_chain_raw"))
             how = ("FETCH_SIZE x2 (gfx950 half-count of 16-byte streaming reads: this kernel's tiles arrive by 16-byte LDS-DMA)"
                    if doubled else "FETCH_SIZE as read (this kernel's 4- / 8-byte accesses are not half-counted)")
-            traffic_source = (f"profiles/{PMC_TRAFFIC_FILE}: {how} + "
+            traffic_source = (f"profiles/{pmc['_file']}: {how} + "
                               f"WRITE_SIZE of separate rocprofv3 --pmc passes of the bench command with this library "
                               f"(digest {pmc['_library_digest'][:12]}, {pmc.get('_chains_per_launch', '?')} chains per launch), "
                               "per chain x this batch -- a committed pass, NOT a counter read during this run")
@@ -705,7 +806,7 @@ def main():
                     "fetched": t["fetch_bytes_per_chain"], "written": t["write_bytes_per_chain"],
                     "algorithmic": t["algorithmic_bytes_per_chain"],
                     "ratio": (t["fetch_bytes_per_chain"] + t["write_bytes_per_chain"]) /
-                    t["algorithmic_bytes_per_chain"], "source": f"profiles/{PMC_TRAFFIC_FILE} (separate PMC pass, this library)"}
+                    t["algorithmic_bytes_per_chain"], "source": f"profiles/{pmc['_file']} (separate PMC pass, this library)"}
         line["kernel_ms_per_step"] = {k: round(v["ms"], 3) for k, v in
                                       sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:16]}
         line["launches_per_forward"] = int(sum(v["launches"] for v in agg.values()))
@@ -813,7 +914,7 @@ def main():
             for key, idx in (("l1_vs_oracle_slice_b", (B + 1) // 2), ("l1_vs_oracle_last", B - 1)):
                 if idx > 0:
                     line[key] = oracle_check(cfg, idx, idepth[idx:idx + 1].cpu())
-        print(json.dumps(line))
+        emit(line)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

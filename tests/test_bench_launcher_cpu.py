@@ -17,6 +17,8 @@ def _run(extra, env_extra=None):
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout          # exactly ONE JSON line, from rank 0
+    assert p.stdout.rstrip("\n").splitlines()[-1] == lines[0]        # ... and it is the LAST line printed
+    assert len(lines[0]) < 4096
     return json.loads(lines[0])
 
 
@@ -65,3 +67,53 @@ def test_real_line_builds_quality_fields_for_every_world_size():
 def test_single_rank_needs_no_launcher():
     line = _run(["--gpus", "1", "--steps", "2", "--warmup", "0", "--batch", "3", "--launcher-selftest"])
     assert line["n_gpus"] == 1 and line["world_size"] == 1 and line["rows_gathered"] == 3
+
+
+def test_final_line_is_small_last_and_carries_the_contract():
+    """round 5's single 22 KB line outgrew the driver's stdout capture (`parsed: null`).  The full
+    record of that very run (profiles/r05_final/bench_default.json), widened to 8 ranks, must come out as a DETAIL line
+    + sidecar and ONE final JSON line < 4 KB holding the contract's keys, `roofline` and `cpu_baseline`."""
+    import io
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_final", "bench_default.json")))
+    assert len(json.dumps(full)) > 20000
+    full["n_gpus"] = full["world_size"] = 8
+    full["roofline"]["frac_per_rank"] = [0.66716 + i * 1e-3 for i in range(8)]
+    full["chain_kernel"]["avg_launch_ms_per_rank"] = [5.6535 + i * 1e-2 for i in range(8)]
+    full["per_rank_ms_per_step"] = [68.9 + i * 0.0123456789 for i in range(8)]
+    buf = io.StringIO()
+    saved, bench.DETAIL_FILE = bench.DETAIL_FILE, os.path.join(os.environ.get("TMPDIR", "/tmp"), "bench_detail_test.json")
+    try:
+        bench.emit(full, buf)
+        assert json.load(open(bench.DETAIL_FILE)) == full
+    finally:
+        bench.DETAIL_FILE = saved
+    out = buf.getvalue().rstrip("\n").splitlines()
+    assert len(out) == 2 and out[0].startswith("DETAIL {") and json.loads(out[0][7:]) == full
+    assert [ln for ln in out if ln.startswith("{")] == [out[-1]]
+    assert len(out[-1]) < 4096
+    line = json.loads(out[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "world_size", "backend",
+                "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "l1_vs_ref", "roofline",
+                "chain_kernel", "cpu_baseline", "l1_vs_oracle"):
+        assert key in line, key
+    assert abs(line["value"] - full["value"]) < 1e-3 * full["value"]
+    assert line["config"]["workload"] == full["config"]["workload"]
+    for key in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_per_rank", "traffic", "launches_per_step",
+                "avg_launch_ms"):
+        assert key in line["roofline"], key
+    assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-3
+    for key in ("value", "unit", "cores", "kind", "sample", "cpu_model", "one_thread", "all_physical_cores"):
+        assert key in line["cpu_baseline"], key
+    # no prose outside the contract's own strings: every other string leaf is short
+    def strings(node, path=""):
+        if isinstance(node, dict):
+            for k, v in node.items():
+                yield from strings(v, f"{path}.{k}")
+        elif isinstance(node, str):
+            yield path, node
+    assert all(len(v) <= 160 for _, v in strings(line)), [p for p, v in strings(line) if len(v) > 160]
+    # a pathological record (every optional group inflated) still yields a parsable line under the limit
+    full["l1_vs_oracle_last"] = {f"k{i}": float(i) for i in range(300)}
+    assert len(bench.final_line(full)) < 4096

@@ -8,7 +8,8 @@ TAG=${TAG:-r02}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 BENCH="python bench.py --steps ${STEPS:-5} --warmup 2 --no-cpu-baseline --no-tiers"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- $BENCH > $OUT/bench_under_trace.json 2> $OUT/trace.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- $BENCH 2> $OUT/trace.log | tail -1 > $OUT/bench_under_trace.json
+cp bench_detail.json $OUT/bench_under_trace_detail.json
 PMC="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-tiers"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -o pmc_fetch -- $PMC > /dev/null 2> $OUT/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT -o pmc_write -- $PMC > /dev/null 2> $OUT/pmc_write.log
