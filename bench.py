@@ -456,8 +456,10 @@ def mask_mean(mask):
 def timed_steps(step, steps, warmup, world, sync, reduce_device):
     """The timing protocol: `warmup` untimed steps, then exactly `steps` steps between barrier + device sync on
     both sides; returns (max over ranks, per-rank list) of the elapsed seconds."""
+    grouped = torch.distributed.is_initialized()        # (a forced single-rank group takes the collective path too)
+
     def barrier():
-        if world > 1:
+        if grouped:
             torch.distributed.barrier()
 
     out = None
@@ -472,7 +474,7 @@ def timed_steps(step, steps, warmup, world, sync, reduce_device):
     barrier()
     elapsed = time.perf_counter() - t0
     per_rank = [elapsed]
-    if world > 1:
+    if grouped:
         mine = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
         every = [torch.zeros_like(mine) for _ in range(world)]
         torch.distributed.all_gather(every, mine)
@@ -482,7 +484,7 @@ def timed_steps(step, steps, warmup, world, sync, reduce_device):
 
 def gather_floats(x, world, device):
     """One float per rank -> list over ranks (identity without a process group)."""
-    if world == 1:
+    if not torch.distributed.is_initialized():
         return [float(x)]
     mine = torch.tensor([float(x)], dtype=torch.float64, device=device)
     every = [torch.zeros_like(mine) for _ in range(world)]
@@ -511,12 +513,12 @@ def launcher_selftest(args, rank, world):
                           "roofline": {"frac": min(fracs), "frac_per_rank": fracs, "stand_in": True},
                           "metric": "launcher self-test (no forward, not a measurement)", "value": 0.0,
                           "unit": "none", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "world_size": torch.distributed.get_world_size() if world > 1 else 1,
-                          "backend": torch.distributed.get_backend() if world > 1 else "none",
+                          "world_size": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                          "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else "none",
                           "per_rank_ms_per_step": [e / args.steps * 1e3 for e in per_rank],
                           "rows_gathered": int(all_rows.shape[0]), "rank_sum": float(all_rows[:, 0].sum()),
                           "data": "none"})
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 
@@ -663,8 +665,11 @@ def main():
         # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run on
         # the loopback address; rank 0 of the children prints the JSON line on the inherited stdout
         sys.exit(self_launch(args.gpus))
+    # MVSN_BENCH_BACKEND=nccl|gloo: create the process group even for ONE rank, so that `--gpus 1` loads RCCL and sends
+    # its barriers, timings and metric rows through the collectives an N-GPU run uses (no multi-GPU box needed)
+    forced = os.environ.get("MVSN_BENCH_BACKEND") or None
     rank, world, local = mdist.init_from_env(backend="gloo" if (args.launcher_selftest or args.single_device_selftest)
-                                             else None)
+                                             else forced, force=forced is not None)
     if args.single_device_selftest:
         local = 0
     if world != args.gpus:
@@ -732,8 +737,8 @@ def main():
                 "steps": args.steps, "warmup": args.warmup, "setup_forwards": 1,
                 "ms_per_step": elapsed / args.steps * 1e3,
                 "per_rank_ms_per_step": [e / args.steps * 1e3 for e in per_rank],
-                "world_size": torch.distributed.get_world_size() if world > 1 else 1,
-                "backend": torch.distributed.get_backend() if world > 1 else "none",
+                "world_size": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else "none",
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                 "data": f"synthetic (seeded frames, pretrained {cfg['weights']} weights)",
                 "config": {"workload": cfg["what"], "name": args.config, "images_per_gpu_per_step": B,
@@ -915,7 +920,7 @@ def main():
                 if idx > 0:
                     line[key] = oracle_check(cfg, idx, idepth[idx:idx + 1].cpu())
         emit(line)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

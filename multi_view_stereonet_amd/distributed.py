@@ -13,13 +13,14 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+def init_from_env(backend: Optional[str] = None, force: bool = False) -> Tuple[int, int, int]:
     """(rank, world_size, local_rank) from torchrun's environment; initialises the process group
-    when WORLD_SIZE > 1."""
+    when WORLD_SIZE > 1 -- or, with `force`, also for a single rank (a world-size-1 "nccl" group
+    loads RCCL and sends the metric rows through its all-gather on a one-GPU box)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -39,10 +40,11 @@ def gather_metric_rows(rows: torch.Tensor, indices: torch.Tensor) -> Tuple[torch
     """All-gather (n_local, C) metric rows and their global image indices from every rank.
 
     Returns (all_rows, all_indices) sorted by image index, identical on every rank.  Works with
-    zero local rows.  With no process group it is the identity.
+    zero local rows.  With no process group it is the identity; with one -- of any size, a single
+    rank included -- the rows travel through the collective.
     """
     rows = rows.reshape(-1, rows.shape[-1]) if rows.numel() else rows.reshape(0, rows.shape[-1])
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         order = torch.argsort(indices)
         return rows[order], indices[order]
     world = dist.get_world_size()

@@ -64,3 +64,13 @@ def rel_err_per_pixel(a, ref):
         return 0.0, 0.0
     e = ((a - ref).abs() / ref.abs().clamp_min(floor))[sel]
     return float(e.max()), float(torch.quantile(e, 0.999)) if e.numel() <= (1 << 24) else float(e.sort().values[int(0.999 * (e.numel() - 1))])
+
+
+def free_port():
+    """A loopback TCP port for a torch.distributed rendezvous (127.0.0.1: the container hostname may not resolve)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p

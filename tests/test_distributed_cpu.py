@@ -54,3 +54,29 @@ def test_single_process_is_identity():
     r, i = mdist.gather_metric_rows(rows, idx)
     assert i.tolist() == [2, 5] and r.tolist() == [[1.0, 2.0], [3.0, 1.0]]
     assert mdist.shard_indices(10, 1, 4) == [1, 5, 9]
+
+
+def _single_rank_worker(rank, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r, w, _ = mdist.init_from_env(backend="gloo", force=True)
+    assert (r, w) == (0, 1) and dist.is_initialized() and dist.get_world_size() == 1
+    calls = []
+    real = dist.all_gather
+    dist.all_gather = lambda out, x, *a, **k: (calls.append(tuple(x.shape)), real(out, x, *a, **k))[1]
+    try:
+        rows = torch.tensor([[3.0, 1.0], [1.0, 2.0], [0.5, 4.0]])
+        all_rows, all_idx = mdist.gather_metric_rows(rows, torch.tensor([5, 2, 9]))
+    finally:
+        dist.all_gather = real
+    ret["rows"], ret["idx"], ret["calls"] = all_rows.clone(), all_idx.clone(), calls
+    dist.destroy_process_group()
+
+
+def test_forced_single_rank_group_goes_through_the_collective():
+    """A world-size-1 group (what `MVSN_BENCH_BACKEND=nccl python bench.py --gpus 1` creates to load RCCL on a one-GPU
+    box) must not take the no-group shortcut: counts and the (rows + index) float64 payload go through all_gather."""
+    ret = mp.Manager().dict()
+    mp.spawn(_single_rank_worker, args=(_free_port(), ret), nprocs=1, join=True)
+    assert ret["idx"].tolist() == [2, 5, 9]
+    assert ret["rows"].tolist() == [[1.0, 2.0], [3.0, 1.0], [0.5, 4.0]]
+    assert ret["calls"] == [(1,), (3, 3)]          # the count, then 3 rows x (2 columns + the index column)

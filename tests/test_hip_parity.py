@@ -1729,6 +1729,7 @@ def test_bench_real_multi_rank_line_on_one_gpu():
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
+    assert p.stdout.rstrip("\n").splitlines()[-1] == lines[0] and len(lines[0]) < 4096      # the driver parses the LAST line
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["backend"] == "gloo"
     assert line["config"]["global_batch"] == 16 and len(line["per_rank_ms_per_step"]) == 2
@@ -1737,6 +1738,83 @@ def test_bench_real_multi_rank_line_on_one_gpu():
     assert np.isfinite(l1["l1"]) and l1["max_rel_per_pixel"] < 1e-3, l1
     assert np.isfinite(line["mean_idepth"]) and line["value"] > 0 and "selftest" in line
     print("bench --gpus 2 --single-device-selftest:", lines[0][:400])
+
+
+_RCCL_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from multi_view_stereonet_amd import distributed as mdist
+rank, world, local = mdist.init_from_env(backend="nccl", force=True)      # world size 1: loads librccl, sets the device
+assert (rank, world, local) == (0, 1, 0) and dist.get_backend() == "nccl" and torch.cuda.current_device() == 0
+dev = torch.device("cuda", 0)
+seen = []
+real = dist.all_gather
+dist.all_gather = lambda out, x, *a, **k: (seen.append((tuple(x.shape), str(x.dtype), x.device.type)), real(out, x, *a, **k))[1]
+rows = torch.tensor([[0.11, 0.02, 1.5, 0.3, 0.9, 0.97, 0.99, 2.46, 8.9e-6], [0.12, 0.03, 1.6, 0.31, 0.91, 0.98, 0.995, 2.5, 9.1e-6],
+                     [0.10, 0.01, 1.4, 0.29, 0.89, 0.96, 0.985, 2.4, 8.7e-6]], dtype=torch.float32, device=dev)
+idx = torch.tensor([7, 3, 5], dtype=torch.int64, device=dev)
+all_rows, all_idx = mdist.gather_metric_rows(rows, idx)
+dist.all_gather = real
+torch.cuda.synchronize()
+assert seen == [((1,), "torch.int64", "cuda"), ((3, 10), "torch.float64", "cuda")], seen
+assert all_idx.tolist() == [3, 5, 7] and all_rows.device.type == "cuda" and all_rows.dtype == torch.float32
+assert torch.equal(all_rows.cpu(), rows.cpu()[[1, 2, 0]])
+empty_rows, empty_idx = mdist.gather_metric_rows(rows[:0], idx[:0])          # a rank whose images were all skipped
+assert empty_rows.shape == (0, 9) and empty_idx.numel() == 0
+dist.barrier()
+loaded = [ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln or "libnccl" in ln]
+assert loaded, "no RCCL library mapped into the process"
+print("RCCL_OK", os.path.basename(loaded[0]), torch.cuda.nccl.version())
+dist.destroy_process_group()
+"""
+
+
+def _clean_rank_env():
+    import os
+    from conftest import free_port
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return env
+
+
+def test_rccl_single_rank_group_carries_the_metric_rows():
+    """RCCL had never been LOADED in any round (every multi-rank test is gloo).  A world-size-1 `nccl`
+    process group on cuda:0, and `gather_metric_rows`' exact payload -- the int64 count, then float64 rows + index column, as
+    DEVICE tensors -- through `dist.all_gather`; `init_from_env`'s `torch.cuda.set_device(local)` runs too (test.py:146-164
+    is what the rows feed)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    p = subprocess.run([sys.executable, "-c", _RCCL_WORKER, ROOT], env=_clean_rank_env(), capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    assert "RCCL_OK" in p.stdout, p.stdout[-1500:]
+    print(p.stdout.strip().splitlines()[-1])
+
+
+def test_bench_single_gpu_line_over_rccl():
+    """`MVSN_BENCH_BACKEND=nccl python bench.py --gpus 1`: the measuring path itself with a world-size-1 RCCL group --
+    barriers around the timed region, the per-rank timing / roofline gathers and the metric rows all go through RCCL on
+    device tensors; the line says `backend: nccl`."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = _clean_rank_env()
+    env["MVSN_BENCH_BACKEND"] = "nccl"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--batch", "8", "--no-cpu-baseline", "--no-tiers"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = p.stdout.rstrip("\n").splitlines()
+    lines = [ln for ln in out if ln.startswith("{")]
+    assert len(lines) == 1 and out[-1] == lines[0] and len(lines[0]) < 4096, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["backend"] == "nccl" and line["world_size"] == 1 and line["n_gpus"] == 1
+    assert line["l1_vs_ref"]["max_rel_per_pixel"] < 1e-3 and np.isfinite(line["mean_idepth"]) and line["value"] > 0
+    assert len(line["roofline"]["frac_per_rank"]) == 1 and len(line["per_rank_ms_per_step"]) == 1
+    print("bench --gpus 1 over RCCL:", lines[0][:300])
 
 
 def test_forward_headline_golden_direct_chain_form():
