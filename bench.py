@@ -188,6 +188,15 @@ def final_line(full):
 def emit(full, stream=None):
     """Full record -> `bench_detail.json` next to this script and a `DETAIL <json>` stdout line; then, LAST, the compact
     JSON line (`final_line`) -- the only stdout line that starts with `{`."""
+    if stream is None:
+        # RCCL writes its NCCL_DEBUG=VERSION banner with C stdio: on a pipe it sits in libc's buffer until exit and
+        # would land AFTER the JSON line (seen on the GPU box, whose environment sets NCCL_DEBUG=VERSION) -- push
+        # whatever C code has buffered out first, so the compact line stays the last thing on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
     stream = stream or sys.stdout
     blob = json.dumps(full)
     try:
@@ -667,6 +676,8 @@ def main():
         sys.exit(self_launch(args.gpus))
     # MVSN_BENCH_BACKEND=nccl|gloo: create the process group even for ONE rank, so that `--gpus 1` loads RCCL and sends
     # its barriers, timings and metric rows through the collectives an N-GPU run uses (no multi-GPU box needed)
+    # stdout belongs to the JSON line: RCCL's debug output (the box sets NCCL_DEBUG=VERSION) goes to stderr
+    os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
     forced = os.environ.get("MVSN_BENCH_BACKEND") or None
     rank, world, local = mdist.init_from_env(backend="gloo" if (args.launcher_selftest or args.single_device_selftest)
                                              else forced, force=forced is not None)
@@ -919,10 +930,11 @@ def main():
             for key, idx in (("l1_vs_oracle_slice_b", (B + 1) // 2), ("l1_vs_oracle_last", B - 1)):
                 if idx > 0:
                     line[key] = oracle_check(cfg, idx, idepth[idx:idx + 1].cpu())
-        emit(line)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        emit(line)      # LAST: after the group is gone (nothing RCCL prints at tear-down can follow the line)
 
 
 if __name__ == "__main__":

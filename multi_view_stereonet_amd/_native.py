@@ -157,3 +157,70 @@ def check(rc: int, what: str):
     if rc != 0:
         msg = load().mvsn_last_error()
         raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+# ---- the right to launch CO-RESIDENT workgroups on a device (the banded / slab chain forms) -------------------------
+# Those forms spin on sibling workgroups: every workgroup of a launch must be on a CU at the same time, so only ONE
+# such launch may be in flight per device (include/mvsn_hip.h).  Inside a process the module orders its forwards; across
+# PROCESSES that share a GPU nothing did -- two banded launches could each hold part of the chip and time out into the
+# repair launch.  An advisory file lock keyed by the GPU's identity settles it: the first process that wants the banded
+# form on a device takes the lock for its lifetime; every other process gets `False` here and AUTO gives it the
+# single-launch forms (plane-resident Winograd / stepwise / direct), which need no co-residency and merely queue behind
+# the owner's kernels.  (Processes that cannot see each other's lock directory -- separate containers on one GPU -- are
+# still covered by the in-stream repair, multi_view_stereonet.py: check_device_status.)
+_coresident = {}      # device index -> (granted, open file or None)
+
+
+def _device_key(index: int) -> str:
+    p = torch.cuda.get_device_properties(index)
+    uuid = getattr(p, "uuid", None)
+    if uuid is not None and str(uuid).strip("0-") != "":
+        return str(uuid)
+    return "pci-%04x-%02x-%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", index),
+                                   getattr(p, "pci_device_id", 0))
+
+
+def coresident_lock_path(index: int) -> str:
+    root = os.environ.get("MVSN_LOCK_DIR") or "/tmp"
+    return os.path.join(root, "mvsn_coresident_%s.lock" % _device_key(index).replace("/", "_"))
+
+
+def coresident_right(index: int) -> bool:
+    """True if THIS process may launch the co-resident (banded / slab) chain forms on device `index`: it holds the
+    device's advisory lock (taken on first request, kept until the process exits or `release_coresident_right`).
+    MVSN_CORESIDENT_LOCK=0 switches the lock off (every process is granted; the in-stream repair is then the only
+    guard).  A lock directory that cannot be written grants too -- the pre-lock behaviour, never a silent slowdown."""
+    if index in _coresident:
+        return _coresident[index][0]
+    if os.environ.get("MVSN_CORESIDENT_LOCK", "1") == "0":
+        _coresident[index] = (True, None)
+        return True
+    import fcntl
+    try:
+        f = open(coresident_lock_path(index), "a+")
+    except OSError:
+        _coresident[index] = (True, None)
+        return True
+    try:
+        fcntl.flock(f, fcntl.LOCK_EX | fcntl.LOCK_NB)
+    except OSError:                    # another process owns the device's co-resident launches
+        f.close()
+        _coresident[index] = (False, None)
+        return False
+    try:
+        f.seek(0)
+        f.truncate()
+        f.write("%d\n" % os.getpid())
+        f.flush()
+    except OSError:
+        pass
+    _coresident[index] = (True, f)
+    return True
+
+
+def release_coresident_right(index=None):
+    """Give the lock(s) back (and forget refusals: the next request asks again)."""
+    for i in ([index] if index is not None else list(_coresident)):
+        granted, f = _coresident.pop(i, (False, None))
+        if f is not None:
+            f.close()

@@ -393,10 +393,18 @@ __global__ __launch_bounds__(SB_THREADS) void chain_slab_kernel(ChainArgs a, int
         // the row coordinate alone, by the gather's own expressions (warp_coord / bilinear_taps: the x side is dead code here)
         WarpCoord c = warp_coord(Hl, (float)xx, (float)yy, (float)rows, (float)cols);
         float iy = c.iy < 0.0f ? 0.0f : (c.iy > (float)(rows - 1) ? (float)(rows - 1) : c.iy);
-        int y0 = (int)floorf(iy);
-        if (!(y0 >= 0 && y0 < rows)) y0 = 0;
+        // CONSERVATIVE at integer boundaries: this copy of warp_coord is compiled in another context than the gather's
+        // (x side dead, whole-plane loop), and the contraction of its multiply-adds may differ in the last bits -- a
+        // coordinate within PLAN_TOL of an integer counts as BOTH rows, so the plan can say "in range" only when the
+        // gather's own floor(iy) is in range whichever way its last bit fell (a step judged slow is merely slower:
+        // the two paths produce the same bits).  |iy| <= 32 here: 1e-4 is ~26 ulps, far above any contraction difference.
+        constexpr float PLAN_TOL = 1e-4f;
+        int ya = (int)floorf(iy - PLAN_TOL), yb = (int)floorf(iy + PLAN_TOL);
+        ya = ya < 0 ? 0 : ya;
+        yb = yb > rows - 1 ? rows - 1 : yb;
+        if (!(iy >= 0.0f)) ya = yb = 0;               // NaN coordinate: the gather's y0 = 0
         const int blo = (yy / BR) * BR;
-        slow |= y0 < blo - 1 || y0 + 1 > blo + BR;   // (the unclamped + 1 row: a zero halo row at the image's edge)
+        slow |= ya < blo - 1 || yb + 1 > blo + BR;   // (the unclamped + 1 row: a zero halo row at the image's edge)
       }
     }
     if (__any(slow) && lane == 0) atomicOr(&fastw[dn & 1], 1);

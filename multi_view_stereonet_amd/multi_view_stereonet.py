@@ -205,18 +205,26 @@ class _SharedState:
         self.banded_latched = False
         self.warned = False
         self.clean = 0                 # forwards since the latch was set (it expires: a transiently shared device)
+        self.latch_forwards = self.LATCH_FORWARDS      # ... after this many forwards; doubled by every re-latch
+        self.relatches = 0
 
     # A repaired forward keeps AUTO off the banded form for this many forwards, then the form is tried again (a device that
     # was shared for a moment should not cost the module its small-batch chain for good; a device that IS shared repairs
     # one forward in LATCH_FORWARDS and latches again).  net.reset_device_status() re-arms at once.
+    # A device that stays shared would otherwise pay the spin-limit time-out (seconds) every LATCH_FORWARDS forwards for
+    # ever: every re-latch doubles the wait up to LATCH_CAP, and the warning is issued once (reset_device_status re-arms both).
     LATCH_FORWARDS = 256
+    LATCH_CAP = 1 << 16
 
     def tick(self):
         """Once per forward (after poll): lets the latch expire."""
         if self.banded_latched:
             self.clean += 1
-            if self.clean >= self.LATCH_FORWARDS:
-                self.banded_latched, self.warned, self.clean = False, False, 0
+            if self.clean >= self.latch_forwards:
+                self.banded_latched, self.clean = False, 0
+
+    def rearm(self):
+        self.banded_latched, self.warned, self.clean, self.latch_forwards, self.relatches = False, False, 0, self.LATCH_FORWARDS, 0
 
     def status_ptr(self) -> int:
         if self.words is None:
@@ -231,6 +239,9 @@ class _SharedState:
         count = int(self.words_np[1])
         fresh, self.seen = count - self.seen, count
         if fresh:
+            if self.relatches:         # repaired again after an expiry: the device IS shared -- wait longer next time
+                self.latch_forwards = min(self.latch_forwards * 2, self.LATCH_CAP)
+            self.relatches += 1
             self.banded_latched, self.clean = True, 0
             if not self.warned:
                 self.warned = True
@@ -1084,8 +1095,10 @@ class PlaneSweepEngine:
                 "stepwise": _native.CHAIN_STEPWISE, "banded": _native.CHAIN_BANDED}[self.chain_form]
         if form == _native.CHAIN_AUTO:
             form = self.lib.mvsn_incremental_cost_volume_form_for(N, rows, cols)
-            if form == _native.CHAIN_BANDED and not (self.banded_ok and not self.net_state.banded_latched):
-                # lanes on several streams (see forward): what AUTO picks once the banded form is out of reach
+            if form == _native.CHAIN_BANDED and not (self.banded_ok and not self.net_state.banded_latched
+                                                     and _native.coresident_right(dev.index)):
+                # lanes on several streams (see forward), a latched module, or ANOTHER PROCESS owning this device's
+                # co-resident launches (_native.coresident_right): what AUTO picks once the banded form is out of reach
                 form = self.lib.mvsn_incremental_cost_volume_form_for(1 << 20, rows, cols)
                 if form == _native.CHAIN_BANDED:       # (30x40 / 32x64: AUTO is the banded form at any chain count)
                     form = _native.CHAIN_STEPWISE if cols % 4 == 0 else _native.CHAIN_DIRECT
@@ -1354,7 +1367,7 @@ class MultiViewStereoNet(nn.Module):
         """Re-enable the banded chain form after check_device_status / a forward latched it off."""
         st = self.__dict__.get("_shared_state")
         if st is not None:
-            st.banded_latched, st.warned, st.clean = False, False, 0
+            st.rearm()
 
     def engine(self) -> PlaneSweepEngine:
         # The packed copies go stale when a parameter is rebound (.to(), load_state_dict: both invalidate above) or

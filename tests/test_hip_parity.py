@@ -1740,6 +1740,88 @@ def test_bench_real_multi_rank_line_on_one_gpu():
     print("bench --gpus 2 --single-device-selftest:", lines[0][:400])
 
 
+_SHARED_GPU_WORKER = r"""
+import os, sys, time, warnings
+import numpy as np, torch
+root, tag, tmp, forwards = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+from conftest import load_golden, batch_from_meta, rel_err_per_pixel
+from multi_view_stereonet_amd import MultiViewStereoNet, _native
+from multi_view_stereonet_amd import multi_view_stereonet_utils as snu
+from multi_view_stereonet_amd.weights import load_weights
+from oracle import mvsn_oracle as oracle
+torch.set_grad_enabled(False)
+warnings.simplefilter("error", RuntimeWarning)                  # a repair warns: that must not happen here
+w = load_weights("gta_sfm_150epochs")
+net = MultiViewStereoNet(); net.load_state_dict(w, strict=True); net = net.to("cuda").eval()
+fix = load_golden("g2_gta_512x256_d64_s2.npz")
+batch, D = batch_from_meta(fix["meta"])
+cpu = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
+want = oracle.forward(w, cpu["left_image_pyr"], cpu["K_pyr"], cpu["T_right_in_left"], cpu["right_image_pyr"], D)["left_idepthmap_pyr"][0]
+inp = snu.multi_view_unpack_batch(batch, torch.device("cuda"), 5)
+run = lambda: net(inp["left_image_pyr"], inp["K_pyr"], inp["T_right_in_left"], inp["right_image_pyr"], D, True, [True] * 5)
+out = run(); torch.cuda.synchronize()                           # (the first forward asks for the device's co-resident right)
+form = net.engine().last_chain_form
+open(os.path.join(tmp, tag + ".ready"), "w").close()
+t0 = time.time()
+while not all(os.path.exists(os.path.join(tmp, x + ".ready")) for x in ("a", "b")) and time.time() - t0 < 300:
+    time.sleep(0.01)
+worst = 0.0
+for i in range(forwards):                                        # both processes hammer cuda:0 at the same time
+    out = run()
+    if i % 8 == 7 or i == forwards - 1:
+        got = out["left_idepthmap_pyr"][0].cpu()
+        assert bool(torch.isfinite(got).all())
+        worst = max(worst, rel_err_per_pixel(got, want)[0], rel_err_per_pixel(got, torch.from_numpy(fix["idepth_0"]))[0])
+torch.cuda.synchronize()
+repairs = net.check_device_status()
+assert net.engine().last_chain_form == form
+print("SHARED", tag, form, repairs, "%.3e" % worst, int(_native.coresident_right(torch.cuda.current_device())), flush=True)
+open(os.path.join(tmp, tag + ".done"), "w").close()
+while not all(os.path.exists(os.path.join(tmp, x + ".done")) for x in ("a", "b")) and time.time() - t0 < 600:
+    time.sleep(0.01)                                             # (keep the lock until the other one is through)
+"""
+
+
+def test_two_processes_on_one_gpu_share_it_without_repairs(tmp_path):
+    """"one banded call per device" is ENFORCED across processes (an advisory lock keyed by the GPU's
+    identity, `_native.coresident_right`), not documented.  Two processes run batch-1 headline forwards on cuda:0 at the same
+    time: the one that asked first keeps the banded chain, the other gets the single-launch plane-resident form; both stay
+    inside the contract against the oracle AND the reference fixture on every checked forward, with 0 repaired forwards
+    (before: two banded launches could each hold part of the chip and time out into the repair launch)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    _native.release_coresident_right()            # this pytest process may hold the right from earlier tests
+    try:
+        env = dict(os.environ, MVSN_LOCK_DIR=str(tmp_path))
+        env.pop("MVSN_CORESIDENT_LOCK", None)
+        procs = {}
+        for tag in ("a", "b"):
+            procs[tag] = subprocess.Popen([sys.executable, "-c", _SHARED_GPU_WORKER, ROOT, tag, str(tmp_path), "120"],
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            if tag == "a":                        # a asks first (its ready file follows its first forward)
+                import time
+                t0 = time.time()
+                while not os.path.exists(os.path.join(str(tmp_path), "a.ready")):
+                    assert procs["a"].poll() is None and time.time() - t0 < 600, procs["a"].communicate()[1][-3000:]
+                    time.sleep(0.05)
+        res = {}
+        for tag, p in procs.items():
+            out, err = p.communicate(timeout=900)
+            assert p.returncode == 0, (tag, out[-1000:], err[-3000:])
+            ln = [x for x in out.splitlines() if x.startswith("SHARED")][-1].split()
+            res[tag] = dict(form=int(ln[2]), repairs=int(ln[3]), worst=float(ln[4]), right=int(ln[5]))
+        print("two processes on cuda:0:", res)
+        assert res["a"]["right"] == 1 and res["b"]["right"] == 0
+        assert res["a"]["form"] == _native.CHAIN_BANDED and res["b"]["form"] == _native.CHAIN_WINOGRAD
+        for tag in ("a", "b"):
+            assert res[tag]["repairs"] == 0 and res[tag]["worst"] < 1e-3, res
+    finally:
+        _native.release_coresident_right()
+
+
 _RCCL_WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
