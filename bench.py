@@ -871,7 +871,8 @@ def main():
                      "bf16 FEATURES (BASELINE config 5): the bf16-operand tier + the regulariser's intermediate volumes "
                      "STORED as bf16 (layer 0 fp32 -> bf16, layers 1-2 bf16 -> bf16, layer 3 bf16 -> fp32; fp32 "
                      "accumulation and GroupNorm statistics); NOT within the 1e-3 parity contract")):
-                eng.conv_precision = tier
+                eng.conv_precision = tier      # (= net.options.conv_precision: the engine's switches ARE the module's
+                #                                  options object, so the tier is part of every recorded plan's key)
                 for _ in range(max(1, args.warmup)):
                     out_t = step()
                 torch.cuda.synchronize()

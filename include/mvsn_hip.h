@@ -128,8 +128,14 @@ size_t mvsn_incremental_cost_volume_workspace_bytes(int n_chains, int rows, int 
                                                                                              features (always, since ABI 3) + the
                                                                                              activation planes that do not fit LDS */
 int mvsn_incremental_cost_volume_form(int rows, int cols);   /* the fused form of this grid: WINOGRAD or DIRECT */
-/* what MVSN_CHAIN_AUTO resolves to for this many chains on this grid (BANDED, WINOGRAD, STEPWISE or DIRECT), and the
- * workspace `form` (AUTO allowed) needs for num_idepth_samples planes */
+/* what MVSN_CHAIN_AUTO resolves to for this many chains on this grid (BANDED, WINOGRAD, STEPWISE or DIRECT) in the
+ * entry points that put a repair launch behind a banded call (mvsn_incremental_cost_volume_guarded / _bf16), and the
+ * workspace `form` needs for num_idepth_samples planes (AUTO allowed: enough for either entry point).
+ * The PLAIN mvsn_incremental_cost_volume has no repair launch, so its AUTO is more conservative: on 30x40 / 32x64 it
+ * takes the banded form only while the chains fit ONE thin-band pass (17 / 16 chains on 256 CUs) and the
+ * co-residency-free STEPWISE form (DIRECT for cols % 4 != 0) beyond -- the multi-pass slab plan holds the whole device
+ * for milliseconds and a time-out without repair would leave NaN in the cost slice.  Ask for MVSN_CHAIN_BANDED (or use
+ * the guarded entry) to get the slab plan. */
 int mvsn_incremental_cost_volume_form_for(int n_chains, int rows, int cols);
 size_t mvsn_incremental_cost_volume_workspace_bytes_for(int n_chains, int num_idepth_samples, int rows, int cols,
                                                         int form);

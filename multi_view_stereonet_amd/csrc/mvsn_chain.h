@@ -131,7 +131,7 @@ int chain_band_launch(const ChainArgs &a, int n_chains, void *workspace, size_t 
                       hipStream_t stream);
 
 // Slab plans of the banded form (mvsn_chain_slab.hip): a few fat bands per chain, 512-thread workgroups -- what the
-// banded dispatcher launches once more chains are in flight than two passes of the thin-band plan hold
+// banded dispatcher launches once more chains are in flight than ONE pass of the thin-band plan holds
 struct SlabPlan {
   int G, threads;
   size_t chain_u64, lds_bytes;

@@ -606,19 +606,18 @@ extern "C" size_t mvsn_incremental_cost_volume_workspace_bytes(int n_chains, int
   return (size_t)n_chains * (act_floats + mv_floats) * sizeof(float);
 }
 
-// What MVSN_CHAIN_AUTO resolves to for this many chains on this coarse grid.
+// What MVSN_CHAIN_AUTO resolves to for this many chains on this coarse grid -- in the entry points that put a gated repair
+// launch behind a banded call (mvsn_incremental_cost_volume_guarded / _bf16; what the module calls).
 static int chain_auto_form(int n_chains, int rows, int cols) {
-  // few chains on a grid with a banded plan: several workgroups per chain.  Where a plane-resident plan exists
-  // (16x32) only while all of them fit the chip at once; on the 30x40 / 32x64 grids also as two consecutive passes
-  // (measured, MI355X: 32 chains 5.1 / 7.1 ms against the stepwise form's 7.3 / 10.4 ms; three passes tie with it)
   if (mvsn::chain_band_supported(rows, cols)) {
     // 30x40 / 32x64 (no plane-resident plan): the banded form for any number of chains -- thin bands while they fit one
     // pass, the slab plan (3 / 4 fat bands per chain resident in LDS, mvsn_chain_slab.hip) beyond; the stepwise form, which
     // sends the plane through HBM every step, is no longer AUTO's choice there
     if (!mvsn::chain_wino_supported(rows, cols)) return MVSN_CHAIN_BANDED;
+    // 16x32: several workgroups per chain only while all chains fit the chip in ONE pass (beyond 64 chains the
+    // plane-resident kernel is faster)
     const int cap = mvsn::chain_band_chains_per_pass(rows, cols);
-    const int passes = cap > 0 ? (n_chains + cap - 1) / cap : 1 << 20;
-    if (passes <= (mvsn::chain_wino_supported(rows, cols) ? 1 : 2)) return MVSN_CHAIN_BANDED;
+    if (cap > 0 && n_chains <= cap) return MVSN_CHAIN_BANDED;
   }
   if (mvsn::chain_wino_supported(rows, cols)) return MVSN_CHAIN_WINOGRAD;
   // no plane-resident plan: one plane per round of full-chip launches, whatever the number of chains (re-measured in
@@ -626,6 +625,19 @@ static int chain_auto_form(int n_chains, int rows, int cols) {
   // the direct form -- one workgroup per chain, planes in a global workspace -- remains for cols % 4 != 0)
   if (mvsn::chain_steps_supported(rows, cols)) return MVSN_CHAIN_STEPWISE;
   return MVSN_CHAIN_DIRECT;
+}
+
+// ... and in the PLAIN entry point (mvsn_incremental_cost_volume), which has no repair launch behind it: the multi-pass
+// slab launches need the device to themselves for milliseconds at a stretch and a time-out there would leave a
+// NaN-poisoned cost slice, so beyond ONE thin-band pass the plain AUTO stays on the co-residency-free forms (the
+// round-4 policy).  A caller that wants the slab plan asks for MVSN_CHAIN_BANDED or uses the guarded entry.
+static int chain_auto_form_unguarded(int n_chains, int rows, int cols) {
+  const int form = chain_auto_form(n_chains, rows, cols);
+  if (form == MVSN_CHAIN_BANDED && !mvsn::chain_wino_supported(rows, cols)) {
+    const int cap = mvsn::chain_band_chains_per_pass(rows, cols);
+    if (cap <= 0 || n_chains > cap) return mvsn::chain_steps_supported(rows, cols) ? MVSN_CHAIN_STEPWISE : MVSN_CHAIN_DIRECT;
+  }
+  return form;
 }
 
 extern "C" int mvsn_incremental_cost_volume_form_for(int n_chains, int rows, int cols) {
@@ -636,7 +648,12 @@ extern "C" int mvsn_incremental_cost_volume_form_for(int n_chains, int rows, int
 extern "C" size_t mvsn_incremental_cost_volume_workspace_bytes_for(int n_chains, int num_idepth_samples, int rows,
                                                                    int cols, int form) {
   if (n_chains <= 0 || rows <= 0 || cols <= 0 || num_idepth_samples <= 0) return 0;
-  if (form == MVSN_CHAIN_AUTO) form = chain_auto_form(n_chains, rows, cols);
+  if (form == MVSN_CHAIN_AUTO) {      // whichever entry point resolves it (they differ beyond one thin-band pass)
+    const int fg = chain_auto_form(n_chains, rows, cols), fu = chain_auto_form_unguarded(n_chains, rows, cols);
+    const size_t g = mvsn_incremental_cost_volume_workspace_bytes_for(n_chains, num_idepth_samples, rows, cols, fg);
+    const size_t u = fu == fg ? g : mvsn_incremental_cost_volume_workspace_bytes_for(n_chains, num_idepth_samples, rows, cols, fu);
+    return g > u ? g : u;
+  }
   if (form == MVSN_CHAIN_STEPWISE) return mvsn::chain_steps_workspace_bytes(n_chains, num_idepth_samples, rows, cols);
   if (form == MVSN_CHAIN_BANDED) return mvsn::chain_band_workspace_bytes(n_chains, rows, cols);
   if (form == MVSN_CHAIN_WINOGRAD) return 0;
@@ -677,7 +694,7 @@ static int chain_run(const float *src_image_lvl4, const float *H_lvl4, const flo
   MVSN_REQUIRE(n_chains > 0 && batch > 0 && num_idepth_samples >= 1 && rows > 0 && cols > 0, MVSN_E_BADARG,
                "mvsn_incremental_cost_volume: bad sizes");
   MVSN_REQUIRE(form >= 0 && form <= 4, MVSN_E_BADARG, "mvsn_incremental_cost_volume: form must be 0 .. 4");
-  if (form == MVSN_CHAIN_AUTO) form = chain_auto_form(n_chains, rows, cols);
+  if (form == MVSN_CHAIN_AUTO) form = chain_auto_form_unguarded(n_chains, rows, cols);   // (the guarded entries resolve AUTO themselves)
   MVSN_REQUIRE(form != MVSN_CHAIN_WINOGRAD || chain_wino_supported(rows, cols), MVSN_E_TOOLARGE,
                "mvsn_incremental_cost_volume: no Winograd plan for a %dx%d coarse grid", rows, cols);
   const bool wino = form == MVSN_CHAIN_WINOGRAD || (form == MVSN_CHAIN_AUTO && chain_wino_supported(rows, cols));

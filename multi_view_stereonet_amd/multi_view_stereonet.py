@@ -613,7 +613,13 @@ class PlaneSweepEngine:
                        _native.stream(), flops=2.0 * c.cin * taps * c.cout * out[:, 0].numel(), nbytes=nbytes)
         stats = None
         if want_stats:
-            if lazy_stats and n <= self.lazy_stats_max_samples and partials.shape[1] <= self.lazy_stats_max_records:
+            # (records handed to the consumer are reduced in the ONE-workgroup order; the finalize launch switches to the
+            # sliced order above a record count the library decides: a sample's statistics must not depend on which of
+            # the two ran -- planned vs eager, batch 1 vs 8 --, so the lazy path ends where the sliced order begins
+            # whatever lazy_stats_max_records says)
+            if (lazy_stats and n <= self.lazy_stats_max_samples and partials.shape[1] <= self.lazy_stats_max_records
+                    and not (self.split_finalize and
+                             self.lib.mvsn_groupnorm_finalize_split_workspace_bytes(n, partials.shape[1]))):
                 stats = _Records(partials)
             else:
                 stats = self.finalize_stats(partials)

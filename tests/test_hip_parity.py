@@ -1010,6 +1010,54 @@ def test_slab_chain_gather_paths_vs_oracle(kind, N, D, grid, extra):
     assert torch.equal(got["banded"][1], got[other][1])
 
 
+@pytest.mark.parametrize("grid,N", [((30, 40), 24), ((32, 64), 20), ((30, 40), 12), ((16, 32), 80)])
+def test_plain_entry_auto_stays_off_the_slab_plan(grid, N):
+    """the PLAIN C entry point has no repair launch behind a banded call, so its MVSN_CHAIN_AUTO must not pick
+    the multi-pass slab plan (a time-out there leaves NaN): beyond one thin-band pass it runs the stepwise form, word for
+    word what an explicit MVSN_CHAIN_STEPWISE call returns; within one pass it is the thin bands; and the AUTO workspace
+    figure covers whichever entry point resolves it."""
+    net = net_for("gta_sfm_150epochs")
+    eng = net.engine()
+    lib = eng.lib
+    r4, c4 = grid
+    D = 5
+    g = torch.Generator().manual_seed(41)
+    H, Hinc = _motion_family(N, D, "small", seed=4)
+    src, H, Hinc, f0, fl = [x.to(DEV) for x in (torch.rand(N, 3, r4, c4, generator=g) * 2 - 1, H, Hinc,
+                                                 torch.randn(N, 32, r4, c4, generator=g), torch.randn(N, 32, r4, c4, generator=g))]
+    thin_cap = 256 // lib.mvsn_incremental_cost_volume_banded_groups(1, r4, c4)
+    if grid == (16, 32):
+        want = _native.CHAIN_WINOGRAD                      # (plane-resident plan: never the slab question)
+    else:
+        want = _native.CHAIN_BANDED if N <= thin_cap else _native.CHAIN_STEPWISE
+        assert lib.mvsn_incremental_cost_volume_form_for(N, r4, c4) == _native.CHAIN_BANDED     # the guarded entries' AUTO
+    need = {f: lib.mvsn_incremental_cost_volume_workspace_bytes_for(N, D, r4, c4, f) for f in (0, want, _native.CHAIN_BANDED)}
+    assert need[0] >= need[want] and (grid == (16, 32) or need[0] >= need[_native.CHAIN_BANDED])
+
+    def run(form):
+        cost = torch.full((N, 32, D, r4, c4), float("nan"), device=DEV)
+        mask = torch.zeros((N, D, r4, c4), dtype=torch.bool, device=DEV)
+        nbytes = lib.mvsn_incremental_cost_volume_workspace_bytes_for(N, D, r4, c4, form)
+        ws = torch.zeros(max(nbytes, 16), dtype=torch.uint8, device=DEV)
+        rc = lib.mvsn_incremental_cost_volume(_native.ptr(src), _native.ptr(H), _native.ptr(Hinc), _native.ptr(f0),
+                                              _native.ptr(fl), _native.ptr(eng.refiner_packed), N, N, D, r4, c4,
+                                              _native.ptr(cost), _native.ptr(mask), None, _native.ptr(ws), nbytes, form,
+                                              _native.stream())
+        _native.check(rc, "mvsn_incremental_cost_volume")
+        torch.cuda.synchronize()
+        return cost, mask
+
+    auto_cost, auto_mask = run(_native.CHAIN_AUTO)
+    same_cost, same_mask = run(want)
+    assert bool(torch.isfinite(auto_cost).all())
+    assert torch.equal(auto_cost, same_cost) and torch.equal(auto_mask, same_mask)
+    if want == _native.CHAIN_STEPWISE:                       # the slab plan (explicit BANDED) agrees to rounding only
+        slab_cost, slab_mask = run(_native.CHAIN_BANDED)
+        assert torch.equal(slab_mask, auto_mask)
+        mean_rel, max_rel = rel_err(slab_cost.cpu(), auto_cost.cpu())
+        assert mean_rel < 1e-5 and max_rel < 1e-3, (mean_rel, max_rel)
+
+
 @pytest.mark.parametrize("grid,N,D", [((30, 40), 90, 4), ((32, 64), 70, 4), ((30, 40), 40, 5)])
 def test_slab_chain_selected_for_many_chains_and_in_passes(grid, N, D):
     """Beyond two passes of the thin-band plan (34 / 32 chains on 256 CUs) the banded form runs the slab plan, and more
