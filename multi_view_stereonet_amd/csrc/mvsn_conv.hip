@@ -1092,7 +1092,7 @@ extern "C" int mvsn_conv_num_tiles(const mvsn_conv_desc *desc) {
   // number of GroupNorm partial records per sample: one per (tile, wave, 16-lane row)
   if (desc && desc->precision == MVSN_CONV_FP32_WINO) {
     mvsn::WinoGeom wg;
-    return mvsn::wino_geom(desc, &wg) ? wg.D * wg.tiles * 32 : 0;   // per (plane,) tile: 8 waves x 4 lane rows
+    return mvsn::wino_geom(desc, &wg) ? (int)(mvsn::wino_items(wg) * 32) : 0;   // per (plane,) tile: 8 waves x 4 lane rows
   }
   if (desc && (desc->precision == MVSN_CONV_BF16X3 || desc->precision == MVSN_CONV_BF16)) {
     mvsn::Bf16x3Geom bg;

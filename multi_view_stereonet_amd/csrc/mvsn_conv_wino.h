@@ -12,10 +12,13 @@ struct WinoGeom {
   int D;      // planes per sample (1 for the 2-D layers)
   bool vol;   // 3 x 3 x 3 layer (volume form)
   bool s2;    // 5 x 5 stride-2 layer on the input's four phases
-  bool wide;  // volume form on planes 32 < W <= 40 columns wide: tiles of 10 rows x the whole width (see conv_wino_kernel)
+  int wide;   // volume form on planes 32 < W <= 40 columns wide: 1 = tiles of 10 rows x the whole width, 2 = rolling strips
+              // of six patch rows through the sample's planes (`tiles` = items per SAMPLE there; see conv_wino_kernel)
   int nty, ntx, tiles, nchunks;
   size_t packed_floats;
 };
+// work items (one per workgroup visit, 32 GroupNorm records each) of a sample
+inline long wino_items(const WinoGeom &g) { return g.wide == 2 ? (long)g.tiles : (long)g.D * g.tiles; }
 
 bool wino_geom(const mvsn_conv_desc *d, WinoGeom *g);
 int wino_pack(const mvsn_conv_desc *d, const float *weight, float *packed, hipStream_t stream);

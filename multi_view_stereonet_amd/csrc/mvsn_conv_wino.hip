@@ -207,6 +207,8 @@ struct WinoArgs {
   size_t bs0, cs0;   // block 0: floats between samples / between channels (cb0 * plane, plane when contiguous)
   int rev;           // walk the work items from the last to the first (placement only: results are identical)
   int D;   // planes per sample (volume form; 1 for the 2-D layers)
+  int pr;  // WIDE == 2: patch rows per plane, (H + 1) / 2 (there `tiles` = work items per SAMPLE, see conv_wino_kernel)
+  WinoDiv fd_pr;
 };
 
 // A normalise / activate / add pass over ANOTHER tensor that this launch's waves carry along (template RIDE = 256-float
@@ -265,8 +267,18 @@ __global__ void wino_pack_kernel(const float *__restrict__ w, int cin, int cout,
 //         width a plane is 3 tiles of 5 x 20 = 100 patches: 78 %.  The 128 patch slots of a tile are dealt row-major
 //         (slot q = 16 wave + lane & 15 -> patch row q / 20, column q % 20; slots >= 100 idle): only the lane -> patch
 //         map, the tile constants and the epilogue's per-lane validity differ.
+// WIDE 2  ROLLING strips (round 6): the patch rows of a sample's planes are numbered through, R = z * PR + patch row
+//         (PR = (H + 1) / 2), and a work item is the SIX consecutive rows R = 6 t .. 6 t + 5 x the whole width = 120 of the
+//         128 slots -- wherever they fall: s of them at the bottom of plane zA, the other 6 - s at the top of plane
+//         zA + 1.  A 30 x 40 plane (PR = 15) costs 2.5 items instead of 3 (94 % of the slots instead of 78 %).  The raw
+//         tile has 15 rows: rows yA0 - 1 .. of plane zA + kz - 1 for the A part, ONE zero row that is both the A part's
+//         row H [+ 1] and the B part's row -1, then rows 0 .. of plane zA + kz; both parts of a step come from one
+//         descriptor that starts at plane zA + kz - 1 (planes are contiguous), a B lane's offset being one plane further.
+//         Per item only s changes: the lane's first raw row (ya: one row further down for B patches), the DMA plan
+//         and the epilogue's per-lane plane / row.  Items never span samples (a sample's last item may be short).
 constexpr int WN_WIDE_TY = 10, WN_WIDE_TX = 40, WN_WIDE_PC = WN_WIDE_TX / 2, WN_WIDE_NP = (WN_WIDE_TY / 2) * WN_WIDE_PC;
-template <int MODE, int KS, int NSTAGE, int DIL, bool VOL = false, int RIDE = 0, bool WIDE = false>
+constexpr int WN_ROLL_PR = 6, WN_ROLL_NP = WN_ROLL_PR * WN_WIDE_PC, WN_ROLL_HY = 2 * WN_ROLL_PR + 3;
+template <int MODE, int KS, int NSTAGE, int DIL, bool VOL = false, int RIDE = 0, int WIDE = 0>
 __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, const float *__restrict__ in,
                                                                   const float *__restrict__ upk,
                                                                   const float *__restrict__ bias,
@@ -288,10 +300,13 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   constexpr bool LDS_BARRIER = !VOL;               // see wn_barrier (r4: with the LDS-only barrier the volume form carrying a
                                                    // pass is no faster either: 14.6 vs 14.4 ms per step for the six carriers)
 #endif
-  static_assert(!WIDE || (VOL && DIL == 1), "wide tiles: volume form only");
-  constexpr int TY = WIDE ? WN_WIDE_TY : WN_TY, TX = WIDE ? WN_WIDE_TX : WN_TX;
-  constexpr int PA = wn_pa(DIL), XS = TX + 2 * PA, DQ = XS / 4, GROUPS = (TY + 2 * DIL) * DQ, PIECES = (GROUPS + 63) / 64;
-  constexpr int RCST = (TY + 2 * DIL) * XS + 16;
+  static_assert(!WIDE || (VOL && DIL == 1 && MVSN_WN_TRANSPOSED), "wide tiles: volume form only (transposed epilogue)");
+  constexpr bool ROLL = WIDE == 2;
+  constexpr int TY = ROLL ? 2 * WN_ROLL_PR : (WIDE ? WN_WIDE_TY : WN_TY), TX = WIDE ? WN_WIDE_TX : WN_TX;
+  constexpr int HY = ROLL ? WN_ROLL_HY : TY + 2 * DIL;   // raw rows (ROLL: two parts around one shared zero row)
+  constexpr int NP = ROLL ? WN_ROLL_NP : WN_WIDE_NP;     // WIDE: patches among the tile's 128 slots
+  constexpr int PA = wn_pa(DIL), XS = TX + 2 * PA, DQ = XS / 4, GROUPS = HY * DQ, PIECES = (GROUPS + 63) / 64;
+  constexpr int RCST = HY * XS + 16;
   static_assert(WIDE || (XS == wn_xs(DIL) && GROUPS == wn_groups(DIL) && PIECES == wn_pieces(DIL) && RCST == wn_rcst(DIL)), "");
   constexpr int STAGE = KS * 4 * RCST;               // ring stage (floats)
   float *U = smem + NSTAGE * STAGE;                  // nchunks * WN_UFLOATS, resident (VOL: ring of NSTAGE steps)
@@ -310,7 +325,14 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const size_t plane = (size_t)g.H * g.W;
-  const int ptiles = g.D * g.tiles;                  // tiles per sample (VOL: planes x tiles)
+  const int ptiles = ROLL ? g.tiles : g.D * g.tiles; // work items per sample (VOL: planes x tiles; ROLL: rolling strips)
+  // ROLL: item t of a sample -> plane zA of its first patch row, that row prA0 inside the plane, rows s taken from zA
+  auto roll_item = [&](int t, int &zA, int &prA0, int &sA) {
+    const int R0 = t * WN_ROLL_PR;
+    zA = wdiv(R0, g.fd_pr);
+    prA0 = R0 - zA * g.pr;
+    sA = g.pr - prA0 < WN_ROLL_PR ? g.pr - prA0 : WN_ROLL_PR;
+  };
   const int total = g.n * ptiles;                    // work items in (image, [plane,] tile) order
   const int G = gridDim.x;
   // item of this workgroup in round r: r * G + an XCD-contiguous slot (neighbouring tiles share halo lines in one L2)
@@ -353,19 +375,25 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   int pf_round = 0, pf_chunk = 0, pf_stage = 0;
   int pf_goff[PER];
   int pf_n = 0, pf_z = 0;
+  unsigned pf_isb = 0;   // ROLL: which of this lane's pieces belong to the B part (plane zA + 1)
   bool pf_live = slot < total;
   int rd_young = 0;   // RIDE: DMA pieces this wave has issued since its carried loads
   auto pf_plan = [&]() {   // DMA plan of the prefetcher's current item
     const int flat = g.rev ? total - 1 - (pf_round * G + slot) : pf_round * G + slot;
     const int n = flat / ptiles;
     int tile = flat - n * ptiles;
-    if constexpr (VOL) {
+    int r_pr0 = 0, r_s = WN_ROLL_PR;
+    if constexpr (ROLL) {
+      roll_item(tile, pf_z, r_pr0, r_s);
+      tile = 0;
+    } else if constexpr (VOL) {
       pf_z = tile / g.tiles;
       tile -= pf_z * g.tiles;
     }
-    const int tyi = wdiv(tile, g.fd_ntx), txi = tile - tyi * g.ntx;
-    const int y0 = tyi * TY, x0 = txi * TX;
+    const int tyi = ROLL ? 0 : wdiv(tile, g.fd_ntx), txi = tile - tyi * g.ntx;
+    const int y0 = ROLL ? 2 * r_pr0 : tyi * TY, x0 = txi * TX;
     pf_n = n;
+    pf_isb = 0;
     // (the pieces' rows / columns are re-derived per tile from an opaque copy of the lane id: hoisted out of the tile
     // loop they occupy six registers for the whole launch -- spilled, and reloaded per step, in the carrying kernels)
     int lo;   // (from the hardware, not from `lane`: that one gets spilled around the loops, and a reload here waits vmcnt(0))
@@ -374,8 +402,17 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     for (int i = 0; i < PER; ++i) {
       const int e = (dp0 + i) * 64 + lo;
       const int row = e / DQ, q = e - row * DQ;
-      const int gy = y0 - DIL + row, gx = x0 - PA + 4 * q;
-      pf_goff[i] = (i < dpn && e < GROUPS && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) ? (gy * g.W + gx) * (MVSN_WN_BUFDMA ? 4 : 1) : -1;
+      int gy = y0 - DIL + row;
+      const int gx = x0 - PA + 4 * q;
+      bool isb = false;
+      if constexpr (ROLL) {   // raw rows 0 .. 2 s: plane zA from its row y0 - 1; row 2 s + 1: zero; then plane zA + 1 from row 0
+        isb = r_s < WN_ROLL_PR && row >= 2 * r_s + 1;
+        if (isb) gy = row - (2 * r_s + 2);
+        pf_isb |= (isb ? 1u : 0u) << i;
+      }
+      const bool ok = i < dpn && e < GROUPS && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W;
+      // (a B piece outside the image: 0x80000000 -- still out of range once the plane shift is added in pf_issue)
+      pf_goff[i] = ok ? (gy * g.W + gx) * (MVSN_WN_BUFDMA ? 4 : 1) : (isb ? (int)0x80000000u : -1);
     }
   };
   auto pf_issue = [&]() {   // issue the DMA of the prefetcher's step and advance it
@@ -383,7 +420,15 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     rd_young += PER;
     bool cok;
     const float *src;
-    if constexpr (VOL) {   // step = (depth tap, 8 channels): plane pf_z + kz - 1 of channel c, zeros outside the volume
+    unsigned bshift = 0, rbytes = 0;   // ROLL: byte offset of the B part's plane from `src`; bytes the descriptor covers
+    if constexpr (ROLL) {   // A part: plane zz = zA + kz - 1, B part: plane zz + 1; one descriptor from the first that exists
+      const int kz = pf_chunk >> 2, c = (pf_chunk & 3) * 8 + dch, zz = pf_z + kz - 1;
+      cok = zz >= 0 && zz < g.D;                                  // the A part's plane exists
+      const bool cokb = zz + 1 < g.D;                             // the B part's (zz >= -1)
+      src = in + (((size_t)pf_n * 32 + c) * g.D + (zz > 0 ? (zz < g.D ? zz : 0) : 0)) * plane;
+      bshift = zz >= 0 ? (unsigned)plane * 4u : 0u;
+      rbytes = zz >= g.D ? 0u : (cokb ? bshift + (unsigned)plane * 4u : (cok ? (unsigned)plane * 4u : 0u));
+    } else if constexpr (VOL) {   // step = (depth tap, 8 channels): plane pf_z + kz - 1 of channel c, zeros outside the volume
       const int kz = pf_chunk >> 2, c = (pf_chunk & 3) * 8 + dch, zz = pf_z + kz - 1;
       cok = zz >= 0 && zz < g.D;
       src = in + (((size_t)pf_n * 32 + c) * g.D + (cok ? zz : 0)) * plane;
@@ -396,12 +441,20 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
                    : g.in2 + ((size_t)pf_n * (g.cin - g.cb0 - g.cb1) + c2) * plane;
     }
     float *dst = smem + pf_stage * STAGE + dch * RCST + SHIFT + CSHIFT * (dch & 1);
-    const unsigned pbytes = cok ? (unsigned)plane * 4u : 0u;   // (uniform) an empty descriptor: zeros for every lane
+    const unsigned pbytes = ROLL ? rbytes : (cok ? (unsigned)plane * 4u : 0u);   // (uniform) an empty descriptor: zeros for every lane
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       if (i < dpn) {   // uniform
         if ((dp0 + i) * 64 + lane < GROUPS) {   // lanes past the tile's last 16-byte group stay out of the slot
-          if constexpr (MVSN_WN_BUFDMA) {
+          if constexpr (ROLL) {
+            static_assert(!ROLL || MVSN_WN_BUFDMA, "rolling strips: descriptor DMA only");
+            // B lanes: one plane further (where the descriptor starts at the A part's plane); A lanes of a plane that
+            // does not exist (zz = -1: the descriptor starts at the B part's plane) are sent out of range
+            const bool lb = (pf_isb >> i) & 1u;
+            unsigned off = (unsigned)pf_goff[i] + (lb ? bshift : 0u);
+            if (!cok && !lb) off = 0xFFFFFFFFu;
+            wn_dma16_buf<ASM_DMA>(src, pbytes, off, dst + (dp0 + i) * 256);
+          } else if constexpr (MVSN_WN_BUFDMA) {
             wn_dma16_buf<ASM_DMA>(src, pbytes, (unsigned)pf_goff[i], dst + (dp0 + i) * 256);   // byte offset; -1: out of range
           } else {
             const float *p = (cok && pf_goff[i] >= 0) ? src + pf_goff[i] : zero;
@@ -445,10 +498,12 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   const int pcol = lane & 15, kc = lane >> 4;   // this lane's patch column / channel within the chunk; patch row = wave
   // first output row / column of patch row `wave` / patch column `pcol` inside the tile (the second is + DIL)
   int ya = (wave / DIL) * 2 * DIL + wave % DIL, xa = (pcol / DIL) * 2 * DIL + pcol % DIL;
-  if constexpr (WIDE) {   // slot q of the tile -> patch (q / 20, q % 20); idle slots read patch 0 (their outputs are never stored)
-    const int q = wave * 16 + pcol, qq = q < WN_WIDE_NP ? q : 0;
+  int lane_pr = 0;        // WIDE: this lane's patch row inside the tile
+  if constexpr (WIDE != 0) {   // slot q of the tile -> patch (q / 20, q % 20); idle slots read patch 0 (their outputs are never stored)
+    const int q = wave * 16 + pcol, qq = q < NP ? q : 0;
     const int pr = qq / WN_WIDE_PC;
-    ya = 2 * pr, xa = 2 * (qq - pr * WN_WIDE_PC);
+    lane_pr = pr;
+    ya = 2 * pr, xa = 2 * (qq - pr * WN_WIDE_PC);   // (ROLL: ya is set per item by tr_setup -- B patches sit one raw row further down)
   }
   const int my_items = slot < total ? (total - slot + G - 1) / G : 0;
   const int total_steps = my_items * nsteps;
@@ -484,6 +539,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   // the image keep their zeros, as the padding of the materialised tensor would be.
   int xf_round = 0, xf_chunk = 0, xf_stage = 0;
   unsigned xf_mask = 0;            // which of this wave's pieces of the current tile lie inside the image
+  unsigned xf_maska = 0, xf_maskb = 0;   // ROLL: ... of the A part / of the B part (xf_mask = those whose plane exists this step)
   float xf_sc = 0.f, xf_sh = 0.f;  // scale / shift of this wave's channel of the current step
   bool xf_on = false;
   auto xf_prepare = [&]() {        // parameters of the step the in-LDS side handles next (issued one step early)
@@ -494,22 +550,36 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       if (!xf_on) return;
       const int n = flat / ptiles;
       int tile = flat - n * ptiles, z = 0;
-      if constexpr (VOL) {
+      int r_pr0 = 0, r_s = WN_ROLL_PR;
+      if constexpr (ROLL) {
+        roll_item(tile, z, r_pr0, r_s);
+        tile = 0;
+      } else if constexpr (VOL) {
         z = tile / g.tiles;
         tile -= z * g.tiles;
       }
       if (xf_chunk == 0) {
-        const int tyi = wdiv(tile, g.fd_ntx), txi = tile - tyi * g.ntx;
-        const int y0 = tyi * TY, x0 = txi * TX;
+        const int tyi = ROLL ? 0 : wdiv(tile, g.fd_ntx), txi = tile - tyi * g.ntx;
+        const int y0 = ROLL ? 2 * r_pr0 : tyi * TY, x0 = txi * TX;
         xf_mask = 0;
+        xf_maska = xf_maskb = 0;
         int lo;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lo));
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
           const int e = (dp0 + i) * 64 + lo;
           const int row = e / DQ, q = e - row * DQ;
-          const int gy = y0 - DIL + row, gx = x0 - PA + 4 * q;
-          if (i < dpn && e < GROUPS && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) xf_mask |= 1u << i;
+          int gy = y0 - DIL + row;
+          const int gx = x0 - PA + 4 * q;
+          bool isb = false;
+          if constexpr (ROLL) {
+            isb = r_s < WN_ROLL_PR && row >= 2 * r_s + 1;
+            if (isb) gy = row - (2 * r_s + 2);
+          }
+          if (i < dpn && e < GROUPS && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W) {
+            if constexpr (ROLL) (isb ? xf_maskb : xf_maska) |= 1u << i;
+            else xf_mask |= 1u << i;
+          }
         }
       }
       int c = xf_chunk * (KS * 4) + dch;   // wave-uniform: scalar loads
@@ -518,6 +588,11 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         const int zz = z + (xf_chunk >> 2) - 1;
         c = (xf_chunk & 3) * 8 + dch;
         live = zz >= 0 && zz < g.D;
+        if constexpr (ROLL) {   // per part: the A part's plane zz, the B part's zz + 1
+          const bool liveb = zz + 1 < g.D;
+          xf_mask = (live ? xf_maska : 0u) | (liveb ? xf_maskb : 0u);
+          live = live || liveb;
+        }
       }
       if (live) {
         const float mean = in_stats[((size_t)n * 4 + (c >> 3)) * 2 + 0];
@@ -557,7 +632,19 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
 
   // ---- transform side: runs one step ahead of the multiplies (its tile may already be the next one)
   int tr_round = 0, tr_chunk = 0, tr_stage = 0;
-  auto tr_setup = [&]() {};   // (nothing per tile on this side: MODE 1 is applied in LDS by the fetching wave)
+  // (nothing per tile on this side -- MODE 1 is applied in LDS by the fetching wave -- except ROLL: the lane's first raw
+  // row depends on how the item splits)
+  auto tr_setup = [&]() {
+    if constexpr (ROLL) {
+      const int lin = tr_round * G + slot;
+      if (lin < total) {
+        const int flat = g.rev ? total - 1 - lin : lin;
+        int zA, prA0, sA;
+        roll_item(flat - (flat / ptiles) * ptiles, zA, prA0, sA);
+        ya = 2 * lane_pr + (lane_pr >= sA ? 1 : 0);
+      }
+    }
+  };
   // the 4 x 4 patch of (channel kc, patch pcol of patch row wave) of the transform side's step, transformed:
   // the result IS the A fragment of the 16 coefficient GEMMs
   // raw patch as loaded, d[h][row][slot]:
@@ -836,24 +923,33 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   // GroupNorm records: the 16 lanes of row gq hold, per cout tile t, 4 couts x 4 outputs of group 2 t + (gq >> 1) for
   // their 16 patches: one record per (wave, gq) as before, with data for two of its four groups and count 0 for the
   // others (gn_finalize adds cnt, cnt * mean, M2 + cnt * mean^2: an empty group contributes nothing).
-  auto finish_tile_tr = [&](int n, int z, int tile_id, int y0, int x0) {
+  // (ROLL: z = the A part's plane, y0 = its first output row, r_s = patch rows it holds; tile_id = the item of the sample)
+  auto finish_tile_tr = [&](int n, int z, int tile_id, int y0, int x0, int r_s) {
     int lq;   // (re-derived, see finish_tile)
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lq));
     const int pc = lq & 15, gq = lq >> 4;
     int oy = y0 + 2 * wave, ox = x0 + 2 * pc;
-    bool slot_ok = true;   // WIDE: the tile's 128 slots hold 100 patches
-    if constexpr (WIDE) {
+    bool slot_ok = true;   // WIDE: the tile's 128 slots hold 100 (ROLL: 120) patches
+    unsigned zb = 0;       // ROLL: float offset of this lane's plane from plane z (B patches: one plane further)
+    if constexpr (WIDE != 0) {
       const int q = wave * 16 + pc;
-      slot_ok = q < WN_WIDE_NP;
+      slot_ok = q < NP;
       const int qq = slot_ok ? q : 0, pr = qq / WN_WIDE_PC;
       oy = y0 + 2 * pr, ox = x0 + 2 * (qq - pr * WN_WIDE_PC);
+      if constexpr (ROLL) {
+        if (pr >= r_s) {   // a B patch: rows from the top of plane z + 1 (which may not exist: the sample's last item)
+          oy = 2 * (pr - r_s);
+          zb = (unsigned)plane;
+          slot_ok = slot_ok && z + 1 < g.D;
+        }
+      }
     }
     // rows: wave-uniform in the 16 x 32 form, per lane in the WIDE form (there a row past the image is an out-of-range
     // offset like a column past it, and the stores are unconditional)
     const bool row0 = oy < g.H, row1 = oy + 1 < g.H, cok = slot_ok && ox < g.W;   // W % 4 == 0: a column pair is inside or outside
     const size_t cstride = VOL ? (size_t)g.D * plane : plane;
     const __amdgpu_buffer_rsrc_t osrd = wn_rsrc(out + (size_t)n * 32 * cstride + (size_t)z * plane, (unsigned)(32 * cstride * 4));
-    const unsigned ovoff = cok ? ((unsigned)(4 * gq) * (unsigned)cstride + (unsigned)(oy * g.W + ox)) * 4u : 0xFFFFFFFFu;
+    const unsigned ovoff = cok ? ((unsigned)(4 * gq) * (unsigned)cstride + zb + (unsigned)(oy * g.W + ox)) * 4u : 0xFFFFFFFFu;
     const unsigned ovoff0 = (!WIDE || row0) ? ovoff : 0xFFFFFFFFu, ovoff1 = (!WIDE || row1) ? ovoff : 0xFFFFFFFFu;
     float s[2] = {0.f, 0.f};
     float y[2][4][4];   // [t][r][2 * row + column]
@@ -893,7 +989,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       // valid outputs of the record: 4 couts x rows x 2 columns x the tile's valid patch columns (uniform)
       const int vp = (g.W - x0) >> 1;
       float npos = (float)(8 * ((row0 ? 1 : 0) + (row1 ? 1 : 0)) * (vp > 16 ? 16 : vp));
-      if constexpr (WIDE)   // per lane: 4 couts x 2 columns x the valid rows of the record's valid patches
+      if constexpr (WIDE != 0)   // per lane: 4 couts x 2 columns x the valid rows of the record's valid patches
         npos = sum16(cok ? (float)(8 * ((row0 ? 1 : 0) + (row1 ? 1 : 0))) : 0.0f);
       float m[2], qv[2] = {0.f, 0.f};
 #pragma unroll
@@ -914,7 +1010,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
 #pragma unroll
       for (int t = 0; t < 2; ++t) qv[t] = sum16(qv[t]);
       if (pc < 4) {   // lane j of the row writes group j of the record: the row's two groups, zeros for the others
-        float *rec = out_partials + (((size_t)n * ptiles + (size_t)z * g.tiles + tile_id) * WN_WAVES + wave) * 48;   // uniform
+        float *rec = out_partials + (((size_t)n * ptiles + (ROLL ? (size_t)0 : (size_t)z * g.tiles) + tile_id) * WN_WAVES + wave) * 48;   // uniform
         rec += gq * 12 + pc * 3;
         const int ga = gq >> 1;
         const bool a = pc == ga, b = pc == 2 + ga;
@@ -933,12 +1029,15 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     const int flat = g.rev ? total - 1 - (round * G + slot) : round * G + slot;
     const int n = flat / ptiles;
     int tile_id = flat - n * ptiles, z = 0;
-    if constexpr (VOL) {
+    int r_pr0 = 0, r_s = WN_ROLL_PR;
+    if constexpr (ROLL) {
+      roll_item(tile_id, z, r_pr0, r_s);
+    } else if constexpr (VOL) {
       z = tile_id / g.tiles;
       tile_id -= z * g.tiles;
     }
-    const int tyi = wdiv(tile_id, g.fd_ntx), txi = tile_id - tyi * g.ntx;
-    const int y0 = tyi * TY, x0 = txi * TX;
+    const int tyi = ROLL ? 0 : wdiv(tile_id, g.fd_ntx), txi = ROLL ? 0 : tile_id - tyi * g.ntx;
+    const int y0 = ROLL ? 2 * r_pr0 : tyi * TY, x0 = txi * TX;
 
     // acc is first written by the tile's first 32 multiplies (C = 0): no zeroing pass.  The empty asm "defines"
     // the registers here, so the allocator does not carry 128 undefined values around the tile loop.
@@ -1068,7 +1167,7 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     do_step(std::true_type{});
     for (chunk = 1; chunk < nsteps; ++chunk) do_step(std::false_type{});
     if (!(MVSN_WN_ABLATE & 16) || n < 0) {
-      if constexpr (TR) finish_tile_tr(n, z, tile_id, y0, x0);
+      if constexpr (TR) finish_tile_tr(n, z, tile_id, y0, x0, r_s);
       else finish_tile(n, z, tile_id, y0, x0);
     }
   }
@@ -1326,7 +1425,7 @@ bool wino_geom(const mvsn_conv_desc *d, WinoGeom *g) {
   if (d->kd == 1 && d->kh == 5 && d->kw == 5 && d->stride == 2) {   // 5 x 5 stride 2 on the input's four phases (conv_wino_s2_kernel)
     if (d->c_in != 32 || d->dilation != 1 || d->depth != 1 || d->cols % 8 != 0) return false;
     if ((unsigned long long)d->rows * d->cols * 32ull * 4ull >= (1ull << 31)) return false;   // 32-bit descriptor offsets
-    g->s2 = true, g->wide = false;
+    g->s2 = true, g->wide = 0;
     g->n = d->n, g->cin = 32, g->H = d->rows, g->W = d->cols, g->dil = 1, g->D = 1, g->vol = false;
     g->nty = ((d->rows - 1) / 2 + 1 + S2_TY - 1) / S2_TY;
     g->ntx = ((d->cols - 1) / 2 + 1 + S2_TX - 1) / S2_TX;
@@ -1347,17 +1446,27 @@ bool wino_geom(const mvsn_conv_desc *d, WinoGeom *g) {
   g->ntx = (d->cols + WN_TX - 1) / WN_TX;
   // volume form on planes a little wider than one 16 x 32 tile: 10-row strips of the whole width (WIDE) wherever that
   // takes fewer tile slots per plane (30 x 40: 3 strips of 100 patches instead of 2 x 2 tiles of 128 slots)
-  g->wide = false;
+  g->wide = 0;
 #ifndef MVSN_WN_NO_WIDE
   if (d->kd == 3 && d->cols > WN_TX && d->cols <= WN_WIDE_TX) {
     const int strips = (d->rows + WN_WIDE_TY - 1) / WN_WIDE_TY;
-    if (strips < g->nty * g->ntx) g->wide = true, g->nty = strips, g->ntx = 1;
+    if (strips < g->nty * g->ntx) g->wide = 1, g->nty = strips, g->ntx = 1;
   }
 #endif
   g->tiles = g->nty * g->ntx;
+#ifndef MVSN_WN_NO_ROLL
+  // ... or, where that takes fewer items still, six patch rows at a time rolling through the sample's planes (WIDE 2):
+  // `tiles` then counts the items of a SAMPLE (30 x 40 x D: 2.5 D instead of 3 D)
+  if (d->kd == 3 && d->cols > WN_TX && d->cols <= WN_WIDE_TX && d->c_in == 32 && d->dilation == 1) {
+    const int pr = (d->rows + 1) / 2;
+    const long items = ((long)d->depth * pr + WN_ROLL_PR - 1) / WN_ROLL_PR;
+    if (pr >= WN_ROLL_PR && items < (long)d->depth * g->tiles && items < (1L << 24))
+      g->wide = 2, g->nty = 1, g->ntx = 1, g->tiles = (int)items;
+  }
+#endif
   if (g->vol) {   // volume form: 32 -> 32 channels, dilation 1; U streams, 3 x 8 chunks
     if (d->c_in != 32 || d->dilation != 1) return false;
-    if ((long)d->depth * g->tiles > 1L << 24) return false;
+    if ((long)wino_items(*g) > 1L << 24) return false;
     g->nchunks = 24;
     g->packed_floats = (size_t)g->nchunks * WN_UFLOATS;
     return true;
@@ -1410,7 +1519,7 @@ bool wino_can_carry(const WinoGeom &g, const mvsn_apply_job *job) {
   const long units = (long)job->n * 32 * (job->spatial / 256);
   if (g.vol && job->residual) return false;   // (no residual slots next to the volume form's two rings)
   const int nsteps = g.vol ? 12 : (g.dil >= 4 ? 8 : 4);
-  const long capacity = (long)g.n * g.D * g.tiles * nsteps * WN_WAVES * r;   // unit indices are 32-bit in the kernel
+  const long capacity = (long)g.n * wino_items(g) * nsteps * WN_WAVES * r;   // unit indices are 32-bit in the kernel
   return units <= capacity && capacity < (1L << 31) && units < (1L << 30);
 }
 
@@ -1451,6 +1560,7 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   a.fd_ntx = wino_div((unsigned)g.ntx);
   a.cb0 = g.cin, a.cb1 = 0, a.in1 = a.in2 = in;
   a.D = g.D;
+  a.pr = (g.H + 1) / 2, a.fd_pr = wino_div((unsigned)a.pr);
   if (blocks) a.cb0 = blocks->cb0, a.cb1 = blocks->cb1, a.in1 = blocks->in1, a.in2 = blocks->in2;
   a.rev = (job && job->reverse == 1) ? 1 : 0;
   a.cs0 = (size_t)g.H * g.W, a.bs0 = (size_t)a.cb0 * a.cs0;
@@ -1463,7 +1573,8 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   const int ks = (head || g.dil == 8 || (job && g.dil == 4)) ? 1 : 2;
   // (a carrying launch waits with one step of DMA in flight, see RideArgs: a fourth stage would never be used)
   const int nstage = head ? 6 : ((g.dil == 1 && g.nchunks <= 8 && !job) ? 4 : 3);
-  const size_t rcst = g.wide ? (size_t)(WN_WIDE_TY + 2) * (WN_WIDE_TX + 2 * wn_pa(1)) + 16 : (size_t)wn_rcst(g.dil);
+  const size_t rcst = g.wide ? (size_t)(g.wide == 2 ? WN_ROLL_HY : WN_WIDE_TY + 2) * (WN_WIDE_TX + 2 * wn_pa(1)) + 16
+                             : (size_t)wn_rcst(g.dil);
   size_t lds = ((size_t)nstage * ks * 4 * rcst +
                 (g.vol ? (size_t)nstage * ks : (size_t)((g.nchunks + ks - 1) / ks * ks)) * WN_UFLOATS) * sizeof(float);
   lds += 32 * sizeof(float);                                      // bias
@@ -1492,18 +1603,20 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
                        (const void *)rd.x, (const void *)rd.stats, (const void *)rd.res, (const void *)rd.r_stats,  \
                        (const void *)rd.out, (const void *)nullptr, (const void *)nullptr, (const void *)nullptr);  \
   } while (0)
-  const long total = (long)g.n * g.D * g.tiles;
+  const long total = (long)g.n * wino_items(g);
   grid = dim3((unsigned)(total < cus ? total : cus));   // persistent: one workgroup per CU walks items grid-strided
   const bool xf = in_stats != nullptr;
   if (job) {   // the same kernels with the carried job's loads / stores in their steps
-    if (g.vol && g.wide) { if (xf) WN_CASE(1, 2, 3, 1, true, 1, true); else WN_CASE(0, 2, 3, 1, true, 1, true); }
+    if (g.vol && g.wide == 2) { if (xf) WN_CASE(1, 2, 3, 1, true, 1, 2); else WN_CASE(0, 2, 3, 1, true, 1, 2); }
+    else if (g.vol && g.wide) { if (xf) WN_CASE(1, 2, 3, 1, true, 1, 1); else WN_CASE(0, 2, 3, 1, true, 1, 1); }
     else if (g.vol) { if (xf) WN_CASE(1, 2, 3, 1, true, 1); else WN_CASE(0, 2, 3, 1, true, 1); }
     else if (g.dil == 1) { if (xf) WN_CASE(1, 2, 3, 1, false, 2); else WN_CASE(0, 2, 3, 1, false, 2); }
     else if (g.dil == 2) { if (xf) WN_CASE(1, 2, 3, 2, false, 2); else WN_CASE(0, 2, 3, 2, false, 2); }
     else if (g.dil == 4) { if (xf) WN_CASE(1, 1, 3, 4, false, 1); else WN_CASE(0, 1, 3, 4, false, 1); }
     else { if (xf) WN_CASE(1, 1, 3, 8, false, 1); else WN_CASE(0, 1, 3, 8, false, 1); }
   } else
-  if (g.vol && g.wide) { if (xf) WN_CASE(1, 2, 3, 1, true, 0, true); else WN_CASE(0, 2, 3, 1, true, 0, true); }
+  if (g.vol && g.wide == 2) { if (xf) WN_CASE(1, 2, 3, 1, true, 0, 2); else WN_CASE(0, 2, 3, 1, true, 0, 2); }
+  else if (g.vol && g.wide) { if (xf) WN_CASE(1, 2, 3, 1, true, 0, 1); else WN_CASE(0, 2, 3, 1, true, 0, 1); }
   else if (g.vol) { if (xf) WN_CASE(1, 2, 3, 1, true); else WN_CASE(0, 2, 3, 1, true); }
   else if (head) { if (xf) WN_CASE(1, 1, 6, 1); else WN_CASE(0, 1, 6, 1); }
   else if (g.dil == 1 && g.nchunks > 8) { if (xf) WN_CASE(1, 2, 3, 1); else WN_CASE(0, 2, 3, 1); }

@@ -244,7 +244,13 @@ def test_conv_winograd_form(cin, rows, cols, n, dil):
                                                (2, 8, 12, 3), (16, 16, 32, 20),
                                                # 32 < cols <= 40: 10-row strips of the whole width (WIDE tiles): the 30x40 grid
                                                # of BASELINE config 4, a ragged last strip, a narrower plane, many items
-                                               (6, 30, 40, 2), (3, 23, 36, 1), (96, 30, 40, 1), (4, 30, 40, 70)])
+                                               (6, 30, 40, 2), (3, 23, 36, 1), (96, 30, 40, 1), (4, 30, 40, 70),
+                                               # round 6, rolling strips (six patch rows at a time through the sample's
+                                               # planes): odd depth (a short last item), odd heights (two zero rows
+                                               # between the parts), PR = 6 / 7 / 8 (no split / every split position),
+                                               # one plane, and heights below six patch rows (stay on the 10-row strips)
+                                               (9, 30, 40, 2), (5, 13, 40, 1), (7, 12, 36, 3), (11, 15, 40, 1), (1, 30, 40, 2),
+                                               (4, 10, 40, 1), (13, 29, 36, 1)])
 def test_conv_winograd_volume_form(depth, rows, cols, n):
     """3x3x3 32->32 layers as 2-D Winograd products summed over the depth tap (MVSN_CONV_FP32_WINO with kd = 3):
     values and GroupNorm statistics against ATen and the direct fp32 kernel, plus the fused input transform."""
@@ -2673,7 +2679,8 @@ def test_sliced_refiner_tower_is_bit_identical():
 @pytest.mark.parametrize("mode1,n,jn,depth,rows,cols,expect", [(False, 2, 2, 8, 16, 32, 1), (True, 2, 2, 5, 16, 32, 1),
                                                                 (False, 3, 2, 4, 12, 24, 0),     # 4*12*24 % 256 != 0
                                                                 (False, 2, 2, 6, 32, 64, 1),
-                                                                (False, 2, 2, 32, 30, 40, 1), (True, 3, 3, 32, 30, 40, 1)])   # WIDE tiles
+                                                                (False, 2, 2, 32, 30, 40, 1), (True, 3, 3, 32, 30, 40, 1),   # WIDE tiles
+                                                                (True, 2, 2, 16, 30, 40, 1), (False, 1, 1, 64, 23, 36, 1)])  # (rolling strips)
 def test_conv3d_forward_carry_is_bit_identical(mode1, n, jn, depth, rows, cols, expect):
     """The volume form (3x3x3 regulariser layer) carrying an in-place LReLU(GN(.)) pass over another volume."""
     from multi_view_stereonet_amd.multi_view_stereonet import _Job
