@@ -375,7 +375,6 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   int pf_round = 0, pf_chunk = 0, pf_stage = 0;
   int pf_goff[PER];
   int pf_n = 0, pf_z = 0;
-  unsigned pf_isb = 0;   // ROLL: which of this lane's pieces belong to the B part (plane zA + 1)
   bool pf_live = slot < total;
   int rd_young = 0;   // RIDE: DMA pieces this wave has issued since its carried loads
   auto pf_plan = [&]() {   // DMA plan of the prefetcher's current item
@@ -393,7 +392,6 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     const int tyi = ROLL ? 0 : wdiv(tile, g.fd_ntx), txi = tile - tyi * g.ntx;
     const int y0 = ROLL ? 2 * r_pr0 : tyi * TY, x0 = txi * TX;
     pf_n = n;
-    pf_isb = 0;
     // (the pieces' rows / columns are re-derived per tile from an opaque copy of the lane id: hoisted out of the tile
     // loop they occupy six registers for the whole launch -- spilled, and reloaded per step, in the carrying kernels)
     int lo;   // (from the hardware, not from `lane`: that one gets spilled around the loops, and a reload here waits vmcnt(0))
@@ -404,15 +402,15 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       const int row = e / DQ, q = e - row * DQ;
       int gy = y0 - DIL + row;
       const int gx = x0 - PA + 4 * q;
-      bool isb = false;
+      int zsh = 0;
       if constexpr (ROLL) {   // raw rows 0 .. 2 s: plane zA from its row y0 - 1; row 2 s + 1: zero; then plane zA + 1 from row 0
-        isb = r_s < WN_ROLL_PR && row >= 2 * r_s + 1;
-        if (isb) gy = row - (2 * r_s + 2);
-        pf_isb |= (isb ? 1u : 0u) << i;
+        // (selects, no branches; a B piece's offset is one plane further: the step's descriptor starts at the A part's plane)
+        const bool isb = (r_s < WN_ROLL_PR) & (row >= 2 * r_s + 1);
+        gy = isb ? row - (2 * r_s + 2) : gy;
+        zsh = isb ? g.H * g.W : 0;
       }
-      const bool ok = i < dpn && e < GROUPS && gy >= 0 && gy < g.H && gx >= 0 && gx < g.W;
-      // (a B piece outside the image: 0x80000000 -- still out of range once the plane shift is added in pf_issue)
-      pf_goff[i] = ok ? (gy * g.W + gx) * (MVSN_WN_BUFDMA ? 4 : 1) : (isb ? (int)0x80000000u : -1);
+      const bool ok = (i < dpn) & (e < GROUPS) & (gy >= 0) & (gy < g.H) & (gx >= 0) & (gx < g.W);
+      pf_goff[i] = ok ? (zsh + gy * g.W + gx) * (MVSN_WN_BUFDMA ? 4 : 1) : -1;
     }
   };
   auto pf_issue = [&]() {   // issue the DMA of the prefetcher's step and advance it
@@ -420,14 +418,22 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     rd_young += PER;
     bool cok;
     const float *src;
-    unsigned bshift = 0, rbytes = 0;   // ROLL: byte offset of the B part's plane from `src`; bytes the descriptor covers
-    if constexpr (ROLL) {   // A part: plane zz = zA + kz - 1, B part: plane zz + 1; one descriptor from the first that exists
+    unsigned rbytes = 0;   // ROLL: bytes the step's descriptor covers
+    bool roll_first = false;   // ROLL: the A part's plane is -1 (the B part's plane 0 is where the descriptor starts)
+    if constexpr (ROLL) {   // A part: plane zz = zA + kz - 1, B part: plane zz + 1; one descriptor from the A part's plane
       const int kz = pf_chunk >> 2, c = (pf_chunk & 3) * 8 + dch, zz = pf_z + kz - 1;
-      cok = zz >= 0 && zz < g.D;                                  // the A part's plane exists
-      const bool cokb = zz + 1 < g.D;                             // the B part's (zz >= -1)
-      src = in + (((size_t)pf_n * 32 + c) * g.D + (zz > 0 ? (zz < g.D ? zz : 0) : 0)) * plane;
-      bshift = zz >= 0 ? (unsigned)plane * 4u : 0u;
-      rbytes = zz >= g.D ? 0u : (cokb ? bshift + (unsigned)plane * 4u : (cok ? (unsigned)plane * 4u : 0u));
+      cok = zz >= 0 && zz < g.D;
+      roll_first = zz < 0;
+      // descriptor: from plane max(zz, 0) over the planes of {zz, zz + 1} that exist (min / max arithmetic, no selects:
+      // the compiler turned the nested selects into vector code and branches between the multiplies)
+      const int zlo = zz < 0 ? 0 : zz, zhi = zz + 1 < g.D ? zz + 1 : g.D - 1;
+      const int np = zhi - zlo + 1 > 0 ? zhi - zlo + 1 : 0;        // 2; 1 at the volume's two ends; 0 beyond
+      const int zsel = zlo < g.D - 1 ? zlo : g.D - 1;
+      // (pinned to scalar registers: left to itself the compiler forms index and size in vector registers and then wraps
+      // every DMA piece in a readfirstlane waterfall loop -- three loops per step between the multiplies, +10 % per tile)
+      src = in + (size_t)(unsigned)__builtin_amdgcn_readfirstlane((pf_n * 32 + c) * g.D + zsel) * plane;
+      rbytes = (unsigned)np * (unsigned)plane * 4u;
+      rbytes = (unsigned)__builtin_amdgcn_readfirstlane((int)rbytes);
     } else if constexpr (VOL) {   // step = (depth tap, 8 channels): plane pf_z + kz - 1 of channel c, zeros outside the volume
       const int kz = pf_chunk >> 2, c = (pf_chunk & 3) * 8 + dch, zz = pf_z + kz - 1;
       cok = zz >= 0 && zz < g.D;
@@ -448,11 +454,10 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
         if ((dp0 + i) * 64 + lane < GROUPS) {   // lanes past the tile's last 16-byte group stay out of the slot
           if constexpr (ROLL) {
             static_assert(!ROLL || MVSN_WN_BUFDMA, "rolling strips: descriptor DMA only");
-            // B lanes: one plane further (where the descriptor starts at the A part's plane); A lanes of a plane that
-            // does not exist (zz = -1: the descriptor starts at the B part's plane) are sent out of range
-            const bool lb = (pf_isb >> i) & 1u;
-            unsigned off = (unsigned)pf_goff[i] + (lb ? bshift : 0u);
-            if (!cok && !lb) off = 0xFFFFFFFFu;
+            unsigned off = (unsigned)pf_goff[i];
+            // (uniform, one step in D x 12: the A part's plane is -1 -- the descriptor starts at plane 0, which is the B
+            // part's: B offsets come back by one plane, A offsets wrap far out of range)
+            off -= roll_first ? (unsigned)plane * 4u : 0u;
             wn_dma16_buf<ASM_DMA>(src, pbytes, off, dst + (dp0 + i) * 256);
           } else if constexpr (MVSN_WN_BUFDMA) {
             wn_dma16_buf<ASM_DMA>(src, pbytes, (unsigned)pf_goff[i], dst + (dp0 + i) * 256);   // byte offset; -1: out of range
@@ -936,12 +941,11 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
       slot_ok = q < NP;
       const int qq = slot_ok ? q : 0, pr = qq / WN_WIDE_PC;
       oy = y0 + 2 * pr, ox = x0 + 2 * (qq - pr * WN_WIDE_PC);
-      if constexpr (ROLL) {
-        if (pr >= r_s) {   // a B patch: rows from the top of plane z + 1 (which may not exist: the sample's last item)
-          oy = 2 * (pr - r_s);
-          zb = (unsigned)plane;
-          slot_ok = slot_ok && z + 1 < g.D;
-        }
+      if constexpr (ROLL) {   // a B patch: rows from the top of plane z + 1 (which may not exist: the sample's last item)
+        const bool pb = pr >= r_s;
+        oy = pb ? 2 * (pr - r_s) : oy;
+        zb = pb ? (unsigned)plane : 0u;
+        slot_ok = slot_ok & (!pb | (z + 1 < g.D));
       }
     }
     // rows: wave-uniform in the 16 x 32 form, per lane in the WIDE form (there a row past the image is an out-of-range
