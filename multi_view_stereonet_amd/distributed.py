@@ -25,9 +25,13 @@ def init_from_env(backend: Optional[str] = None, force: bool = False) -> Tuple[i
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            # (the rank's device named up front: RCCL binds its communicator to it instead of guessing from the global
+            # rank at the first collective -- "can cause a hang if rank to GPU mapping is heterogeneous")
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
