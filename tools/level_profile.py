@@ -57,7 +57,7 @@ def run(level, batch):
 
 def timeline_name(kernel, level):
     """rocprof kernel name -> bench.py timeline name of the same launch at this level (None: not a tower launch)."""
-    m = re.search(r"conv_wino_kernel<(\d), (\d), (\d), (\d)(?:, (true|false), (\d))?(?:, (?:true|false))?>", kernel)
+    m = re.search(r"conv_wino_kernel<(\d), (\d), (\d), (\d)(?:, (true|false), (\d))?(?:, (?:true|false|\d))?>", kernel)
     if m:
         mode, ks, nstage, dil, vol, ride = m.groups()
         if vol == "true":
