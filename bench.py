@@ -769,7 +769,10 @@ def main():
         traffic, traffic_source = None, None
         # HBM bytes per launch from the committed PMC passes of THIS library (refused when the digest differs)
         pmc = load_profile_json(PMC_TRAFFIC_FILE)
-        t = (pmc or {}).get(name)
+        # (per-chain bytes depend on the configuration's geometry: the headline's entries are top-level -- configs 2 / 3 share
+        # its coarse grid and depth --, the others come from passes of their own command under `configs`, or there is none)
+        pmc_cfg = pmc if args.config in ("headline", "config2", "config3") else ((pmc or {}).get("configs", {}).get(args.config) or {})
+        t = (pmc_cfg or {}).get(name)
         if t:
             traffic = (t["fetch_bytes_per_chain"] + t["write_bytes_per_chain"]) * B * Sn
             # (older files carry no flag: the raw / reported pair says whether the kernel's fetch figure was doubled)
@@ -780,7 +783,9 @@ def main():
                               f"WRITE_SIZE of separate rocprofv3 --pmc passes of the bench command with this library "
                               f"(digest {pmc['_library_digest'][:12]}, {pmc.get('_chains_per_launch', '?')} chains per launch), "
                               "per chain x this batch -- a committed pass, NOT a counter read during this run")
-        elif pmc is None:
+        elif pmc is not None:
+            traffic_source = f"profiles/{pmc['_file']} holds no pass of this configuration's `{name}` kernel"
+        else:
             traffic_source = (f"profiles/{PMC_TRAFFIC_FILE} is missing or was taken with another build of the library "
                               "(digest mismatch): refused")
         line["roofline"] = {"kernel": name, "bound": "mfma", "achieved": tfl, "peak": PEAK_FP32_MFMA_TFLOPS,
@@ -816,8 +821,8 @@ def main():
                                     "executed_TFLOPs": exec_tfl,
                                     "executed_frac_of_fp32_mfma_peak": exec_tfl / PEAK_FP32_MFMA_TFLOPS,
                                     "share_of_step": ch["ms"] / total_ms}
-            t = (pmc or {}).get("mvsn_incremental_cost_volume")
-            if t and form == "winograd":
+            t = (pmc_cfg or {}).get("mvsn_incremental_cost_volume")
+            if t and (form == "winograd" or args.config != "headline"):
                 line["chain_kernel"]["hbm_traffic_bytes_per_chain"] = {
                     "fetched": t["fetch_bytes_per_chain"], "written": t["write_bytes_per_chain"],
                     "algorithmic": t["algorithmic_bytes_per_chain"],
