@@ -16,7 +16,12 @@ R=${R:-r06}
 TAG=${TAG:-${R}_final}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT/json
-if [ "${SKIP_FINAL:-0}" != "1" ]; then
+if [ "${SKIP_FINAL:-0}" = "1" ]; then   # (gpurun_out does not travel: seed it from what profiles/ keeps of THIS library)
+  cp -r profiles/$TAG/. $OUT/
+  mkdir -p gpurun_out/${TAG}_levels gpurun_out/${R}_bf16s
+  cp -r profiles/${R}_levels/. gpurun_out/${TAG}_levels/
+  cp -r profiles/${R}_bf16s/. gpurun_out/${R}_bf16s/
+else
   TAG=$TAG SOAK=${SOAK:-600} SOAKG=${SOAKG:-200} bash tools/prof_final.sh > $OUT/prof_final.log 2>&1
   TAG=${TAG}_levels bash tools/prof_levels.sh > $OUT/prof_levels.log 2>&1
   TAG=${R}_bf16s bash tools/prof_feature_tier.sh > /dev/null 2>&1
