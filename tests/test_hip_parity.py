@@ -2701,6 +2701,40 @@ def test_conv3d_forward_carry_is_bit_identical(mode1, n, jn, depth, rows, cols, 
     assert torch.equal(got_out, want_out) and torch.equal(got_st, want_st) and torch.equal(jr2, want_job)
 
 
+@pytest.mark.parametrize("mode1,n,depth,rows,cols", [(False, 3, 32, 30, 40), (True, 2, 16, 30, 40), (False, 1, 64, 23, 36)])
+def test_rolling_strip_launches_stress_bit_identical(mode1, n, depth, rows, cols):
+    """The rolling-strip form of the volume kernel (six patch rows at a time through a sample's planes; one descriptor over two
+    planes per step, per-item lane geometry) issues its LDS-DMA by hand-counted waits when it carries a pass: 300 launches
+    per shape, plain and carrying alternately, both walk directions, every output word, every GroupNorm record-derived
+    statistic and every word of the carried pass compared with the first launch / the two-call reference each time."""
+    from multi_view_stereonet_amd.multi_view_stereonet import _Job
+    eng = net_for("gta_sfm_150epochs").engine()
+    conv, norm = eng.vf_convs[1], eng.vf_norms[0]
+    g = torch.Generator().manual_seed(rows * 3 + depth)
+    x = torch.randn(n, 32, depth, rows, cols, generator=g).to(DEV)
+    jr = torch.randn(n, 32, depth, rows, cols, generator=g).to(DEV)
+    st, ist = _gn_stats(n, 4), _gn_stats(n, 5)
+    kw = dict(in_stats=ist, in_norm=norm) if mode1 else {}
+    want_out, want_st = eng.conv(conv, x, want_stats=True, **kw)
+    want_job = eng.gn_lrelu(jr, st, norm)
+    can_carry = (depth * rows * cols) % 256 == 0
+    jr2 = torch.empty_like(jr)
+    bad, carried0 = 0, eng.carried_jobs
+    for it in range(300):
+        if it % 2 and can_carry:
+            jr2.copy_(jr)
+            job = _Job(jr2, st, norm)
+            job.job.reverse = (it // 2) % 2
+            out, got_st = eng.conv(conv, x, want_stats=True, carry=job, **kw)
+            ok = torch.equal(out, want_out) & torch.equal(got_st, want_st) & torch.equal(jr2, want_job)
+        else:
+            out, got_st = eng.conv(conv, x, want_stats=True, **kw)
+            ok = torch.equal(out, want_out) & torch.equal(got_st, want_st)
+        bad += 0 if ok else 1
+    assert bad == 0, f"{bad} of 300 launches deviated"
+    assert (eng.carried_jobs - carried0 == 150) == can_carry
+
+
 def test_sliced_regulariser_is_bit_identical():
     net = net_for("gta_sfm_150epochs")
     eng = net.engine()
