@@ -196,8 +196,12 @@ def coresident_right(index: int) -> bool:
         _coresident[index] = (True, None)
         return True
     import fcntl
-    try:
-        f = open(coresident_lock_path(index), "a+")
+    try:      # (world-writable: the other process on this GPU may belong to another user)
+        old_mask = os.umask(0)
+        try:
+            f = os.fdopen(os.open(coresident_lock_path(index), os.O_RDWR | os.O_CREAT, 0o666), "r+")
+        finally:
+            os.umask(old_mask)
     except OSError:
         _coresident[index] = (True, None)
         return True
