@@ -278,7 +278,19 @@ __global__ void wino_pack_kernel(const float *__restrict__ w, int cin, int cout,
 //         and the epilogue's per-lane plane / row.  Items never span samples (a sample's last item may be short).
 constexpr int WN_WIDE_TY = 10, WN_WIDE_TX = 40, WN_WIDE_PC = WN_WIDE_TX / 2, WN_WIDE_NP = (WN_WIDE_TY / 2) * WN_WIDE_PC;
 constexpr int WN_ROLL_PR = 6, WN_ROLL_NP = WN_ROLL_PR * WN_WIDE_PC, WN_ROLL_HY = 2 * WN_ROLL_PR + 3;
-template <int MODE, int KS, int NSTAGE, int DIL, bool VOL = false, int RIDE = 0, int WIDE = 0>
+// FULLW   (round 6) the tile spans the WHOLE plane width (W = 32: the 16 x 32 coarse grid's regulariser): neighbouring
+//         patches overlap by two columns, so lane p forms the column sums t[.][1], t[.][2] of ITS OWN two image columns
+//         2p, 2p + 1 only (8 adds instead of 16, half the raw-tile reads: one 8-byte read per row) and takes t[.][0] /
+//         t[.][3] -- columns 2p - 1 / 2p + 2 -- from lanes p - 1 / p + 1 as DPP operands (row_shr:1 / row_shl:1) of the second
+//         stage's adds: 24 VALU instructions per patch and channel instead of 32, no extra instruction.  The edge lanes'
+//         missing neighbours are columns -1 and 32, i.e. the zero padding -- exactly what bound_ctrl:0 supplies -- which
+//         is why the form needs the tile to span the plane.  Same operands, same operations: bit-identical results.
+#ifndef MVSN_WN_NO_FULLW
+#define MVSN_WN_FULLW_OK 1
+#else
+#define MVSN_WN_FULLW_OK 0
+#endif
+template <int MODE, int KS, int NSTAGE, int DIL, bool VOL = false, int RIDE = 0, int WIDE = 0, bool FULLW = false>
 __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, const float *__restrict__ in,
                                                                   const float *__restrict__ upk,
                                                                   const float *__restrict__ bias,
@@ -311,7 +323,9 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
   constexpr int STAGE = KS * 4 * RCST;               // ring stage (floats)
   float *U = smem + NSTAGE * STAGE;                  // nchunks * WN_UFLOATS, resident (VOL: ring of NSTAGE steps)
   // dilation 1: raw tiles stored one float further (4-byte-aligned DMA destination), see tr_load
-  constexpr int SHIFT = (DIL == 1 && MVSN_WN_SHIFT) ? 1 : 0;
+  // (FULLW: no shift -- a lane reads its OWN two columns, which then start at an even float)
+  static_assert(!FULLW || (DIL == 1 && WIDE == 0 && MVSN_WN_XF == 2 && MVSN_WN_TRANSPOSED), "full-width form: 16 x 32 tiles, burst + block");
+  constexpr int SHIFT = (DIL == 1 && MVSN_WN_SHIFT && !FULLW) ? 1 : 0;
   // dilated layers: a half-wave reads two channels whose strided columns fall on the same half of the banks;
   // odd channels are stored DIL floats further, which moves them to the other half (conflict-free)
   constexpr int CSHIFT = (DIL > 1 && MVSN_WN_SHIFT) ? DIL : 0;
@@ -663,7 +677,14 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
     for (int h = 0; h < KS; ++h) {
       if (h < h0 || h >= h1) continue;
       const float *raw = smem + tr_stage * STAGE + (h * 4 + kc) * RCST + ya * XS + xa + (PA - DIL) + SHIFT + CSHIFT * (kc & 1);
-      if constexpr (SHIFT) {
+      if constexpr (FULLW) {   // own columns j = 1, 2 of the patch (image columns 2p, 2p + 1): one aligned 8-byte read per row
+        const float2 *r2 = reinterpret_cast<const float2 *>(raw + 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float2 c = r2[i * (XS / 2)];
+          d[h][i][1] = c.x, d[h][i][2] = c.y;
+        }
+      } else if constexpr (SHIFT) {
         const float2 *r2 = reinterpret_cast<const float2 *>(raw);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -694,6 +715,25 @@ __global__ __launch_bounds__(WN_THREADS, 2) void conv_wino_kernel(WinoArgs g, co
 #pragma unroll
     for (int h = 0; h < KS; ++h) {
       if (h < h0 || h >= h1) continue;
+      if constexpr (FULLW) {
+        // column sums of the lane's own columns; the outer two from the neighbouring patches (lanes p -+ 1 of the 16-lane
+        // row: DPP operands of the adds below; lanes 0 / 15 get 0 = the padding columns -1 / 32)
+        float t1[4], t2[4];
+        {
+          const float a0 = d[h][0][1], a1 = d[h][1][1], a2 = d[h][2][1], a3 = d[h][3][1];
+          const float b0 = d[h][0][2], b1 = d[h][1][2], b2 = d[h][2][2], b3 = d[h][3][2];
+          t1[0] = a0 - a2, t1[1] = a1 + a2, t1[2] = a2 - a1, t1[3] = a1 - a3;
+          t2[0] = b0 - b2, t2[1] = b1 + b2, t2[2] = b2 - b1, t2[3] = b1 - b3;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[h][i * 4 + 0] = dpp_mov<0x111>(t2[i]) - t2[i];   // t[i][0] = lane p - 1's t[i][2]   (row_shr:1)
+          v[h][i * 4 + 1] = t1[i] + t2[i];
+          v[h][i * 4 + 2] = t2[i] - t1[i];
+          v[h][i * 4 + 3] = t1[i] - dpp_mov<0x101>(t1[i]);   // t[i][3] = lane p + 1's t[i][1]   (row_shl:1)
+        }
+        continue;
+      }
       float t[4][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1612,9 +1652,13 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   const long total = (long)g.n * wino_items(g);
   grid = dim3((unsigned)(total < cus ? total : cus));   // persistent: one workgroup per CU walks items grid-strided
   const bool xf = in_stats != nullptr;
+  // volume form on planes one tile wide (the 16 x 32 coarse grid): neighbouring lanes share the input transform's column
+  // sums (FULLW, see conv_wino_kernel)
+  const bool fullw = MVSN_WN_FULLW_OK && g.vol && !g.wide && g.ntx == 1 && g.W <= WN_TX;
   if (job) {   // the same kernels with the carried job's loads / stores in their steps
     if (g.vol && g.wide == 2) { if (xf) WN_CASE(1, 2, 3, 1, true, 1, 2); else WN_CASE(0, 2, 3, 1, true, 1, 2); }
     else if (g.vol && g.wide) { if (xf) WN_CASE(1, 2, 3, 1, true, 1, 1); else WN_CASE(0, 2, 3, 1, true, 1, 1); }
+    else if (g.vol && fullw) { if (xf) WN_CASE(1, 2, 3, 1, true, 1, 0, true); else WN_CASE(0, 2, 3, 1, true, 1, 0, true); }
     else if (g.vol) { if (xf) WN_CASE(1, 2, 3, 1, true, 1); else WN_CASE(0, 2, 3, 1, true, 1); }
     else if (g.dil == 1) { if (xf) WN_CASE(1, 2, 3, 1, false, 2); else WN_CASE(0, 2, 3, 1, false, 2); }
     else if (g.dil == 2) { if (xf) WN_CASE(1, 2, 3, 2, false, 2); else WN_CASE(0, 2, 3, 2, false, 2); }
@@ -1623,6 +1667,7 @@ int wino_launch(const WinoGeom &g, const float *in, const float *upk, const floa
   } else
   if (g.vol && g.wide == 2) { if (xf) WN_CASE(1, 2, 4, 1, true, 0, 2); else WN_CASE(0, 2, 4, 1, true, 0, 2); }
   else if (g.vol && g.wide) { if (xf) WN_CASE(1, 2, 3, 1, true, 0, 1); else WN_CASE(0, 2, 3, 1, true, 0, 1); }
+  else if (g.vol && fullw) { if (xf) WN_CASE(1, 2, 3, 1, true, 0, 0, true); else WN_CASE(0, 2, 3, 1, true, 0, 0, true); }
   else if (g.vol) { if (xf) WN_CASE(1, 2, 3, 1, true); else WN_CASE(0, 2, 3, 1, true); }
   else if (head) { if (xf) WN_CASE(1, 1, 6, 1); else WN_CASE(0, 1, 6, 1); }
   else if (g.dil == 1 && g.nchunks > 8) { if (xf) WN_CASE(1, 2, 3, 1); else WN_CASE(0, 2, 3, 1); }

@@ -5,5 +5,5 @@ tool=$1; shift
 for flags in "$@"; do
   MVSN_HIPCC_FLAGS="$flags" python multi_view_stereonet_amd/build.py --force > /dev/null 2>&1 || { echo "build failed: $flags"; continue; }
   echo "== [$flags]"
-  MVSN_HIPCC_FLAGS="$flags" timeout 300 python $tool 2>&1 | grep -E "median|rror|launch"
+  MVSN_HIPCC_FLAGS="$flags" timeout 300 python $tool 2>&1 | grep -E "median|rror|launch|checksum"
 done

@@ -31,7 +31,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "multi_view_stereonet_amd", "csrc", "mvsn_conv_wino.hip")
 VMEM = re.compile(r"^\s*(global_(load|store|atomic)|buffer_(load|store|atomic)|flat_(load|store|atomic)|scratch_(load|store))")
-KERNEL = re.compile(r"^(_ZN4mvsn16conv_wino_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELi(\d+)E(?:Lb[01]E|Li\d+E)?E\S*):")
+KERNEL = re.compile(r"^(_ZN4mvsn16conv_wino_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])ELi(\d+)E(?:Lb[01]E|Li\d+E)?(?:Lb[01]E)?E\S*):")
 
 
 def assemble() -> str:

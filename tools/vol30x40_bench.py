@@ -30,8 +30,11 @@ def timed(fn, reps=9):
     return ts[len(ts) // 2], ts[0]
 
 
+torch.manual_seed(0)
 for (D, H, W) in ((96, 30, 40), (64, 16, 32)):
     x = torch.randn(N, 32, D, H, W, device="cuda")
+    out, st = eng.conv(eng.vf_convs[1], x, want_stats=True)      # (checksums: A/B builds must agree bit for bit)
+    print("  checksum out %d stats %d" % (int(out.view(torch.int32).to(torch.int64).sum()), int(st.view(torch.int32).to(torch.int64).sum())))
     med, mn = timed(lambda: eng.conv(eng.vf_convs[1], x, want_stats=True))
     direct = 2.0 * 27 * 32 * 32 * D * H * W * N
     print("%dx%dx%d x %d samples: median %.3f min %.3f ms   executed %.1f TFLOP/s = %.3f of 157.3" %
