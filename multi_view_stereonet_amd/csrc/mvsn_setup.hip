@@ -4,6 +4,10 @@
 // reference's fp32 pipeline rounds them (see include/mvsn_hip.h for the call sites replaced).
 #include "mvsn_common.h"
 
+#ifndef MVSN_SETUP_FP64_H   // A/B aid: 1 = the homographies from the fp64 evaluation, rounded once (rounds 1-5)
+#define MVSN_SETUP_FP64_H 0
+#endif
+
 namespace mvsn {
 
 __device__ inline void inv3(const double *m, double *o) {
@@ -39,6 +43,106 @@ __device__ inline void plane_homography(const double *K3, const double *K3inv, c
   mul3(K3, tmp, H);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The homographies the kernels CONSUME (H at levels 0 and 4), operation by operation as the reference's fp32 pipeline
+// forms them (round 6).  The fp64 evaluation above is more accurate, but it is not what the reference computes: its
+// H = K (R + t idepth e3^T) K^-1 chains two fp32 LAPACK inverses and two naive 3x3 products, and one ulp of the level-0
+// translation entries (3e-5 px at ~300 px) is 4.5e-5 of a warped noise frame -- the whole forward's deviation from the
+// reference entered there (profiles/r06_parity/).  What torch's CPU path does, found by matching bits on the host:
+//   * inverse(T) on a contiguous (B,4,4) tensor = ATen's linalg_solve_ex shortcut: LU of the TRANSPOSE (right-looking,
+//     first-maximum partial pivoting, FMA updates, a column scaled by the reciprocal pivot -- except the last,
+//     one-element column, which is divided), then getrs with trans = 'T' on the identity (dot form, FMA, reciprocal
+//     diagonal), then the row interchanges in reverse.  The LU matches MKL's bit for bit; the solve's cancellation
+//     residues (entries of magnitude 1e-9 that are 0 in exact arithmetic) may not -- they move H by < 4e-9;
+//   * inverse(K[:, :3, :3]) of an upper-triangular intrinsics matrix = LAPACK strti2: reciprocal diagonal,
+//     -(c * (1 / f)) above it;
+//   * (N,3,3) @ (N,3,3) = ATen's small-matrix bmm: acc = 0, acc += a[i][k] * b[k][j] for k = 0, 1, 2, every operation rounded.
+// (stereo/image_predictor.py:446-459, multi_view_stereonet.py:167-194; the idepth samples keep their own path above.)
+namespace ref32 {
+
+__device__ inline void inverse_pose(const float *T, float *X) {
+#pragma clang fp contract(off)
+  float L[16];
+  int ip[4];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) L[i * 4 + j] = T[j * 4 + i];
+  for (int j = 0; j < 4; ++j) {
+    int p = j;
+    float m = fabsf(L[j * 4 + j]);
+    for (int i = j + 1; i < 4; ++i)
+      if (fabsf(L[i * 4 + j]) > m) m = fabsf(L[i * 4 + j]), p = i;
+    ip[j] = p;
+    if (p != j)
+      for (int k = 0; k < 4; ++k) {
+        const float t = L[j * 4 + k];
+        L[j * 4 + k] = L[p * 4 + k], L[p * 4 + k] = t;
+      }
+    const float piv = L[j * 4 + j], r = 1.0f / piv;
+    for (int i = j + 1; i < 4; ++i) L[i * 4 + j] = (3 - j <= 1) ? L[i * 4 + j] / piv : L[i * 4 + j] * r;
+    for (int i = j + 1; i < 4; ++i)
+      for (int k = j + 1; k < 4; ++k) L[i * 4 + k] = __builtin_fmaf(-L[i * 4 + j], L[j * 4 + k], L[i * 4 + k]);
+  }
+  for (int c = 0; c < 4; ++c) {
+    float b[4] = {0.f, 0.f, 0.f, 0.f};
+    b[c] = 1.0f;
+    for (int i = 0; i < 4; ++i) {      // U^T y = e_c
+      float t = b[i];
+      for (int k = 0; k < i; ++k) t = __builtin_fmaf(-L[k * 4 + i], b[k], t);
+      b[i] = t * (1.0f / L[i * 4 + i]);
+    }
+    for (int i = 3; i >= 0; --i) {     // L^T x = y (unit diagonal)
+      float t = b[i];
+      for (int k = i + 1; k < 4; ++k) t = __builtin_fmaf(-L[k * 4 + i], b[k], t);
+      b[i] = t;
+    }
+    for (int j = 3; j >= 0; --j)
+      if (ip[j] != j) {
+        const float t = b[j];
+        b[j] = b[ip[j]], b[ip[j]] = t;
+      }
+    for (int i = 0; i < 4; ++i) X[i * 4 + c] = b[i];
+  }
+}
+
+// true when K3 has the reference's form [[fx,0,cx],[0,fy,cy],[0,0,1]] (anything else keeps the fp64 path)
+__device__ inline bool inverse_intrinsics(const float *K3, float *Ki) {
+#pragma clang fp contract(off)
+  if (!(K3[1] == 0.f && K3[3] == 0.f && K3[6] == 0.f && K3[7] == 0.f && K3[8] == 1.f && K3[0] != 0.f && K3[4] != 0.f)) return false;
+  for (int i = 0; i < 9; ++i) Ki[i] = 0.f;
+  Ki[0] = 1.0f / K3[0], Ki[4] = 1.0f / K3[4], Ki[8] = 1.0f;
+  Ki[2] = -(K3[2] * Ki[0]);
+  Ki[5] = -(K3[5] * Ki[4]);
+  return true;
+}
+
+__device__ inline void mm3(const float *a, const float *b, float *o) {
+#pragma clang fp contract(off)
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      float acc = 0.f;
+      for (int k = 0; k < 3; ++k) {
+        const float prod = a[i * 3 + k] * b[k * 3 + j];
+        acc = acc + prod;
+      }
+      o[i * 3 + j] = acc;
+    }
+}
+
+// H = K ((R + t idepth e3^T) K^-1), R / t = rotation / translation of the inverted pose
+__device__ inline void plane_homography(const float *K3, const float *Ki, const float *Tl, float idepth, float *H) {
+#pragma clang fp contract(off)
+  float core[9], tmp[9];
+  for (int i = 0; i < 3; ++i) {
+    core[i * 3] = Tl[i * 4], core[i * 3 + 1] = Tl[i * 4 + 1];
+    const float ti = Tl[i * 4 + 3] * idepth;
+    core[i * 3 + 2] = Tl[i * 4 + 2] + ti;
+  }
+  mm3(core, Ki, tmp);
+  mm3(K3, tmp, H);
+}
+
+}  // namespace ref32
+
 constexpr int SETUP_THREADS = 256;
 
 // Where a chain's pose and intrinsics live: per chain (T (N,4,4), K (N,4,4)) or, `per_source`, as the forward holds
@@ -63,11 +167,19 @@ __global__ __launch_bounds__(SETUP_THREADS) void plane_sweep_setup_kernel(
   __shared__ double s_sum[SETUP_THREADS];
   __shared__ int s_cnt[SETUP_THREADS];
   __shared__ float s_top;
+  __shared__ float s_Tl[16], s_K4i[9];   // ref32: the inverted (normalised) pose, the level-4 intrinsics' inverse
+  __shared__ int s_ref32;                // ... and whether the intrinsics have the form that path covers
 
   // --- baseline renormalisation in fp32, as multi_view_stereonet.py:566-571 -------------------
   float tx = T[3], ty = T[7], tz = T[11];
-  float base = sqrtf(tx * tx + ty * ty + tz * tz);
-  float tn[3] = {tx / base, ty / base, tz / base};
+  float base, tn[3];
+  {
+#pragma clang fp contract(off)   // T[:, :3, 3].pow(2).sum(1).sqrt(): every operation rounded, no fused multiply-add
+    const float xx = tx * tx, yy = ty * ty, zz = tz * tz;
+    const float sxy = xx + yy;
+    base = sqrtf(sxy + zz);
+    tn[0] = tx / base, tn[1] = ty / base, tn[2] = tz / base;
+  }
 
   // --- T_left_in_right = inverse([R t; 0 1]) ---------------------------------------------------
   double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
@@ -130,7 +242,16 @@ __global__ __launch_bounds__(SETUP_THREADS) void plane_sweep_setup_kernel(
     double K0inv[9], H0[9];
     inv3(K0d, K0inv);
     plane_homography(K0d, K0inv, Rl, tl, 0.0, H0);
-    for (int i = 0; i < 9; ++i) H0_out[(size_t)n * 9 + i] = (float)H0[i];
+    // the reference's own fp32 chain where the intrinsics have its form (ref32 above); the fp64 value otherwise
+    float Tn[16], K0f[9], K4f[9], K0i[9], H0f[9];
+    for (int i = 0; i < 16; ++i) Tn[i] = T[i];
+    Tn[3] = tn[0], Tn[7] = tn[1], Tn[11] = tn[2];
+    for (int i = 0; i < 9; ++i) K0f[i] = (float)K0d[i], K4f[i] = (float)K4d[i];
+    ref32::inverse_pose(Tn, s_Tl);
+    const bool ok = ref32::inverse_intrinsics(K0f, K0i) && ref32::inverse_intrinsics(K4f, s_K4i) && !MVSN_SETUP_FP64_H;
+    s_ref32 = ok ? 1 : 0;
+    if (ok) ref32::plane_homography(K0f, K0i, s_Tl, 0.0f, H0f);
+    for (int i = 0; i < 9; ++i) H0_out[(size_t)n * 9 + i] = ok ? H0f[i] : (float)H0[i];
   }
   __syncthreads();
   const float delta = s_top / (float)(D - 1);
@@ -141,10 +262,13 @@ __global__ __launch_bounds__(SETUP_THREADS) void plane_sweep_setup_kernel(
     double H[9];
     plane_homography(K4d, K4inv, Rl, tl, (double)sd, H);
     float Hf[9];
-    for (int i = 0; i < 9; ++i) {
-      Hf[i] = (float)H[i];
-      H4_out[((size_t)n * D + d) * 9 + i] = Hf[i];
+    for (int i = 0; i < 9; ++i) Hf[i] = (float)H[i];
+    if (s_ref32) {
+      float K4f[9];
+      for (int i = 0; i < 9; ++i) K4f[i] = (float)K4d[i];
+      ref32::plane_homography(K4f, s_K4i, s_Tl, sd, Hf);
     }
+    for (int i = 0; i < 9; ++i) H4_out[((size_t)n * D + d) * 9 + i] = Hf[i];
     float *inc = Hinc_out + ((size_t)n * D + d) * 9;
     if (d == 0) {
       for (int i = 0; i < 9; ++i) inc[i] = (i % 4 == 0) ? 1.0f : 0.0f;
@@ -153,8 +277,15 @@ __global__ __launch_bounds__(SETUP_THREADS) void plane_sweep_setup_kernel(
       float sp = (float)(d - 1) * delta;
       double Hp[9], Hpf[9], Hpinv[9], Hcf[9], Hi[9];
       plane_homography(K4d, K4inv, Rl, tl, (double)sp, Hp);
+      float Hpr[9];
+      for (int i = 0; i < 9; ++i) Hpr[i] = (float)Hp[i];
+      if (s_ref32) {
+        float K4f[9];
+        for (int i = 0; i < 9; ++i) K4f[i] = (float)K4d[i];
+        ref32::plane_homography(K4f, s_K4i, s_Tl, sp, Hpr);
+      }
       for (int i = 0; i < 9; ++i) {
-        Hpf[i] = (double)(float)Hp[i];
+        Hpf[i] = (double)Hpr[i];
         Hcf[i] = (double)Hf[i];
       }
       inv3(Hpf, Hpinv);
