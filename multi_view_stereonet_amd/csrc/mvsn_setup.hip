@@ -1,7 +1,8 @@
 // Plane-sweep set-up: baseline normalisation, idepth samples, homography families.
-// One workgroup per chain; the geometry is evaluated in double and rounded once, the idepth
-// samples and the incremental homographies start from fp32-rounded values exactly where the
-// reference's fp32 pipeline rounds them (see include/mvsn_hip.h for the call sites replaced).
+// One workgroup per chain; the idepth samples come from a double evaluation that starts from fp32-rounded
+// values exactly where the reference's fp32 pipeline rounds them; the homographies the kernels consume (H at
+// levels 0 and 4, H_inc) follow the reference's own fp32 operation order (namespace ref32 below; the double
+// evaluation remains for intrinsics of another form).  include/mvsn_hip.h names the call sites replaced.
 #include "mvsn_common.h"
 
 #ifndef MVSN_SETUP_FP64_H   // A/B aid: 1 = the homographies from the fp64 evaluation, rounded once (rounds 1-5)
@@ -51,11 +52,17 @@ __device__ inline void plane_homography(const double *K3, const double *K3inv, c
 // reference entered there (profiles/r06_parity/).  What torch's CPU path does, found by matching bits on the host:
 //   * inverse(T) on a contiguous (B,4,4) tensor = ATen's linalg_solve_ex shortcut: LU of the TRANSPOSE (right-looking,
 //     first-maximum partial pivoting, FMA updates, a column scaled by the reciprocal pivot -- except the last,
-//     one-element column, which is divided), then getrs with trans = 'T' on the identity (FMA; the forward solve
-//     takes its products in ascending, the backward solve in DESCENDING order of the unknowns; reciprocal diagonal), then
-//     the row interchanges in reverse.  The LU matches MKL's bit for bit on 400 of 400 test poses, rotation and
-//     translation of the inverse in all but one of their 4800 entries; cancellation residues (entries of magnitude 1e-9
-//     that are 0 in exact arithmetic) may differ -- they move H by < 4e-9;
+//     one-element column, which is divided), then getrs with trans = 'T' on the identity, then the row interchanges in
+//     reverse.  MKL's small-matrix solve is neither a plain FMA chain nor a plain rounded one; unknown by unknown
+//     (each formula matched on 1200 of 1200 random cases, the whole inverse on 8000 of 8000 entries of random matrices
+//     and every entry of the test poses, residues included -- tests/test_reference_geometry_cpu.py):
+//       U^T y = e_c   reciprocal diagonal; products rounded and subtracted one by one; only y3's last term is fused;
+//       L^T x = y     x3 = y3; x2 = fma(-l32, x3, y2); x1 = y1 - fma(l21, x2, l31 x3);
+//                     x0 = y0 - fma(l30, x3, fma(l10, x1, l20 x2))      (a dot product, first product rounded);
+//   * inverse(H[:, d-1].unsqueeze(1)) of a plane's 3x3 homographies (multi_view_stereonet.py:281; the slice of the
+//     reference's permuted (D,B,3,3) family is contiguous for every batch size, so this is the same shortcut): LU of
+//     the transpose as above; y without a fused operation; x2 = y2; x1 = fma(-l21, x2, y1);
+//     x0 = y0 - fma(l10, x1, l20 x2)       (5400 of 5400 entries of random matrices, every H tried);
 //   * inverse(K[:, :3, :3]) of an upper-triangular intrinsics matrix = LAPACK strti2: reciprocal diagonal,
 //     -(c * (1 / f)) above it;
 //   * (N,3,3) @ (N,3,3) = ATen's small-matrix bmm: acc = 0, acc += a[i][k] * b[k][j] for k = 0, 1, 2, every operation rounded.
@@ -84,25 +91,78 @@ __device__ inline void inverse_pose(const float *T, float *X) {
     for (int i = j + 1; i < 4; ++i)
       for (int k = j + 1; k < 4; ++k) L[i * 4 + k] = __builtin_fmaf(-L[i * 4 + j], L[j * 4 + k], L[i * 4 + k]);
   }
+  const float r0 = 1.0f / L[0], r1 = 1.0f / L[5], r2 = 1.0f / L[10], r3 = 1.0f / L[15];
   for (int c = 0; c < 4; ++c) {
     float b[4] = {0.f, 0.f, 0.f, 0.f};
     b[c] = 1.0f;
-    for (int i = 0; i < 4; ++i) {      // U^T y = e_c
-      float t = b[i];
-      for (int k = 0; k < i; ++k) t = __builtin_fmaf(-L[k * 4 + i], b[k], t);
-      b[i] = t * (1.0f / L[i * 4 + i]);
-    }
-    for (int i = 3; i >= 0; --i) {     // L^T x = y (unit diagonal); the products leave b[i] from the LAST unknown down
-      float t = b[i];                  // (column-oriented back substitution: x3's column first -- the order matters to the bit)
-      for (int k = 3; k > i; --k) t = __builtin_fmaf(-L[k * 4 + i], b[k], t);
-      b[i] = t;
-    }
+    // U^T y = e_c (L[k * 4 + i], k < i, is u_ki)
+    const float y0 = b[0] * r0;
+    const float p01 = L[1] * y0;
+    const float y1 = (b[1] - p01) * r1;
+    const float p12 = L[6] * y1, p02 = L[2] * y0;
+    const float y2 = ((b[2] - p12) - p02) * r2;
+    const float p13 = L[7] * y1, p03 = L[3] * y0;
+    const float y3 = __builtin_fmaf(-L[11], y2, (b[3] - p13) - p03) * r3;
+    // L^T x = y (unit diagonal; L[k * 4 + i], k > i, is l_ki)
+    float z[4];
+    z[3] = y3;
+    z[2] = __builtin_fmaf(-L[14], z[3], y2);
+    const float p31 = L[13] * z[3];
+    z[1] = y1 - __builtin_fmaf(L[9], z[2], p31);
+    const float p20 = L[8] * z[2];
+    z[0] = y0 - __builtin_fmaf(L[12], z[3], __builtin_fmaf(L[4], z[1], p20));
     for (int j = 3; j >= 0; --j)
       if (ip[j] != j) {
-        const float t = b[j];
-        b[j] = b[ip[j]], b[ip[j]] = t;
+        const float t = z[j];
+        z[j] = z[ip[j]], z[ip[j]] = t;
       }
-    for (int i = 0; i < 4; ++i) X[i * 4 + c] = b[i];
+    for (int i = 0; i < 4; ++i) X[i * 4 + c] = z[i];
+  }
+}
+
+// torch.inverse of one 3x3 homography (see above); M and X row-major
+__device__ inline void inverse3(const float *M, float *X) {
+#pragma clang fp contract(off)
+  float L[9];
+  int ip[3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) L[i * 3 + j] = M[j * 3 + i];
+  for (int j = 0; j < 3; ++j) {
+    int p = j;
+    float m = fabsf(L[j * 3 + j]);
+    for (int i = j + 1; i < 3; ++i)
+      if (fabsf(L[i * 3 + j]) > m) m = fabsf(L[i * 3 + j]), p = i;
+    ip[j] = p;
+    if (p != j)
+      for (int k = 0; k < 3; ++k) {
+        const float t = L[j * 3 + k];
+        L[j * 3 + k] = L[p * 3 + k], L[p * 3 + k] = t;
+      }
+    const float piv = L[j * 3 + j], r = 1.0f / piv;
+    for (int i = j + 1; i < 3; ++i) L[i * 3 + j] = (2 - j <= 1) ? L[i * 3 + j] / piv : L[i * 3 + j] * r;
+    for (int i = j + 1; i < 3; ++i)
+      for (int k = j + 1; k < 3; ++k) L[i * 3 + k] = __builtin_fmaf(-L[i * 3 + j], L[j * 3 + k], L[i * 3 + k]);
+  }
+  const float r0 = 1.0f / L[0], r1 = 1.0f / L[4], r2 = 1.0f / L[8];
+  for (int c = 0; c < 3; ++c) {
+    float b[3] = {0.f, 0.f, 0.f};
+    b[c] = 1.0f;
+    const float y0 = b[0] * r0;
+    const float p01 = L[1] * y0;
+    const float y1 = (b[1] - p01) * r1;
+    const float p12 = L[5] * y1, p02 = L[2] * y0;
+    const float y2 = ((b[2] - p12) - p02) * r2;
+    float z[3];
+    z[2] = y2;
+    z[1] = __builtin_fmaf(-L[7], z[2], y1);
+    const float p20 = L[6] * z[2];
+    z[0] = y0 - __builtin_fmaf(L[3], z[1], p20);
+    for (int j = 2; j >= 0; --j)
+      if (ip[j] != j) {
+        const float t = z[j];
+        z[j] = z[ip[j]], z[ip[j]] = t;
+      }
+    for (int i = 0; i < 3; ++i) X[i * 3 + c] = z[i];
   }
 }
 
@@ -292,7 +352,14 @@ __global__ __launch_bounds__(SETUP_THREADS) void plane_sweep_setup_kernel(
       }
       inv3(Hpf, Hpinv);
       mul3(Hpinv, Hcf, Hi);
-      for (int i = 0; i < 9; ++i) inc[i] = (float)Hi[i];
+      float Hif[9];
+      for (int i = 0; i < 9; ++i) Hif[i] = (float)Hi[i];
+      if (s_ref32) {   // inverse(H[d-1]) @ H[d] as torch evaluates it (multi_view_stereonet.py:281-282)
+        float Hpi[9];
+        ref32::inverse3(Hpr, Hpi);
+        ref32::mm3(Hpi, Hf, Hif);
+      }
+      for (int i = 0; i < 9; ++i) inc[i] = Hif[i];
     }
   }
 }

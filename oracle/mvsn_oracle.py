@@ -211,7 +211,11 @@ def feature_refiner(w: Weights, prefix: str, image: torch.Tensor, feats: torch.T
 
 
 def inv3x3(M: torch.Tensor) -> torch.Tensor:
-    return torch.linalg.inv(M)
+    """torch.inverse of a plane's homographies as the reference calls it (multi_view_stereonet.py:281): its H family is
+    a permuted (D,B,3,3) tensor (:192), so the slice `H[:, d-1]` is CONTIGUOUS for every batch size and ATen's inverse
+    takes its transposed-LU shortcut; this oracle's (B,D,3,3) slice is strided for B > 1 and would take ATen's other
+    route, which rounds differently (4e-5 of a depth map on noise frames) -- hence the copy."""
+    return torch.linalg.inv(M.contiguous())
 
 
 def incremental_feature_volume(w: Weights, T: torch.Tensor, K_pyr: List[torch.Tensor],
@@ -232,7 +236,7 @@ def incremental_feature_volume(w: Weights, T: torch.Tensor, K_pyr: List[torch.Te
         cap["plane0_features"] = f
     planes = [f]
     for d in range(1, D):
-        H_inc = inv3x3(H[:, d - 1]) @ H[:, d]
+        H_inc = inv3x3(H[:, d - 1]) @ H[:, d].contiguous()
         moved, _ = homography_warp(planes[-1], H_inc[:, None])
         planes.append(feature_refiner(w, "right_feature_extractor.refiner", image_vol[:, :, d], moved[:, :, 0]))
     vol = torch.stack(planes, 2)

@@ -24,6 +24,7 @@ Fixtures:
   gc2_gta_512x256_d64_s1.npz    BASELINE config 2 (one source view): outputs only
   gc3_gta_512x256_d64_s5.npz    BASELINE config 3 (five source views): outputs only
   gc5_gta_1024x512_d128_s4.npz  BASELINE config 5 geometry (fp32 reference): idepth_0 (fp32), idepth_4, mask_4
+  g11_incremental_homographies.npz  every homography the reference hands its warper during a forward (H0, H family, H_inc)
 
     python tests/golden/make_golden.py [name-prefix ...]     # e.g. "gc" regenerates only the gc* fixtures
 """
@@ -376,6 +377,52 @@ def consistency_pins(name):
     print(name, "ok", "loss", d["left_right_loss"], [(int(m.sum()), m.numel()) for m in left_occ])
 
 
+INC_CASES = [  # (tag, rows, cols, D, S, B, seed, jitter): the golden forwards' geometry + two batched, jittered families
+    ("headline", 256, 512, 64, 2, 1, 7, 0.0), ("config4", 480, 640, 96, 1, 1, 9, 0.0), ("config5", 512, 1024, 128, 4, 1, 25, 0.0),
+    ("config2", 256, 512, 64, 1, 1, 21, 0.0), ("config3", 256, 512, 64, 5, 1, 23, 0.0),
+    ("b2_jitter", 80, 96, 8, 2, 2, 2, 0.3), ("b2_wide_jitter", 256, 512, 64, 2, 2, 40, 0.5)]
+
+
+def incremental_homography_pins(name):
+    """Every homography the reference's PlaneSweepWarper is HANDED during a forward (multi_view_stereonet.py:254-283):
+    call 0 of a source = the level-0 plane-0 matrix, call 1 = the level-4 family, calls 2.. = the incremental
+    `inverse(H[d-1]) @ H[d]` of every step -- captured by a pre-hook on the warper, so the values are the reference's own
+    (its tensor layouts, hence its ATen paths, included).  Inputs are regenerated from the seeds by the tests."""
+    net = ref_net("gta_sfm_150epochs")
+    d = {}
+    for tag, rows, cols, D, S, B, seed, jitter in INC_CASES:
+        batch = synthetic.make_batch(rows, cols, S, batch=B, seed=seed, pose_jitter=jitter)
+        seen = []
+        hook = net.right_feature_extractor.warper.register_forward_pre_hook(lambda m, i: seen.append(i[1].clone()))
+        spy = {}
+        orig_samples = ref_mod.create_idepth_samples
+
+        def samples_spy(*a, **k):
+            r = orig_samples(*a, **k)
+            spy.setdefault("samples", []).append(r.clone())
+            return r
+        ref_mod.create_idepth_samples = samples_spy
+        try:
+            inputs, _, _ = run_reference(net, batch, D, capture=False)
+        finally:
+            hook.remove()
+            ref_mod.create_idepth_samples = orig_samples
+        assert len(seen) == S * (D + 1), (len(seen), S, D)
+        for s in range(S):
+            calls = seen[s * (D + 1):(s + 1) * (D + 1)]
+            d[f"{tag}_H0_{s}"] = npy(calls[0])                                  # (B,1,3,3)
+            d[f"{tag}_H4_{s}"] = npy(calls[1])                                  # (B,D,3,3)
+            d[f"{tag}_Hinc_{s}"] = npy(torch.cat(calls[2:], 1))                 # (B,D-1,3,3)
+            d[f"{tag}_samples_{s}"] = npy(spy["samples"][s])                    # (B,D)
+            # the pose as the reference's unpacker hands it over (translations over the first source's baseline,
+            # multi_view_stereonet_utils.py:597-604): torch's reduction there rounds differently from host to host, so
+            # the tests take it from here instead of re-deriving it on whatever host they run on
+            d[f"{tag}_T_{s}"] = npy(inputs["T_right_in_left"][s])               # (B,4,4)
+        d[f"{tag}_meta"] = np.array([rows, cols, D, S, B, seed, int(round(jitter * 100))], np.int64)
+    np.savez_compressed(os.path.join(HERE, name), **d)
+    print(name, "ok")
+
+
 def main():
     torch.set_num_threads(8)
     G = "gta_sfm_150epochs"
@@ -395,6 +442,7 @@ def main():
         ("gc3_gta_512x256_d64_s5.npz", lambda n: outputs_only(n, G, 256, 512, 64, 5, seed=23, slim=True)),
         ("gc5_gta_1024x512_d128_s4.npz", lambda n: outputs_only(n, G, 512, 1024, 128, 4, seed=25, slim=True)),
         ("g9_two_view_consistency.npz", lambda n: consistency_pins(n)),
+        ("g11_incremental_homographies.npz", lambda n: incremental_homography_pins(n)),
     ]
     want = sys.argv[1:]
     for name, job in jobs:
