@@ -60,14 +60,19 @@ def test_mfma_fragment_mapping():
     assert lib.mvsn_selftest_mfma(_native.stream()) == 0, lib.mvsn_last_error()
 
 
-@pytest.mark.parametrize("rows,cols,S,B,D", [(64, 128, 1, 1, 16), (256, 512, 2, 2, 64), (480, 640, 1, 1, 96),
-                                              (80, 96, 2, 3, 8)])
-def test_plane_sweep_setup(rows, cols, S, B, D):
+@pytest.mark.parametrize("rows,cols,S,B,D,skew", [(64, 128, 1, 1, 16, 0.0), (256, 512, 2, 2, 64, 0.0), (480, 640, 1, 1, 96, 0.0),
+                                                   (80, 96, 2, 3, 8, 0.0), (256, 512, 2, 2, 64, 0.7), (80, 96, 2, 3, 8, 0.3)])
+def test_plane_sweep_setup(rows, cols, S, B, D, skew):
+    """`skew` != 0: intrinsics with a shear term are not of the form the reference-order path (ref32, csrc/mvsn_setup.hip)
+    covers -- the kernel's double-precision evaluation, rounded once, must serve them inside the same tolerances."""
     eng = net_for("gta_sfm_150epochs").engine()
     batch = synthetic.make_batch(rows, cols, S, batch=B, seed=3, pose_jitter=0.3)
     inp = snu.multi_view_unpack_batch(batch, torch.device("cpu"), 5)
     r4, c4 = inp["left_image_pyr"][4].shape[-2:]
     T = torch.cat(inp["T_right_in_left"], 0)
+    for lvl in (0, 4):
+        inp["K_pyr"][lvl] = inp["K_pyr"][lvl].clone()
+        inp["K_pyr"][lvl][:, 0, 1] = skew
     K0, K4 = inp["K_pyr"][0].repeat(S, 1, 1), inp["K_pyr"][4].repeat(S, 1, 1)
     samples, H4, Hinc, H0, base = eng.plane_sweep_setup(T.to(DEV), K0.to(DEV), K4.to(DEV), r4, c4, D)
     # oracle: renormalise per source, then the reference pipeline
