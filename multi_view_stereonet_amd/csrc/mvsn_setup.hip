@@ -203,9 +203,62 @@ __device__ inline void plane_homography(const float *K3, const float *Ki, const 
   mm3(K3, tmp, H);
 }
 
+// The maximum idepth of a chain (stereo/image_predictor.py:120-209 from multi_view_stereonet.py:139-147) as the
+// reference's fp32 tensor program evaluates it, pixel by pixel: every ATen elementwise op rounds; `matmul(KRKinv,
+// xyz_pix)` is MKL's sgemm -- per output a product and two fused multiply-adds in the order k = 0, 1, 2 -- unless
+// 3 * 3 * P < 400, where ATen's small-matrix loop runs instead (no fused operation).  One thing is NOT reproduced:
+// torch's vectorised sqrt (MKL VML) is an ulp off the correctly rounded root for 0.7 % of its arguments; the mean over
+// the pixels absorbs it (tests/test_reference_geometry_cpu.py: 204 of 204 chains, tests/golden/g11: 21 of 21).
+struct MaxIdepth {
+  float M[9], Kt[3];   // K R K^-1 and the translation column of K T_left_in_right (both by ATen's naive small products)
+  float disp;          // D - 1
+  int naive;           // 9 P < 400
+};
+
+__device__ inline float max_idepth_pixel(const MaxIdepth &g, float x, float y) {
+#pragma clang fp contract(off)
+  float inf[3], far[3];
+  const float x2 = x * 1e2f, y2 = y * 1e2f;
+  for (int i = 0; i < 3; ++i) {
+    const float m0 = g.M[i * 3], m1 = g.M[i * 3 + 1], m2 = g.M[i * 3 + 2];
+    if (g.naive) {
+      const float a0 = m0 * x, a1 = m1 * y;
+      inf[i] = (a0 + a1) + m2;
+      const float f0 = m0 * x2, f1 = m1 * y2, f2 = m2 * 1e2f;
+      far[i] = (f0 + f1) + f2;
+    } else {
+      const float a0 = m0 * x;
+      inf[i] = __builtin_fmaf(m2, 1.0f, __builtin_fmaf(m1, y, a0));
+      const float f0 = m0 * x2;
+      far[i] = __builtin_fmaf(m2, 1e2f, __builtin_fmaf(m1, y2, f0));
+    }
+    far[i] = far[i] + g.Kt[i];
+  }
+  const float infx = inf[0] / inf[2], infy = inf[1] / inf[2];
+  const float farx = far[0] / far[2], fary = far[1] / far[2];
+  const float dx = farx - infx, dy = fary - infy;
+  const float dxx = dx * dx, dyy = dy * dy;
+  const float norm = sqrtf(dxx + dyy);
+  const float den = norm + 1e-6f;
+  const float lx = dx / den, ly = dy / den;
+  const float w0 = g.M[6] * x, w1 = g.M[7] * y;
+  const float wz = (w0 + w1) + g.M[8];
+  const float sx = g.disp * lx, sy = g.disp * ly;
+  const float ux = infx + sx, uy = infy + sy;
+  const float vx = g.Kt[2] * ux, vy = g.Kt[2] * uy;
+  const float A0 = g.Kt[0] - vx, A1 = g.Kt[1] - vy;
+  const float wd = wz * g.disp;
+  const float b0 = wd * lx, b1 = wd * ly;
+  const float n0 = A0 * b0, n1 = A1 * b1, d0 = A0 * A0, d1 = A1 * A1;
+  float idp = (n0 + n1) / (d0 + d1);
+  idp = (norm < 1e-6f ? 0.0f : 1.0f) * idp;       // (~mask).float() * idepth: a NaN stays a NaN, as there
+  return (idp > 0.0f ? 1.0f : 0.0f) * idp;        // (x > 0).float() * x
+}
+
 }  // namespace ref32
 
 constexpr int SETUP_THREADS = 256;
+constexpr int SETUP_MAX_PIXELS = 8192;   // level-4 pixels the reference-order sample path holds in LDS (else: the double path)
 
 // Where a chain's pose and intrinsics live: per chain (T (N,4,4), K (N,4,4)) or, `per_source`, as the forward holds
 // them -- one (B,4,4) pose tensor per source view and the B reference images' intrinsics shared by their S chains
@@ -229,8 +282,11 @@ __global__ __launch_bounds__(SETUP_THREADS) void plane_sweep_setup_kernel(
   __shared__ double s_sum[SETUP_THREADS];
   __shared__ int s_cnt[SETUP_THREADS];
   __shared__ float s_top;
-  __shared__ float s_Tl[16], s_K4i[9];   // ref32: the inverted (normalised) pose, the level-4 intrinsics' inverse
+  __shared__ float s_Tl[16], s_K4i[9], s_K0i[9];   // ref32: the inverted (normalised) pose, the intrinsics' inverses
   __shared__ int s_ref32;                // ... and whether the intrinsics have the form that path covers
+  __shared__ ref32::MaxIdepth s_g;       // ref32 sample path: K R K^-1, K t, D - 1
+  __shared__ float s_m[SETUP_MAX_PIXELS];   // ... its per-pixel idepths, summed in torch's order below
+  __shared__ float s_lane[32];
 
   // --- baseline renormalisation in fp32, as multi_view_stereonet.py:566-571 -------------------
   float tx = T[3], ty = T[7], tz = T[11];
@@ -254,6 +310,43 @@ __global__ __launch_bounds__(SETUP_THREADS) void plane_sweep_setup_kernel(
   double K4inv[9];
   inv3(K4d, K4inv);
 
+  // --- the reference-order pieces every later step shares (ref32), by one thread --------------------------------------
+  const int P = rows4 * cols4;
+  if (tid == 0) {
+    float Tn[16], K0f[9], K4f[9];
+    for (int i = 0; i < 16; ++i) Tn[i] = T[i];
+    Tn[3] = tn[0], Tn[7] = tn[1], Tn[11] = tn[2];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) K0f[i * 3 + j] = K0[i * 4 + j], K4f[i * 3 + j] = K4[i * 4 + j];
+    ref32::inverse_pose(Tn, s_Tl);
+    const bool ok = ref32::inverse_intrinsics(K0f, s_K0i) && ref32::inverse_intrinsics(K4f, s_K4i) && !MVSN_SETUP_FP64_H;
+    s_ref32 = ok ? 1 : 0;
+    if (ok) {
+#pragma clang fp contract(off)
+      // disparity_to_idepth's own matrices: inverse(K) of the 4x4, K R K^-1 and (K T_left_in_right)[:3, 3] by ATen's
+      // naive small products (image_predictor.py:148-160)
+      float K4x4[16], Kinv[16], Kinv3[9], Tl3[9], tmp3[9];
+      for (int i = 0; i < 16; ++i) K4x4[i] = K4[i];
+      ref32::inverse_pose(K4x4, Kinv);
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Kinv3[i * 3 + j] = Kinv[i * 4 + j], Tl3[i * 3 + j] = s_Tl[i * 4 + j];
+      ref32::mm3(Tl3, Kinv3, tmp3);
+      ref32::mm3(K4f, tmp3, s_g.M);
+      for (int i = 0; i < 3; ++i) {
+        float acc = 0.f;
+        for (int k = 0; k < 4; ++k) {
+          const float prod = K4x4[i * 4 + k] * s_Tl[k * 4 + 3];
+          acc = acc + prod;
+        }
+        s_g.Kt[i] = acc;
+      }
+      s_g.disp = (float)(D - 1);
+      s_g.naive = 9 * P < 400;
+    }
+  }
+  __syncthreads();
+  const bool ref_samples = s_ref32 && P >= 8 && P <= SETUP_MAX_PIXELS;   // (rows shorter than one vector: another ATen sum)
+
   // --- maximum idepth: mean over pixels of the idepth that yields D-1 px of disparity ----------
   // (stereo/image_predictor.py:148-207)
   double M[9], tmp[9];
@@ -264,8 +357,7 @@ __global__ __launch_bounds__(SETUP_THREADS) void plane_sweep_setup_kernel(
   const double disp = (double)(D - 1);
   double acc = 0.0;
   int cnt = 0;
-  const int P = rows4 * cols4;
-  for (int p = tid; p < P; p += SETUP_THREADS) {
+  for (int p = tid; p < P && !ref_samples; p += SETUP_THREADS) {
     double x = (double)(p % cols4), y = (double)(p / cols4);
     double i0 = M[0] * x + M[1] * y + M[2], i1 = M[3] * x + M[4] * y + M[5], i2 = M[6] * x + M[7] * y + M[8];
     double infx = i0 / i2, infy = i1 / i2;
@@ -283,8 +375,38 @@ __global__ __launch_bounds__(SETUP_THREADS) void plane_sweep_setup_kernel(
       cnt += 1;
     }
   }
+  if (ref_samples) {   // the reference's fp32 program per pixel; the sum below in torch's order
+    for (int p = tid; p < P; p += SETUP_THREADS) {
+      const float m = ref32::max_idepth_pixel(s_g, (float)(p % cols4), (float)(p / cols4));
+      s_m[p] = m;
+      cnt += m > 0.0f ? 1 : 0;
+    }
+  }
   s_sum[tid] = acc;
   s_cnt[tid] = cnt;
+  __syncthreads();
+  if (ref_samples && tid < 32) {
+    // torch.sum over a contiguous row of floats (ATen SumKernel.cpp, 8-float vectors): 4 x 8 lanes take the elements
+    // l, l + 32, l + 64, ... of the first (P / 32) * 32 in order, through a four-level cascade that folds level j - 1
+    // into level j every 16^j steps
+#pragma clang fp contract(off)
+    const int rounds = (P / 8) / 4;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int i = 0;
+    while (i + 16 <= rounds) {
+      for (int j = 0; j < 16; ++j, ++i) a0 = a0 + s_m[i * 32 + tid];
+      a1 = a1 + a0, a0 = 0.f;
+      if ((i & (15 << 4)) == 0) {
+        a2 = a2 + a1, a1 = 0.f;
+        if ((i & (15 << 8)) == 0) a3 = a3 + a2, a2 = 0.f;
+      }
+    }
+    for (; i < rounds; ++i) a0 = a0 + s_m[i * 32 + tid];
+    a0 = a0 + a1;
+    a0 = a0 + a2;
+    a0 = a0 + a3;
+    s_lane[tid] = a0;
+  }
   __syncthreads();
   for (int s = SETUP_THREADS / 2; s > 0; s >>= 1) {
     if (tid < s) {
@@ -295,6 +417,18 @@ __global__ __launch_bounds__(SETUP_THREADS) void plane_sweep_setup_kernel(
   }
   if (tid == 0) {
     float top = (float)s_sum[0] / (float)s_cnt[0];  // NaN when no pixel qualifies, as the reference
+    if (ref_samples) {
+#pragma clang fp contract(off)
+      const int vecs = P / 8, rounds = vecs / 4;
+      for (int v = rounds * 4; v < vecs; ++v)        // whole vectors beyond the four-lane rounds: into lane group 0
+        for (int l = 0; l < 8; ++l) s_lane[l] = s_lane[l] + s_m[v * 8 + l];
+      for (int k = 1; k < 4; ++k)
+        for (int l = 0; l < 8; ++l) s_lane[l] = s_lane[l] + s_lane[k * 8 + l];
+      float total = 0.f;
+      for (int p = vecs * 8; p < P; ++p) total = total + s_m[p];   // the scalar tail first, then the eight partial sums
+      for (int l = 0; l < 8; ++l) total = total + s_lane[l];
+      top = total / (float)s_cnt[0];
+    }
     if (top > 2.0f) top = 2.0f;
     if (1.0f / top < tn[2]) top = 1.0f / tn[2];      // keep samples in front of the source camera
     s_top = top;
@@ -305,14 +439,10 @@ __global__ __launch_bounds__(SETUP_THREADS) void plane_sweep_setup_kernel(
     inv3(K0d, K0inv);
     plane_homography(K0d, K0inv, Rl, tl, 0.0, H0);
     // the reference's own fp32 chain where the intrinsics have its form (ref32 above); the fp64 value otherwise
-    float Tn[16], K0f[9], K4f[9], K0i[9], H0f[9];
-    for (int i = 0; i < 16; ++i) Tn[i] = T[i];
-    Tn[3] = tn[0], Tn[7] = tn[1], Tn[11] = tn[2];
-    for (int i = 0; i < 9; ++i) K0f[i] = (float)K0d[i], K4f[i] = (float)K4d[i];
-    ref32::inverse_pose(Tn, s_Tl);
-    const bool ok = ref32::inverse_intrinsics(K0f, K0i) && ref32::inverse_intrinsics(K4f, s_K4i) && !MVSN_SETUP_FP64_H;
-    s_ref32 = ok ? 1 : 0;
-    if (ok) ref32::plane_homography(K0f, K0i, s_Tl, 0.0f, H0f);
+    float K0f[9], H0f[9];
+    for (int i = 0; i < 9; ++i) K0f[i] = (float)K0d[i];
+    const bool ok = s_ref32 != 0;
+    if (ok) ref32::plane_homography(K0f, s_K0i, s_Tl, 0.0f, H0f);
     for (int i = 0; i < 9; ++i) H0_out[(size_t)n * 9 + i] = ok ? H0f[i] : (float)H0[i];
   }
   __syncthreads();

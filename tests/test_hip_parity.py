@@ -166,14 +166,11 @@ def test_plane_sweep_setup_reproduces_the_captured_reference_homographies():
         got = {"samples": samples.cpu().numpy(), "H4": H4.cpu().numpy(), "Hinc": Hinc.cpu().numpy()[:, 1:],
                "H0": H0.cpu().numpy().reshape(S * B, 1, 3, 3)}
         assert np.array_equal(Hinc.cpu().numpy()[:, 0], np.broadcast_to(np.eye(3, dtype=np.float32), (S * B, 3, 3)))
-        # the idepth samples have their own path (the maximum idepth is a mean over the level-4 pixels: summed in double
-        # here, by torch's vectorised fp32 reduction there): equal bit for bit for most chains, an ulp or two apart for
-        # the rest (one source of config 3, one of config 5, some jittered poses of the 5x6 grid) -- the homographies of
-        # THOSE chains were built from another sample and are not compared here (plane 0 is: its idepth is 0)
+        # the idepth samples: the reference's fp32 tensor program per level-4 pixel and torch's own summation order
+        # (ref32::max_idepth_pixel and the cascade after it) -- every chain of the capture, bit for bit
         chain_ok = (got["samples"].view(np.int32) == want["samples"].view(np.int32)).all(1)
-        np.testing.assert_allclose(got["samples"], want["samples"], rtol=5e-7, atol=0)
         report.append(f"{tag}: samples of {int(chain_ok.sum())} of {S * B} chains equal")
-        assert chain_ok.sum() * 2 >= S * B, (tag, chain_ok)
+        assert chain_ok.all(), (tag, "samples", chain_ok, float(np.abs(got["samples"] - want["samples"]).max()))
         for k in ("H0", "H4", "Hinc"):
             rows_ok = chain_ok if k != "H0" else np.ones(S * B, bool)     # (plane 0: idepth 0 whatever the samples)
             same = (got[k].view(np.int32) == want[k].view(np.int32))[rows_ok]
