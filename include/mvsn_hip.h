@@ -50,10 +50,11 @@ const char *mvsn_last_error(void);
  * baseline renormalisation (:566-571) and the per-step torch.inverse/matmul (:281-282).
  *   T_right_in_left (N,4,4)  K_lvl0 (N,4,4)  K_lvl4 (N,4,4)
  *   idepth_samples (N,D)  H_lvl4 (N,D,3,3)  H_inc (N,D,3,3)  H_lvl0_plane0 (N,3,3)  baseline (N)
- * The three homography outputs carry the bits of the reference's own fp32 evaluation (torch's CPU inverse of the
- * pose, of the intrinsics and of H[d-1], its 3x3 products: csrc/mvsn_setup.hip, namespace ref32; pinned by
- * tests/golden/g11_incremental_homographies.npz) when the intrinsics are [[fx,0,cx],[0,fy,cy],[0,0,1]]; for any other
- * intrinsics they are a double-precision evaluation rounded once.
+ * The idepth samples and the three homography outputs carry the bits of the reference's own fp32 evaluation (its
+ * per-pixel tensor program and torch.sum's order; torch's CPU inverse of the pose, of the intrinsics and of H[d-1],
+ * its 3x3 products: csrc/mvsn_setup.hip, namespace ref32; pinned by tests/golden/g11_incremental_homographies.npz)
+ * when the intrinsics are [[fx,0,cx],[0,fy,cy],[0,0,1]]; for any other intrinsics they are a double-precision
+ * evaluation rounded once.
  * ------------------------------------------------------------------------------------------- */
 int mvsn_plane_sweep_setup(const float *T_right_in_left, const float *K_lvl0, const float *K_lvl4,
                            int n_chains, int rows4, int cols4, int num_idepth_samples,

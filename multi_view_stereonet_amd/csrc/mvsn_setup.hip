@@ -1,8 +1,10 @@
 // Plane-sweep set-up: baseline normalisation, idepth samples, homography families.
-// One workgroup per chain; the idepth samples come from a double evaluation that starts from fp32-rounded
-// values exactly where the reference's fp32 pipeline rounds them; the homographies the kernels consume (H at
-// levels 0 and 4, H_inc) follow the reference's own fp32 operation order (namespace ref32 below; the double
-// evaluation remains for intrinsics of another form).  include/mvsn_hip.h names the call sites replaced.
+// One workgroup per chain.  Everything the kernels downstream consume -- the idepth samples, H at levels 0 and 4,
+// H_inc -- is formed in the reference's own fp32 operation order (namespace ref32 below: torch's CPU inverses, small
+// products, sgemm and summation order, found by matching bits on the host and pinned by tests/golden/g11), so that the
+// outputs carry the reference's bits; a double-precision evaluation, rounded once where the reference's pipeline
+// rounds, remains for intrinsics of another form (and for level-4 grids outside 8 .. 8192 pixels: the samples).
+// include/mvsn_hip.h names the call sites replaced.
 #include "mvsn_common.h"
 
 #ifndef MVSN_SETUP_FP64_H   // A/B aid: 1 = the homographies from the fp64 evaluation, rounded once (rounds 1-5)

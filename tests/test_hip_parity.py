@@ -141,10 +141,10 @@ def test_plane_sweep_homographies_follow_the_reference_fp32_chain(rows, cols, S,
 
 
 def test_plane_sweep_setup_reproduces_the_captured_reference_homographies():
-    """Host-independent pin of the whole geometry chain: every matrix the REFERENCE handed its warper during the golden
-    forwards (tests/golden/g11_incremental_homographies.npz: level-0 plane-0 H, the level-4 family, every incremental
-    `inverse(H[d-1]) @ H[d]`; batches of one and two, jittered poses) against what `mvsn_plane_sweep_setup` emits for the
-    same inputs -- bit for bit."""
+    """Host-independent pin of the whole geometry chain (rows a3 / a4): the idepth samples and every matrix the REFERENCE
+    handed its warper during seven forwards (tests/golden/g11_incremental_homographies.npz: level-0 plane-0 H, the level-4
+    family, every incremental `inverse(H[d-1]) @ H[d]`; the golden configs, batches of one and two, jittered poses) against
+    what `mvsn_plane_sweep_setup` emits for the same inputs -- bit for bit, every chain."""
     eng = net_for("gta_sfm_150epochs").engine()
     fix = load_golden("g11_incremental_homographies.npz")
     report = []
