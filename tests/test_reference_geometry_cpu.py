@@ -1,9 +1,11 @@
 """What csrc/mvsn_setup.hip (namespace ref32) assumes about the reference's fp32 geometry, checked on the HOST against the torch
-that generated the fixtures: the operation order of torch's CPU `inverse` of a pose, of the intrinsics' inverse and of the 3x3
-products in `H = K (R + t idepth e3^T) K^-1` (stereo/image_predictor.py:446-459, multi_view_stereonet.py:167-194).  A plain numpy
-restatement of those orders -- the same one the kernel implements -- must reproduce the oracle's homographies bit for bit except
-cancellation residues.  If a future torch / MKL changes the order, this test says so (the kernel would then merely be one more
-correctly-behaved fp32 evaluation, a few ulps from the reference's, as it was before round 6)."""
+that generated the fixtures: the operation order of torch's CPU `inverse` of a pose, of the intrinsics and of a 3x3 homography, of
+its small matrix products, of `matmul(KRKinv, xyz_pix)` and of `torch.sum` (stereo/image_predictor.py:120-209, 400-461,
+multi_view_stereonet.py:131-194, 279-282).  A plain numpy restatement of those orders -- the same one the kernel implements --
+reproduces torch bit for bit (random matrices, poses, homographies), the oracle's idepth samples and homographies, and the capture
+of what the reference hands its warper (tests/golden/g11_incremental_homographies.npz).  If a future torch / MKL changes an order,
+these tests say so (the kernel would then merely be one more correctly-behaved fp32 evaluation, a few ulps from the reference's, as
+it was before round 6); the g11 comparisons are data against data and do not depend on the host."""
 import numpy as np
 import torch
 
